@@ -1,0 +1,146 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself (container-only).
+
+    python -m oracle.make_goldens
+
+The reference (/root/reference) is imported through oracle/ref_bootstrap.py, loaded with the
+deterministic weights of giga_amd/weights.py (seed recorded in each fixture) and run on seeded
+synthetic inputs (giga_amd/synth.py).  Only *data* is committed: inputs are reproducible from the
+seeds, outputs are stored (full or a fixed strided subset + float64 sums).  SURVEY.md section 8c G1-G5.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from giga_amd import synth, weights  # noqa: E402
+from oracle import ref_bootstrap  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+WEIGHT_SEED = 7
+LATTICE_SUBSET = np.arange(0, 64000, 64000 // 4096)[:4096] + (np.arange(4096) % 7)
+
+
+def sums(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item()], np.float64)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+    sd = weights.make_state_dict(WEIGHT_SEED)
+    net = ref_bootstrap.load_reference_giga(sd)
+
+    # ---- G1 encoder -------------------------------------------------------------------
+    x = torch.from_numpy(synth.tsdf_batch(0, 2))
+    planes = net.encode_inputs(x)
+    g1 = {"weight_seed": WEIGHT_SEED, "scenes": np.array([0, 1])}
+    for k in ("xz", "xy", "yz"):
+        g1[f"plane_{k}_s2"] = planes[k][:, :, ::2, ::2].numpy()
+        g1[f"plane_{k}_sums"] = sums(planes[k])
+        g1[f"plane_{k}_b0c5"] = planes[k][0, 5].numpy()          # one full channel image
+    np.savez_compressed(os.path.join(OUT, "g1_encoder.npz"), **g1)
+
+    # ---- G2 decoder on G1's planes, points incl. out-of-range -------------------------
+    p = torch.from_numpy(synth.query_points(0, 2, 2048, stream=1, half_width=0.6))
+    qual, rot, width, tsdf = net(x, p, p_tsdf=p)
+    raw = {h: getattr(net, h)(p, planes) for h in weights.HEADS}
+    g2 = {"weight_seed": WEIGHT_SEED, "qual": qual.numpy(), "rot": rot.numpy(),
+          "width": width.numpy(), "tsdf": tsdf.numpy()}
+    for h, v in raw.items():
+        g2["raw_" + h] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "g2_decoder.npz"), **g2)
+
+    # ---- G2b decoder only, on seeded random planes (isolates the decoder) -------------
+    rng = np.random.default_rng(4242)
+    rp = {k: torch.from_numpy(rng.standard_normal((2, 32, 40, 40)).astype(np.float32))
+          for k in ("xz", "xy", "yz")}
+    g2b = {"weight_seed": WEIGHT_SEED, "plane_seed": 4242}
+    for h in weights.HEADS:
+        g2b["raw_" + h] = getattr(net, h)(p, rp).numpy()
+    np.savez_compressed(os.path.join(OUT, "g2b_decoder_random_planes.npz"), **g2b)
+
+    # ---- G3 inference lattice (detection_implicit.predict) ----------------------------
+    ref_bootstrap.install()
+    lattice = torch.from_numpy(synth.inference_lattice())
+    x3 = torch.from_numpy(synth.tsdf_batch(5, 1))
+    q3, r3, w3 = net(x3, lattice)
+    g3 = {"weight_seed": WEIGHT_SEED, "scene": 5, "subset": LATTICE_SUBSET,
+          "qual": q3[0, LATTICE_SUBSET].numpy(), "rot": r3[0, LATTICE_SUBSET].numpy(),
+          "width": w3[0, LATTICE_SUBSET].numpy(),
+          "qual_sums": sums(q3), "rot_sums": sums(r3), "width_sums": sums(w3),
+          "lattice_first_last": lattice[0, [0, 1, 40, 1600, 63999]].numpy()}
+    np.savez_compressed(os.path.join(OUT, "g3_lattice.npz"), **g3)
+
+    # ---- G4 train step (scripts/train_giga.py:141-218): losses + per-tensor grad norms -
+    torch.set_grad_enabled(True)
+    B, M = 4, 2048
+    net.train()
+    x4 = torch.from_numpy(synth.tsdf_batch(10, B))
+    pos = torch.from_numpy(synth.query_points(10, B, 1, stream=2))
+    pos_occ = torch.from_numpy(synth.query_points(10, B, M, stream=3))
+    label, rots, width_t, occ = [torch.from_numpy(a) for a in synth.train_labels(10, B, M)]
+    out = net(x4, pos, p_tsdf=pos_occ)
+    # select + loss_fn, scripts/train_giga.py:154-195, evaluated with the reference's formulas
+    q_o, r_o, w_o, o_o = out
+    y_pred = (q_o.squeeze(-1), r_o.squeeze(1), w_o.squeeze(-1), torch.sigmoid(o_o))
+    import torch.nn.functional as F
+    lq = F.binary_cross_entropy(y_pred[0], label, reduction="none")
+    def quat(pr, t):
+        return 1.0 - torch.abs(torch.sum(pr * t, dim=1))
+    lr = torch.min(quat(y_pred[1], rots[:, 0]), quat(y_pred[1], rots[:, 1]))
+    lw = F.mse_loss(40 * y_pred[2], 40 * width_t, reduction="none")
+    lo = F.binary_cross_entropy(y_pred[3], occ, reduction="none").mean(-1)
+    loss = (lq + label * (lr + 0.01 * lw) + lo).mean()
+    net.zero_grad()
+    loss.backward()
+    g4 = {"weight_seed": WEIGHT_SEED, "first_scene": 10, "B": B, "M": M,
+          "loss_qual": lq.mean().item(), "loss_rot": lr.mean().item(),
+          "loss_width": lw.mean().item(), "loss_occ": lo.mean().item(), "loss_all": loss.item(),
+          "qual": q_o.detach().numpy(), "rot": r_o.detach().numpy(), "width": w_o.detach().numpy()}
+    names, norms = [], []
+    for n_, p_ in net.named_parameters():
+        names.append(n_)
+        norms.append(p_.grad.double().norm().item())
+    g4["grad_names"] = np.array(names)
+    g4["grad_norms"] = np.array(norms, np.float64)
+    g4["grad_fc_out_qual"] = net.decoder_qual.fc_out.weight.grad.numpy()
+    g4["grad_conv_in_w"] = net.encoder.conv_in.weight.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "g4_train_step.npz"), **g4)
+    torch.set_grad_enabled(False)
+    net.eval()
+
+    # ---- G5 edge cases -----------------------------------------------------------------
+    g5 = {"weight_seed": WEIGHT_SEED}
+    for name, val in (("zeros", 0.0), ("ones", 1.0)):
+        xe = torch.full((1, 40, 40, 40), val)
+        pl = net.encode_inputs(xe)
+        for k in ("xz", "xy", "yz"):
+            g5[f"{name}_plane_{k}_s4"] = pl[k][:, :, ::4, ::4].numpy()
+            g5[f"{name}_plane_{k}_sums"] = sums(pl[k])
+    # points exactly on the boundary, on cell centres (pixel centres of the align_corners grid)
+    lin = np.linspace(0.0, 1.0, 40)                       # pixel centres in normalised units
+    centres = ((lin - 0.5) * (1 + 10e-6)).astype(np.float32)
+    pe = np.stack([
+        np.array([-0.5, -0.5, -0.5]), np.array([0.5, 0.5, 0.5]), np.array([0.5, -0.5, 0.0]),
+        np.array([-0.5, 0.5, 0.25]), np.array([0.0, 0.0, 0.0]), np.array([0.7, -0.7, 0.1]),
+        np.array([centres[3], centres[17], centres[39]]), np.array([centres[0], centres[1], centres[20]]),
+    ]).astype(np.float32)[None]
+    pe_t = torch.from_numpy(pe)
+    x5 = torch.from_numpy(synth.tsdf_batch(3, 1))
+    qe, re_, we, te = net(x5, pe_t, p_tsdf=pe_t)
+    g5.update({"edge_points": pe, "edge_scene": 3, "edge_qual": qe.numpy(), "edge_rot": re_.numpy(),
+               "edge_width": we.numpy(), "edge_tsdf": te.numpy()})
+    np.savez_compressed(os.path.join(OUT, "g5_edges.npz"), **g5)
+
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
