@@ -1,0 +1,281 @@
+#!/usr/bin/env python
+"""Benchmark of the GIGA dense inference path on MI355X (driver contract in the task brief).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one forward pass of BASELINE.json configs[1] on every rank:
+    32 synthetic 40^3 TSDF scenes per GPU, the literal `train_giga` call shape
+    (1 grasp query point for the three grasp heads + 2048 occupancy queries per scene),
+    encoder + decoders in exact fp32 (fp32 MFMA), inputs resident in HBM, outputs left in HBM.
+Scenes are independent, so ranks are pure replicas on different scenes (weak scaling); the only
+collective is one all_gather of per-rank counters at the end (RCCL over xGMI).
+
+One JSON line is printed by rank 0; besides the contract keys it carries
+  roofline      - the dominant kernel of the timed workload, timed live with HIP events on the
+                  launch stream inside the timed steps
+  cpu_baseline  - the CPU oracle (a port of the reference's PyTorch path) on the host cores
+  extra         - config c4 (64 000 grasp queries/scene, f16-MFMA fused decoder) numbers
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MATRIX_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32-input MFMA == fp32 vector peak
+PEAK_F16_MFMA_TFLOPS = 2500.0         # dense f16/bf16 MFMA
+FLOP_ENCODER = 1_132_953_600          # SURVEY.md 8d / BASELINE.md section 4
+FLOP_HEAD = {"qual": 51_456, "rot": 51_648, "width": 51_456, "tsdf": 51_456}
+FLOP_GRASP3 = 154_560
+
+# U-Net layer table (kind, cin, cout, H, W): algorithmic FLOPs per image = 2*H*W*taps*cin*cout
+_CONV = [(9, 32, 32, 40), (9, 32, 32, 40), (9, 32, 64, 20), (9, 64, 64, 20), (9, 64, 128, 10), (9, 128, 128, 10),
+         (4, 128, 64, 10), (9, 128, 64, 20), (9, 64, 64, 20), (4, 64, 32, 20), (9, 64, 32, 40), (9, 32, 32, 40),
+         (1, 32, 32, 40)]
+STAGE_NAMES = ["convin_project", "plane_finalize"] + [
+    "unet.down0.conv1", "unet.down0.conv2+pool", "unet.down1.conv1", "unet.down1.conv2+pool", "unet.down2.conv1",
+    "unet.down2.conv2", "unet.up0.upconv", "unet.up0.conv1", "unet.up0.conv2", "unet.up1.upconv",
+    "unet.up1.conv1", "unet.up1.conv2", "unet.conv_final"]
+
+
+def stage_flops(stage, B):
+    """Algorithmic FLOPs of one launch of encoder stage `stage` for B scenes."""
+    if stage == 0:
+        return 110_592_000 * B
+    if stage == 1:
+        return 0
+    taps, cin, cout, hw = _CONV[stage - 2]
+    return 2 * hw * hw * taps * cin * cout * 3 * B
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="scenes per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (MI355X); no CPU fallback for the timed path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from giga_amd import _capi, networks, synth, weights
+    from giga_amd.convonet import decode_heads
+
+    B, M = args.batch, 2048
+    sd = weights.make_state_dict(7)
+    net = networks.get_network("giga")
+    net.load_state_dict(sd)
+    net = net.to(dev).eval().set_precision("fp32")
+    first = rank * B                                     # each rank owns its own scenes
+    x = torch.from_numpy(synth.tsdf_batch(first, B)).to(dev)
+    pos = torch.from_numpy(synth.query_points(first, B, 1, stream=2)).to(dev)
+    pos_occ = torch.from_numpy(synth.query_points(first, B, M, stream=3)).to(dev)
+    blob = net.packed_blob(dev)
+    L = _capi.lib()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # -------- find the dominant kernel of the workload (untimed pre-pass, every stage probed once) ----
+    ev_a, ev_b = L.giga_event_create(), L.giga_event_create()
+    dec_ev = (L.giga_event_create(), L.giga_event_create())
+
+    def step(probe=None, dec_probe=None):
+        """One forward of the workload through the module API (vgn-compatible call)."""
+        with torch.no_grad():
+            if dec_probe is None:
+                return net(x, pos, p_tsdf=pos_occ, _probe=probe)
+            nhwc, _ = net.encoder.encode_nhwc(x, blob=blob, precision="fp32")
+            g = decode_heads(nhwc, pos, blob, 7, "fp32", True)
+            t = decode_heads(nhwc, pos_occ, blob, 8, "fp32", False, probe=dec_probe)
+        return g, t
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    stage_ms = []
+    ms = __import__("ctypes").c_float()
+    for st in range(15):
+        step(probe=(st, ev_a, ev_b))
+        _capi.check(L.giga_event_elapsed_ms(ev_a, ev_b, __import__("ctypes").byref(ms)), "event")
+        stage_ms.append(ms.value)
+    step(dec_probe=dec_ev)
+    _capi.check(L.giga_event_elapsed_ms(dec_ev[0], dec_ev[1], __import__("ctypes").byref(ms)), "event")
+    dec_ms_once = ms.value
+    dom = int(np.argmax(stage_ms))
+
+    # -------- timed region ----------------------------------------------------------------------------
+    for _ in range(args.warmup):
+        step()
+    K = args.steps
+    evs = [(L.giga_event_create(), L.giga_event_create()) for _ in range(K)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(probe=(dom, evs[i][0], evs[i][1]))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dom_ms = []
+    for a, b in evs:
+        _capi.check(L.giga_event_elapsed_ms(a, b, __import__("ctypes").byref(ms)), "event")
+        dom_ms.append(ms.value)
+        L.giga_event_destroy(a); L.giga_event_destroy(b)
+    t_elapsed = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t_elapsed, op=dist.ReduceOp.MAX)
+        # the north-star's single data-path-free collective: gather per-rank counters
+        counters = torch.tensor([float(B * K), elapsed], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(counters) for _ in range(world)]
+        dist.all_gather(gathered, counters)
+        total_scenes = sum(float(c[0]) for c in gathered)
+    else:
+        total_scenes = float(B * K)
+    T = float(t_elapsed.item())
+    scenes_per_s = total_scenes / T
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    dom_avg_ms = float(np.mean(dom_ms))
+    dom_flops = stage_flops(dom, B)
+    achieved = dom_flops / (dom_avg_ms * 1e-3) / 1e12
+    flop_scene = FLOP_ENCODER + FLOP_GRASP3 * 1 + FLOP_HEAD["tsdf"] * M
+    points_per_scene = 1 * 3 + M          # head evaluations per scene
+    out = {
+        "metric": "scenes/sec",
+        "value": scenes_per_s,
+        "unit": "scenes/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": args.warmup,
+        "ms_per_step": T / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "c2: batch=32/GPU synthetic 40^3 TSDF, encoder + 3 grasp heads @1 query + "
+                               "occupancy head @2048 queries/scene (literal train_giga call), fp32 MFMA",
+                   "scenes_per_gpu_per_step": B, "occ_points_per_scene": M, "grasp_points_per_scene": 1,
+                   "parallelism": f"scene-sharded x{world} (replicas, one all_gather of counters)"},
+        "query_points_per_sec": scenes_per_s * points_per_scene,
+        "algorithmic_tflops": scenes_per_s * flop_scene / 1e12,
+        "roofline": {
+            "kernel": STAGE_NAMES[dom], "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
+            "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+            "avg_launch_ms": dom_avg_ms, "flops_per_launch": dom_flops,
+            "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) peak; events on the launch stream inside the timed steps",
+        },
+        "stage_ms": {STAGE_NAMES[i]: round(v, 4) for i, v in enumerate(stage_ms)},
+        "decoder_occ_ms": round(dec_ms_once, 4),
+    }
+
+    # -------- extra: c4 (64 000 grasp queries per scene, f16 MFMA fused decoder) ------------------------
+    if not args.no_extra:
+        try:
+            out["extra"] = {"c4": bench_c4(net, sd, dev, L, _capi, synth, decode_heads)}
+        except Exception as e:  # noqa: BLE001
+            out["extra"] = {"c4_error": f"{type(e).__name__}: {e}"}
+
+    # -------- CPU baseline: the oracle (port of the reference path) on the host cores -------------------
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sd, synth, M)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_c4(net, sd, dev, L, _capi, synth, decode_heads, Bc=32, steps=10):
+    import ctypes
+    N = 64000
+    net.set_precision("fp16")
+    blob = net.packed_blob(dev)
+    x = torch.from_numpy(synth.tsdf_batch(1000, Bc)).to(dev)
+    lat = torch.from_numpy(synth.inference_lattice()).to(dev).expand(Bc, -1, -1).contiguous()
+    ev = [(L.giga_event_create(), L.giga_event_create()) for _ in range(steps)]
+
+    def step(pr=None):
+        with torch.no_grad():
+            nhwc, _ = net.encoder.encode_nhwc(x, blob=blob, precision="fp16")
+            return decode_heads(nhwc, lat, blob, 7, "fp16", True, probe=pr)
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(ev[i])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms = ctypes.c_float()
+    dms = []
+    for a, b in ev:
+        _capi.check(L.giga_event_elapsed_ms(a, b, ctypes.byref(ms)), "event")
+        dms.append(ms.value)
+        L.giga_event_destroy(a); L.giga_event_destroy(b)
+    dec_ms = float(np.mean(dms))
+    flops = Bc * N * FLOP_GRASP3
+    ach = flops / (dec_ms * 1e-3) / 1e12
+    net.set_precision("fp32")
+    return {
+        "workload": f"c4: batch={Bc} scenes x 64000 lattice queries, 3 grasp heads, f16 MFMA decoder + f16 encoder",
+        "scenes_per_sec": Bc * steps / el, "query_points_per_sec": Bc * steps * N / el,
+        "ms_per_step": el / steps * 1e3, "dtype": "f16 operands / f32 accumulate",
+        "roofline": {"kernel": "decoder_f16_kernel", "bound": "mfma", "achieved": ach, "peak": PEAK_F16_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+                     "avg_launch_ms": dec_ms, "flops_per_launch": flops},
+    }
+
+
+def cpu_baseline(sd, synth, M, budget_s=20.0):
+    """Time the CPU oracle (oracle/giga_oracle.py, a port of the reference's PyTorch path pinned to
+    reference-generated goldens) on a bounded sample of the same workload."""
+    from oracle import giga_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Bs = 8
+    x = torch.from_numpy(synth.tsdf_batch(0, Bs))
+    pos = torch.from_numpy(synth.query_points(0, Bs, 1, stream=2))
+    pos_occ = torch.from_numpy(synth.query_points(0, Bs, M, stream=3))
+    with torch.no_grad():
+        O.model_forward(sd, x, pos, p_tsdf=pos_occ)          # warm-up
+        times = []
+        t_start = time.perf_counter()
+        while len(times) < 10 and time.perf_counter() - t_start < budget_s:
+            t0 = time.perf_counter()
+            O.model_forward(sd, x, pos, p_tsdf=pos_occ)
+            times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": Bs / med, "unit": "scenes/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} passes of {Bs} scenes (1 grasp query + {M} occupancy queries each), "
+                      f"torch {torch.__version__} CPU fp32, median", "ms_per_pass": med * 1e3}
+
+
+if __name__ == "__main__":
+    main()

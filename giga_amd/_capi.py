@@ -1,0 +1,112 @@
+"""ctypes binding of libgiga_hip.so (C ABI in include/giga_hip.h).
+
+The library is built in-tree (`giga_amd/lib/libgiga_hip.so`, see `giga_amd/build.py`) and is the ONLY
+compute path: there is no CPU or eager-PyTorch fallback.  Loading fails loudly if it is missing.
+torch must be imported first so that the HIP runtime the library binds to (SONAME libamdhip64.so.7)
+is the one PyTorch already loaded -- device pointers and streams are then shared.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL: shares torch's libamdhip64)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgiga_hip.so")
+
+HEAD_QUAL, HEAD_ROT, HEAD_WIDTH, HEAD_TSDF = 1, 2, 4, 8
+HEAD_BITS = {"decoder_qual": 1, "decoder_rot": 2, "decoder_width": 4, "decoder_tsdf": 8}
+PRECISION = {"fp32": 0, "fp16": 1}
+
+_lib = None
+
+_SIGNATURES = {
+    "giga_abi_version": (ctypes.c_int, []),
+    "giga_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "giga_param_count": (ctypes.c_size_t, [ctypes.c_int]),
+    "giga_packed_bytes": (ctypes.c_size_t, []),
+    "giga_pack_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_size_t]),
+    "giga_encoder_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "giga_encoder_workspace_layout": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "giga_encoder_forward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "giga_planes_pack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "giga_planes_unpack": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_void_p]),
+    "giga_decoder_forward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "giga_event_create": (ctypes.c_void_p, []),
+    "giga_event_destroy": (None, [ctypes.c_void_p]),
+    "giga_event_elapsed_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "giga_encoder_forward_probe": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                                  ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "giga_decoder_forward_probe": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.c_void_p]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+
+class GigaHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GigaHipError(
+                f"{LIB_PATH} not found: build it with `python -m giga_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if handle.giga_abi_version() != 1:
+            raise GigaHipError("libgiga_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise GigaHipError(f"{what} failed: {lib().giga_strerror(code).decode()} ({code})")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise GigaHipError(
+                "giga_amd runs only on a HIP device (tensor is on %s); there is no CPU fallback. "
+                "Use the reference PyTorch implementation for CPU execution." % t.device)
+
+
+def pack_weights(flat_params_cpu, head_present):
+    """flat fp32 CPU tensor (reference state-dict order) -> uint8 CPU tensor (fragment blob)."""
+    L = lib()
+    flat = flat_params_cpu.detach().to(dtype=torch.float32, device="cpu").contiguous()
+    n = L.giga_param_count(head_present)
+    if flat.numel() != n:
+        raise GigaHipError(f"expected {n} parameters for head set {head_present}, got {flat.numel()}")
+    blob = torch.empty(L.giga_packed_bytes(), dtype=torch.uint8)
+    check(L.giga_pack_weights(ptr(flat), flat.numel(), head_present, ptr(blob), blob.numel()),
+          "giga_pack_weights")
+    return blob

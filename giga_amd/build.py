@@ -1,0 +1,34 @@
+"""Build libgiga_hip.so in-tree with hipcc for gfx950:  python -m giga_amd.build [--force]"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "lib", "libgiga_hip.so")
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h", "Makefile"))]
+    srcs.append(os.path.join(os.path.dirname(HERE), "include", "giga_hip.h"))
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def build(force=False, verbose=False):
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=not verbose)
+    if force or _stale():
+        r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=not verbose, text=True)
+        if r.returncode != 0:
+            sys.stderr.write((r.stdout or "") + (r.stderr or ""))
+            raise RuntimeError("hipcc build of libgiga_hip.so failed")
+    if not os.path.exists(LIB):
+        raise RuntimeError("libgiga_hip.so missing after build")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

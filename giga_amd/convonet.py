@@ -1,0 +1,507 @@
+"""MI355X-native counterparts of the reference's `vgn.ConvONets` modules on the GIGA hot path.
+
+Same class names, constructor kwargs, `forward` signatures, tensor layouts and state-dict keys as
+the reference (paths relative to /root/reference/src/vgn):
+  * `LocalVoxelEncoder`               ConvONets/encoder/voxels.py:10-121
+  * `UNet`, `DownConv`, `UpConv`      ConvONets/encoder/unet.py:48-239       (parameter containers)
+  * `ResnetBlockFC`                   ConvONets/layers.py:6-47               (parameter container)
+  * `LocalDecoder`                    ConvONets/conv_onet/models/decoder.py:61-206
+  * `ConvolutionalOccupancyNetwork`   ConvONets/conv_onet/models/__init__.py:15-164
+  * `ConvolutionalOccupancyNetworkGeometry`                       ...__init__.py:166-226
+  * `get_model`                       ConvONets/conv_onet/config.py:15-91
+
+The torch.nn layers below only OWN parameters (so `load_state_dict` of a reference checkpoint works
+unchanged and initialisation matches the reference); all arithmetic runs in the hand-written HIP
+kernels of libgiga_hip.so through `giga_amd._capi`.  Inputs must live on a HIP device: there is no
+CPU path (use the reference for that).  Forward only in this round: calling with autograd enabled
+on parameters that require grad raises.
+"""
+import os
+
+import torch
+import torch.nn as nn
+from torch import distributions as dist
+
+from . import _capi
+
+RES = 40
+C_DIM = 32
+PLANES = ("xz", "xy", "yz")
+HEAD_NAMES = ("decoder_qual", "decoder_rot", "decoder_width", "decoder_tsdf")
+_DEFAULT_PRECISION = os.environ.get("GIGA_PRECISION", "fp32")
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers (names == reference state-dict keys)
+# ------------------------------------------------------------------------------------------------
+class ResnetBlockFC(nn.Module):
+    """layers.py:6-47 (size_in == size_out == size_h: no shortcut).  fc_1.weight zero-init (:37)."""
+
+    def __init__(self, size_in, size_out=None, size_h=None):
+        super().__init__()
+        size_out = size_in if size_out is None else size_out
+        size_h = min(size_in, size_out) if size_h is None else size_h
+        if not (size_in == size_out == size_h):
+            raise NotImplementedError("GIGA uses square ResnetBlockFC only")
+        self.size_in, self.size_h, self.size_out = size_in, size_h, size_out
+        self.fc_0 = nn.Linear(size_in, size_h)
+        self.fc_1 = nn.Linear(size_h, size_out)
+        self.shortcut = None
+        nn.init.zeros_(self.fc_1.weight)
+
+
+class DownConv(nn.Module):
+    """unet.py:48-72."""
+
+    def __init__(self, in_channels, out_channels, pooling=True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.pooling = in_channels, out_channels, pooling
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, padding=1)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
+
+
+class UpConv(nn.Module):
+    """unet.py:75-114 (merge_mode='concat', up_mode='transpose')."""
+
+    def __init__(self, in_channels, out_channels, merge_mode="concat", up_mode="transpose"):
+        super().__init__()
+        if merge_mode != "concat" or up_mode != "transpose":
+            raise NotImplementedError("GIGA uses concat/transpose UpConv only")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.upconv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size=2, stride=2)
+        self.conv1 = nn.Conv2d(2 * out_channels, out_channels, 3, padding=1)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
+
+
+class UNet(nn.Module):
+    """unet.py:117-239.  Only the GIGA configuration is supported by the kernels:
+    UNet(32, in_channels=32, depth=3, start_filts=32, merge_mode='concat')."""
+
+    def __init__(self, num_classes, in_channels=3, depth=5, start_filts=64, up_mode="transpose",
+                 merge_mode="concat", **kwargs):
+        super().__init__()
+        if (num_classes, in_channels, depth, start_filts, up_mode, merge_mode) != \
+                (32, 32, 3, 32, "transpose", "concat"):
+            raise NotImplementedError("libgiga_hip is specialised for GIGA's U-Net "
+                                      "(32->32, depth 3, start_filts 32, transpose/concat)")
+        self.num_classes, self.in_channels, self.start_filts, self.depth = \
+            num_classes, in_channels, start_filts, depth
+        downs, ups = [], []
+        outs = in_channels
+        for i in range(depth):
+            ins = in_channels if i == 0 else outs
+            outs = start_filts * (2 ** i)
+            downs.append(DownConv(ins, outs, pooling=i < depth - 1))
+        for i in range(depth - 1):
+            ins = outs
+            outs = ins // 2
+            ups.append(UpConv(ins, outs, up_mode=up_mode, merge_mode=merge_mode))
+        self.down_convs = nn.ModuleList(downs)
+        self.up_convs = nn.ModuleList(ups)
+        self.conv_final = nn.Conv2d(outs, num_classes, 1)
+        for m in self.modules():                      # unet.py:213-222
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_normal_(m.weight)
+                nn.init.constant_(m.bias, 0)
+
+
+class PlaneDict(dict):
+    """The reference's {'xz','xy','yz': (B,32,40,40)} dict, plus the NHWC image the HIP decoder
+    reads (`nhwc`, `precision`).  Behaves as a plain dict for any reference-style consumer."""
+    nhwc = None
+    precision = None
+
+
+# ------------------------------------------------------------------------------------------------
+# packed-weight cache
+# ------------------------------------------------------------------------------------------------
+def _flat_params(named_tensors, device):
+    return torch.cat([t.detach().reshape(-1).to(torch.float32) for t in named_tensors]).to(device)
+
+
+class _PackedWeights:
+    """Caches the device blob; repacks when any parameter tensor changes (version / storage)."""
+
+    def __init__(self):
+        self.key = None
+        self.blob = None
+
+    def get(self, params, head_present, device):
+        key = (head_present, str(device)) + tuple((p.data_ptr(), p._version) for p in params)
+        if key != self.key:
+            flat = _flat_params(params, "cpu")
+            self.blob = _capi.pack_weights(flat, head_present).to(device)
+            self.key = key
+        return self.blob
+
+
+def _check_no_grad(params):
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        raise NotImplementedError(
+            "giga_amd forward kernels are inference-only in this round; wrap the call in "
+            "torch.no_grad() (the training/backward path is tracked in DESIGN.md).")
+
+
+def _head_param_list(dec):
+    out = []
+    for i in range(5):
+        out += [dec.fc_c[i].weight, dec.fc_c[i].bias]
+    out += [dec.fc_p.weight, dec.fc_p.bias]
+    for i in range(5):
+        out += [dec.blocks[i].fc_0.weight, dec.blocks[i].fc_0.bias,
+                dec.blocks[i].fc_1.weight, dec.blocks[i].fc_1.bias]
+    out += [dec.fc_out.weight, dec.fc_out.bias]
+    return out
+
+
+def _encoder_param_list(enc):
+    out = [enc.conv_in.weight, enc.conv_in.bias]
+    u = enc.unet
+    for d in u.down_convs:
+        out += [d.conv1.weight, d.conv1.bias, d.conv2.weight, d.conv2.bias]
+    for m in u.up_convs:
+        out += [m.upconv.weight, m.upconv.bias, m.conv1.weight, m.conv1.bias, m.conv2.weight, m.conv2.bias]
+    out += [u.conv_final.weight, u.conv_final.bias]
+    return out
+
+
+_ENCODER_NUMEL = 476800
+
+
+# ------------------------------------------------------------------------------------------------
+# encoder
+# ------------------------------------------------------------------------------------------------
+class LocalVoxelEncoder(nn.Module):
+    """voxels.py:10-121.  forward(x:(B,40,40,40)) -> {'xz','xy','yz': (B,32,40,40)} (PlaneDict)."""
+
+    def __init__(self, dim=3, c_dim=128, unet=False, unet_kwargs=None, unet3d=False, unet3d_kwargs=None,
+                 plane_resolution=512, grid_resolution=None, plane_type="xz", kernel_size=3, padding=0.1):
+        super().__init__()
+        if not unet or unet3d or c_dim != C_DIM or plane_resolution != RES or kernel_size != 3 \
+                or list(plane_type) != list(PLANES) or padding != 0:
+            raise NotImplementedError(
+                "libgiga_hip is specialised for GIGA's encoder: c_dim=32, unet=True, "
+                "plane_resolution=40, plane_type=['xz','xy','yz'], kernel_size=3, padding=0")
+        self.conv_in = nn.Conv3d(1, c_dim, kernel_size, padding=1)
+        self.unet = UNet(c_dim, in_channels=c_dim, **unet_kwargs)
+        self.unet3d = None
+        self.c_dim, self.reso_plane, self.reso_grid = c_dim, plane_resolution, grid_resolution
+        self.plane_type, self.padding = plane_type, padding
+        self.precision = _DEFAULT_PRECISION
+        self._packed = _PackedWeights()
+        self._ws = {}
+
+    # -- HIP path ---------------------------------------------------------------------------------
+    def _blob(self, device, blob=None):
+        if blob is not None:
+            return blob
+        params = _encoder_param_list(self)
+        return self._packed.get(params, 0, device)     # encoder-only blob (no heads)
+
+    def encode_nhwc(self, x, blob=None, want_nchw=False, precision=None, probe=None):
+        """Run the HIP encoder.  Returns (nhwc planes [3,B,40,40,32], nchw [3,B,32,40,40] or None).
+        probe = (stage, ev_start, ev_stop) brackets one kernel launch with HIP events (bench.py)."""
+        _capi.require_device(x)
+        prec = _capi.PRECISION[precision or self.precision]
+        if x.dim() != 4 or tuple(x.shape[1:]) != (RES, RES, RES):
+            raise ValueError(f"expected a (B,{RES},{RES},{RES}) TSDF batch, got {tuple(x.shape)}")
+        x = x.contiguous().float()
+        B = x.shape[0]
+        L = _capi.lib()
+        blob = self._blob(x.device, blob)
+        nhwc = torch.empty((3, B, RES, RES, C_DIM), device=x.device,
+                           dtype=torch.float16 if prec == 1 else torch.float32)
+        nchw = torch.empty((3, B, C_DIM, RES, RES), device=x.device, dtype=torch.float32) if want_nchw else None
+        key = (B, prec, str(x.device))
+        ws = self._ws.get(key)
+        if ws is None:
+            self._ws.clear()
+            ws = torch.empty(max(L.giga_encoder_workspace_bytes(B, prec), 16), dtype=torch.uint8, device=x.device)
+            self._ws[key] = ws
+        stage, ev0, ev1 = probe if probe is not None else (-1, None, None)
+        _capi.check(L.giga_encoder_forward_probe(_capi.ptr(x), _capi.ptr(blob), _capi.ptr(nhwc), _capi.ptr(nchw),
+                                                 B, prec, _capi.ptr(ws), ws.numel(), _capi.stream_ptr(),
+                                                 stage, ev0, ev1),
+                    "giga_encoder_forward")
+        return nhwc, nchw
+
+    def forward(self, x, _blob=None):
+        _check_no_grad(list(self.parameters()))
+        nhwc, nchw = self.encode_nhwc(x, blob=_blob, want_nchw=True)
+        fea = PlaneDict((k, nchw[i]) for i, k in enumerate(PLANES))
+        fea.nhwc, fea.precision = nhwc, self.precision
+        return fea
+
+
+# ------------------------------------------------------------------------------------------------
+# decoder
+# ------------------------------------------------------------------------------------------------
+def _planes_to_nhwc(c_plane, precision):
+    """PlaneDict fast path, else repack the reference-layout tensors on the device."""
+    if isinstance(c_plane, PlaneDict) and c_plane.nhwc is not None and c_plane.precision == precision:
+        return c_plane.nhwc
+    if list(c_plane.keys()) != list(PLANES):
+        raise NotImplementedError("GIGA decoders sample the three planes ['xz','xy','yz']")
+    xs = [c_plane[k].contiguous().float() for k in PLANES]
+    _capi.require_device(*xs)
+    B = xs[0].shape[0]
+    for t in xs:
+        if tuple(t.shape) != (B, C_DIM, RES, RES):
+            raise ValueError(f"expected (B,{C_DIM},{RES},{RES}) planes, got {tuple(t.shape)}")
+    prec = _capi.PRECISION[precision]
+    nhwc = torch.empty((3, B, RES, RES, C_DIM), device=xs[0].device,
+                       dtype=torch.float16 if prec == 1 else torch.float32)
+    _capi.check(_capi.lib().giga_planes_pack(_capi.ptr(xs[0]), _capi.ptr(xs[1]), _capi.ptr(xs[2]),
+                                             _capi.ptr(nhwc), B, prec, _capi.stream_ptr()),
+                "giga_planes_pack")
+    return nhwc
+
+
+def decode_heads(nhwc, p, blob, head_mask, precision, post, probe=None):
+    """One fused launch for every head in `head_mask` over p (B,N,3).  Returns dict name->tensor.
+    probe = (ev_start, ev_stop) brackets the launch with HIP events (bench.py)."""
+    _capi.require_device(nhwc, p, blob)
+    if p.dim() != 3 or p.shape[-1] != 3:
+        raise ValueError(f"expected (B,N,3) query points, got {tuple(p.shape)}")
+    B, N = p.shape[0], p.shape[1]
+    if nhwc.shape[1] != B:
+        raise ValueError("batch size of planes and points differ")
+    p = p.contiguous().float()
+    dev = p.device
+    out = {}
+    if head_mask & 1:
+        out["decoder_qual"] = torch.empty((B, N), device=dev)
+    if head_mask & 2:
+        out["decoder_rot"] = torch.empty((B, N, 4), device=dev)
+    if head_mask & 4:
+        out["decoder_width"] = torch.empty((B, N), device=dev)
+    if head_mask & 8:
+        out["decoder_tsdf"] = torch.empty((B, N), device=dev)
+    ev0, ev1 = probe if probe is not None else (None, None)
+    _capi.check(_capi.lib().giga_decoder_forward_probe(
+        _capi.ptr(nhwc), _capi.ptr(p), _capi.ptr(blob), head_mask,
+        _capi.ptr(out.get("decoder_qual")), _capi.ptr(out.get("decoder_rot")),
+        _capi.ptr(out.get("decoder_width")), _capi.ptr(out.get("decoder_tsdf")),
+        B, N, _capi.PRECISION[precision], 1 if post else 0, _capi.stream_ptr(), ev0, ev1),
+        "giga_decoder_forward")
+    return out
+
+
+class LocalDecoder(nn.Module):
+    """decoder.py:61-206.  forward(p:(B,N,3), c_plane:dict) -> (B,N) if out_dim == 1 else (B,N,out_dim)."""
+
+    def __init__(self, dim=3, c_dim=128, hidden_size=256, n_blocks=5, out_dim=1, leaky=False,
+                 sample_mode="bilinear", padding=0.1, concat_feat=False, no_xyz=False):
+        super().__init__()
+        if (dim, c_dim, hidden_size, n_blocks, leaky, sample_mode, padding, concat_feat, no_xyz) != \
+                (3, C_DIM, 32, 5, False, "bilinear", 0, True, False) or out_dim not in (1, 4):
+            raise NotImplementedError(
+                "libgiga_hip is specialised for GIGA's decoders: dim=3, c_dim=32, hidden_size=32, "
+                "n_blocks=5, bilinear, padding=0, concat_feat=True, out_dim in {1,4}")
+        self.concat_feat, self.c_dim, self.n_blocks = concat_feat, 3 * c_dim, n_blocks
+        self.no_xyz, self.hidden_size, self.out_dim = no_xyz, hidden_size, out_dim
+        self.fc_c = nn.ModuleList([nn.Linear(self.c_dim, hidden_size) for _ in range(n_blocks)])
+        self.fc_p = nn.Linear(dim, hidden_size)
+        self.blocks = nn.ModuleList([ResnetBlockFC(hidden_size) for _ in range(n_blocks)])
+        self.fc_out = nn.Linear(hidden_size, out_dim)
+        self.sample_mode, self.padding = sample_mode, padding
+        self.precision = _DEFAULT_PRECISION
+        self._packed = _PackedWeights()
+
+    def _standalone(self, device):
+        """Blob holding only this head: slot 'rot' for out_dim 4, slot 'tsdf' (raw output) otherwise."""
+        slot = 2 if self.out_dim == 4 else 8
+        params = _head_param_list(self)
+        key_params = params
+        pw = self._packed
+        key = (slot, str(device)) + tuple((q.data_ptr(), q._version) for q in key_params)
+        if key != pw.key:
+            flat = torch.cat([_flat_params(params, "cpu"), torch.zeros(_ENCODER_NUMEL)])
+            pw.blob = _capi.pack_weights(flat, slot).to(device)
+            pw.key = key
+        return slot, pw.blob
+
+    def forward(self, p, c_plane, **kwargs):
+        _check_no_grad(list(self.parameters()))
+        _capi.require_device(p)
+        nhwc = _planes_to_nhwc(c_plane, self.precision)
+        slot, blob = self._standalone(p.device)
+        name = "decoder_rot" if slot == 2 else "decoder_tsdf"
+        return decode_heads(nhwc, p, blob, slot, self.precision, post=False)[name]
+
+
+# ------------------------------------------------------------------------------------------------
+# full model
+# ------------------------------------------------------------------------------------------------
+class ConvolutionalOccupancyNetwork(nn.Module):
+    """models/__init__.py:15-164: encoder + decoder_qual/rot/width (+ decoder_tsdf)."""
+
+    def __init__(self, decoders, encoder=None, device=None, detach_tsdf=False):
+        super().__init__()
+        self.decoder_qual = decoders[0].to(device)
+        self.decoder_rot = decoders[1].to(device)
+        self.decoder_width = decoders[2].to(device)
+        if len(decoders) == 4:
+            self.decoder_tsdf = decoders[3].to(device)
+        self.encoder = encoder.to(device) if encoder is not None else None
+        self._device = device
+        self.detach_tsdf = detach_tsdf
+        self.precision = _DEFAULT_PRECISION
+        self._packed = _PackedWeights()
+
+    # -- weights ----------------------------------------------------------------------------------
+    def set_precision(self, precision):
+        """'fp32' (exact fp32 MFMA, default) or 'fp16' (f16 operands, fp32 accumulate)."""
+        if precision not in _capi.PRECISION:
+            raise ValueError(precision)
+        self.precision = precision
+        for m in self.modules():
+            if isinstance(m, (LocalDecoder, LocalVoxelEncoder)):
+                m.precision = precision
+        return self
+
+    def _head_present(self):
+        return 7 | (8 if hasattr(self, "decoder_tsdf") else 0)
+
+    def packed_blob(self, device):
+        params = []
+        for h in HEAD_NAMES:
+            if hasattr(self, h):
+                params += _head_param_list(getattr(self, h))
+        params += _encoder_param_list(self.encoder)
+        return self._packed.get(params, self._head_present(), device)
+
+    # -- reference API ------------------------------------------------------------------------------
+    def forward(self, inputs, p, p_tsdf=None, sample=True, _probe=None, **kwargs):
+        """models/__init__.py:42-67.  inputs (B,40,40,40); p (B,N,3); p_tsdf (B,M,3) ->
+        qual (B,N) [sigmoid], rot (B,N,4) [unit], width (B,N) [, tsdf (B,M) raw logits].
+        (`_probe`: bench.py's HIP-event bracket around one encoder kernel; not part of the API.)"""
+        _check_no_grad(list(self.parameters()))
+        _capi.require_device(inputs, p, p_tsdf)
+        blob = self.packed_blob(inputs.device)
+        nhwc, _ = self.encoder.encode_nhwc(inputs, blob=blob, precision=self.precision, probe=_probe)
+        g = decode_heads(nhwc, p, blob, 7, self.precision, post=True)
+        out = (g["decoder_qual"], g["decoder_rot"], g["decoder_width"])
+        if p_tsdf is not None:
+            t = decode_heads(nhwc, p_tsdf, blob, 8, self.precision, post=False)
+            out = out + (t["decoder_tsdf"],)
+        return out
+
+    def infer_geo(self, inputs, p_tsdf, **kwargs):
+        """models/__init__.py:69-72."""
+        c = self.encode_inputs(inputs)
+        return self._decode_tsdf(p_tsdf, c)
+
+    def encode_inputs(self, inputs):
+        """models/__init__.py:74-87."""
+        if self.encoder is None:
+            return torch.empty(inputs.size(0), 0)
+        _check_no_grad(list(self.parameters()))
+        nhwc, nchw = self.encoder.encode_nhwc(inputs, blob=self.packed_blob(inputs.device), want_nchw=True,
+                                              precision=self.precision)
+        fea = PlaneDict((k, nchw[i]) for i, k in enumerate(PLANES))
+        fea.nhwc, fea.precision = nhwc, self.precision
+        return fea
+
+    def _decode_tsdf(self, p, c):
+        blob = self.packed_blob(p.device)
+        nhwc = _planes_to_nhwc(c, self.precision)
+        return decode_heads(nhwc, p, blob, 8, self.precision, post=False)["decoder_tsdf"]
+
+    def decode_occ(self, p, c, **kwargs):
+        """models/__init__.py:100-109."""
+        _check_no_grad(list(self.parameters()))
+        return dist.Bernoulli(logits=self._decode_tsdf(p, c))
+
+    def decode(self, p, c, **kwargs):
+        """models/__init__.py:111-124."""
+        _check_no_grad(list(self.parameters()))
+        _capi.require_device(p)
+        blob = self.packed_blob(p.device)
+        nhwc = _planes_to_nhwc(c, self.precision)
+        g = decode_heads(nhwc, p, blob, 7, self.precision, post=True)
+        return g["decoder_qual"], g["decoder_rot"], g["decoder_width"]
+
+    def to(self, device):
+        """models/__init__.py:126-134."""
+        model = super().to(device)
+        model._device = device
+        return model
+
+
+class ConvolutionalOccupancyNetworkGeometry(nn.Module):
+    """models/__init__.py:166-226 (occupancy head only; `giga_geo`)."""
+
+    def __init__(self, decoder, encoder=None, device=None):
+        super().__init__()
+        self.decoder_tsdf = decoder.to(device)
+        self.encoder = encoder.to(device) if encoder is not None else None
+        self._device = device
+        self.precision = _DEFAULT_PRECISION
+        self._packed = _PackedWeights()
+
+    def set_precision(self, precision):
+        self.precision = precision
+        self.decoder_tsdf.precision = precision
+        self.encoder.precision = precision
+        return self
+
+    def packed_blob(self, device):
+        params = _head_param_list(self.decoder_tsdf) + _encoder_param_list(self.encoder)
+        return self._packed.get(params, 8, device)
+
+    def forward(self, inputs, p, p_tsdf, sample=True, **kwargs):
+        _check_no_grad(list(self.parameters()))
+        _capi.require_device(inputs, p_tsdf)
+        blob = self.packed_blob(inputs.device)
+        nhwc, _ = self.encoder.encode_nhwc(inputs, blob=blob, precision=self.precision)
+        return decode_heads(nhwc, p_tsdf, blob, 8, self.precision, post=False)["decoder_tsdf"]
+
+    def infer_geo(self, inputs, p_tsdf, **kwargs):
+        return self.forward(inputs, None, p_tsdf)
+
+    def encode_inputs(self, inputs):
+        _check_no_grad(list(self.parameters()))
+        nhwc, nchw = self.encoder.encode_nhwc(inputs, blob=self.packed_blob(inputs.device), want_nchw=True,
+                                              precision=self.precision)
+        fea = PlaneDict((k, nchw[i]) for i, k in enumerate(PLANES))
+        fea.nhwc, fea.precision = nhwc, self.precision
+        return fea
+
+    def decode_occ(self, p, c, **kwargs):
+        _check_no_grad(list(self.parameters()))
+        nhwc = _planes_to_nhwc(c, self.precision)
+        logits = decode_heads(nhwc, p, self.packed_blob(p.device), 8, self.precision, post=False)["decoder_tsdf"]
+        return dist.Bernoulli(logits=logits)
+
+    def to(self, device):
+        model = super().to(device)
+        model._device = device
+        return model
+
+
+decoder_dict = {"simple_local": LocalDecoder}          # models/__init__.py:7-12 (GIGA entry only)
+encoder_dict = {"voxel_simple_local": LocalVoxelEncoder}   # encoder/__init__.py:6-11 (GIGA entry only)
+
+
+def get_model(cfg, device=None, dataset=None, **kwargs):
+    """conv_onet/config.py:15-91 for the dict configs of networks.py:65-169."""
+    decoder, encoder = cfg["decoder"], cfg["encoder"]
+    c_dim = cfg["c_dim"]
+    decoder_kwargs, encoder_kwargs = dict(cfg["decoder_kwargs"]), dict(cfg["encoder_kwargs"])
+    padding = cfg["padding"]
+    if padding is None:
+        padding = 0.1
+    tsdf_only = bool(cfg.get("tsdf_only"))
+    detach_tsdf = bool(cfg.get("detach_tsdf"))
+    decoders = []
+    if not tsdf_only:
+        for out_dim in (1, 4, 1):
+            decoders.append(decoder_dict[decoder](c_dim=c_dim, padding=padding, out_dim=out_dim, **decoder_kwargs))
+    if cfg["decoder_tsdf"] or tsdf_only:
+        decoder_tsdf = decoder_dict[decoder](c_dim=c_dim, padding=padding, out_dim=1, **decoder_kwargs)
+        decoders.append(decoder_tsdf)
+    enc = encoder_dict[encoder](c_dim=c_dim, padding=padding, **encoder_kwargs) if encoder is not None else None
+    if tsdf_only:
+        return ConvolutionalOccupancyNetworkGeometry(decoder_tsdf, enc, device=device)
+    return ConvolutionalOccupancyNetwork(decoders, enc, device=device, detach_tsdf=detach_tsdf)

@@ -1,0 +1,149 @@
+// extern "C" entry points of libgiga_hip.so (declared in include/giga_hip.h).
+#include <hip/hip_runtime.h>
+
+#include "../../include/giga_hip.h"
+#include "giga_layout.h"
+
+namespace giga {
+// giga_pack.cpp
+size_t packed_bytes();
+int pack_weights_host(const float* P, size_t n_params, int head_present, uint8_t* blob, size_t blob_bytes);
+// giga_encoder.hip
+struct EncWs { size_t P0, A0, S0, Q0, A1, S1, Q1, A2, S2, U0, A3, A4, U1, A5, A6, YZ, XZ, total; };
+EncWs enc_workspace(int B, int precision, int nslab);
+int enc_nslab(int B);
+int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, float* planes_nchw, int B,
+                   int precision, uint8_t* ws, hipStream_t s, int probe_stage, void* ev0, void* ev1);
+// giga_decoder.hip
+struct DecArgs {
+    const void* planes; const float* p; const uint8_t* blob;
+    size_t head_off[NHEADS]; int head_id[NHEADS]; float* out[NHEADS];
+    int nheads; int B, N; long long P; int nbatch; int post;
+};
+int launch_decoder(const DecArgs& a, int precision, hipStream_t s, void* ev0, void* ev1);
+int launch_planes_pack(const float* xz, const float* xy, const float* yz, void* dst, int B, int precision, hipStream_t s);
+int launch_planes_unpack(const void* src, float* dst, int B, int precision, hipStream_t s);
+}  // namespace giga
+
+using namespace giga;
+
+extern "C" {
+
+int giga_abi_version(void) { return GIGA_ABI_VERSION; }
+
+const char* giga_strerror(int code) {
+    switch (code) {
+        case 0: return "ok";
+        case -1: return "invalid argument";
+        case -2: return "parameter count does not match the head set";
+        case -3: return "packed buffer too small";
+        case -4: return "workspace too small";
+        case -5: return "unsupported precision";
+        case -6: return "null pointer for a requested output";
+        case -10: return "HIP launch failed";
+        default: return "unknown error";
+    }
+}
+
+size_t giga_param_count(int head_present) { return param_offsets(head_present & 15).total; }
+
+size_t giga_packed_bytes(void) { return packed_bytes(); }
+
+int giga_pack_weights(const float* params_host, size_t n_params, int head_present, void* packed_host,
+                      size_t packed_bytes_) {
+    if (!params_host || !packed_host) return -1;
+    return pack_weights_host(params_host, n_params, head_present & 15, static_cast<uint8_t*>(packed_host),
+                             packed_bytes_);
+}
+
+size_t giga_encoder_workspace_bytes(int B, int precision) {
+    if (B <= 0) return 0;
+    return enc_workspace(B, precision, enc_nslab(B)).total;
+}
+
+int giga_encoder_workspace_layout(int B, int precision, size_t* offsets) {
+    if (B <= 0 || !offsets) return -1;
+    const EncWs w = enc_workspace(B, precision, enc_nslab(B));
+    const size_t v[17] = {w.P0, w.A0, w.S0, w.Q0, w.A1, w.S1, w.Q1, w.A2, w.S2, w.U0, w.A3, w.A4, w.U1, w.A5, w.A6,
+                          w.YZ, w.XZ};
+    for (int i = 0; i < 17; ++i) offsets[i] = v[i];
+    return 0;
+}
+
+int giga_encoder_forward_probe(const float* tsdf, const void* packed, void* planes_nhwc, float* planes_nchw,
+                               int B, int precision, void* workspace, size_t workspace_bytes, void* stream,
+                               int probe_stage, void* ev_start, void* ev_stop) {
+    if (B < 0 || (B > 0 && (!tsdf || !packed || !planes_nhwc || !workspace))) return -1;
+    if (precision != 0 && precision != 1) return -5;
+    if (workspace_bytes < giga_encoder_workspace_bytes(B, precision)) return -4;
+    return launch_encoder(tsdf, static_cast<const uint8_t*>(packed), planes_nhwc, planes_nchw, B, precision,
+                          static_cast<uint8_t*>(workspace), static_cast<hipStream_t>(stream), probe_stage,
+                          ev_start, ev_stop);
+}
+
+int giga_encoder_forward(const float* tsdf, const void* packed, void* planes_nhwc, float* planes_nchw, int B,
+                         int precision, void* workspace, size_t workspace_bytes, void* stream) {
+    return giga_encoder_forward_probe(tsdf, packed, planes_nhwc, planes_nchw, B, precision, workspace,
+                                      workspace_bytes, stream, -1, nullptr, nullptr);
+}
+
+void* giga_event_create(void) {
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? static_cast<void*>(e) : nullptr;
+}
+void giga_event_destroy(void* ev) { if (ev) (void)hipEventDestroy(static_cast<hipEvent_t>(ev)); }
+int giga_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms) {
+    if (!ev_start || !ev_stop || !ms) return -1;
+    if (hipEventSynchronize(static_cast<hipEvent_t>(ev_stop)) != hipSuccess) return -10;
+    return hipEventElapsedTime(ms, static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop)) == hipSuccess
+               ? 0 : -10;
+}
+
+int giga_planes_pack(const float* xz, const float* xy, const float* yz, void* planes_nhwc, int B, int precision,
+                     void* stream) {
+    if (B < 0 || (B > 0 && (!xz || !xy || !yz || !planes_nhwc))) return -1;
+    if (precision != 0 && precision != 1) return -5;
+    return launch_planes_pack(xz, xy, yz, planes_nhwc, B, precision, static_cast<hipStream_t>(stream));
+}
+
+int giga_planes_unpack(const void* planes_nhwc, float* planes_nchw, int B, int precision, void* stream) {
+    if (B < 0 || (B > 0 && (!planes_nhwc || !planes_nchw))) return -1;
+    if (precision != 0 && precision != 1) return -5;
+    return launch_planes_unpack(planes_nhwc, planes_nchw, B, precision, static_cast<hipStream_t>(stream));
+}
+
+int giga_decoder_forward_probe(const void* planes_nhwc, const float* p, const void* packed, int head_mask,
+                               float* qual, float* rot, float* width, float* occ, int B, int N, int precision,
+                               int post, void* stream, void* ev_start, void* ev_stop);
+
+int giga_decoder_forward(const void* planes_nhwc, const float* p, const void* packed, int head_mask, float* qual,
+                         float* rot, float* width, float* occ, int B, int N, int precision, int post,
+                         void* stream) {
+    return giga_decoder_forward_probe(planes_nhwc, p, packed, head_mask, qual, rot, width, occ, B, N, precision,
+                                      post, stream, nullptr, nullptr);
+}
+
+int giga_decoder_forward_probe(const void* planes_nhwc, const float* p, const void* packed, int head_mask,
+                               float* qual, float* rot, float* width, float* occ, int B, int N, int precision,
+                               int post, void* stream, void* ev_start, void* ev_stop) {
+    if (B < 0 || N < 0) return -1;
+    if (precision != 0 && precision != 1) return -5;
+    if ((long long)B * N == 0 || (head_mask & 15) == 0) return 0;
+    if (!planes_nhwc || !p || !packed) return -1;
+    const PackOff ko = pack_offsets();
+    DecArgs a{};
+    a.planes = planes_nhwc; a.p = p; a.blob = static_cast<const uint8_t*>(packed);
+    float* outs[NHEADS] = {qual, rot, width, occ};
+    for (int h = 0; h < NHEADS; ++h) {
+        if (!(head_mask >> h & 1)) continue;
+        if (!outs[h]) return -6;
+        a.head_id[a.nheads] = h;
+        a.head_off[a.nheads] = precision == 1 ? ko.dec16[h] : ko.dec32[h];
+        a.out[a.nheads] = outs[h];
+        ++a.nheads;
+    }
+    a.B = B; a.N = N; a.P = (long long)B * N; a.post = post;
+    return launch_decoder(a, precision, static_cast<hipStream_t>(stream), ev_start, ev_stop);
+}
+
+}  // extern "C"

@@ -1,0 +1,72 @@
+// Device-side helpers shared by the gfx950 kernels.  CDNA4 only: 64-wide waves, MFMA, LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "giga_layout.h"
+
+namespace giga {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// D = A(32 x 16, f16) * B(16 x 32, f16) + C.  lane (n = lane&31, hi = lane>>5) holds k-slots
+// (hi, 0..7) of row n of A / column n of B; D: column lane&31, rows (r&3)+8*(r>>2)+4*hi.
+__device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// D = A(32 x 2, f32) * B(2 x 32, f32) + C, exact fp32 (k-ordered fma chain); lane holds k-slot hi.
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float relu(float x) { return __builtin_fmaxf(x, 0.f); }
+
+// relu + round-to-nearest f16 of D registers 8c..8c+7  -> B operand of the next layer's chunk c
+__device__ __forceinline__ half8 pack_relu8(const f32x16& d, int c) {
+    half8 x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (half_t)relu(d[8 * c + j]);
+    return x;
+}
+
+// ---- coordinates: reference ConvONets/common.py:238-261 with padding = 0 -------------------------
+// xy = p / (1 + 0 + 10e-6) + 0.5 ; >= 1 -> 1 - 10e-6 ; < 0 -> 0     (fp32, true division)
+__device__ __forceinline__ float norm_coord(float p) {
+    float v = p / 1.00001f + 0.5f;
+    v = v >= 1.0f ? 0.99999f : v;
+    v = v < 0.0f ? 0.0f : v;
+    return v;
+}
+// pixel coordinate of F.grid_sample(align_corners=True, padding_mode='border') on a 40-wide axis,
+// from the normalised coordinate: vgrid = 2*xy - 1 ; ix = ((vgrid + 1) / 2) * 39 ; clip to [0, 39]
+__device__ __forceinline__ float pix_coord(float xy) {
+    float g = 2.0f * xy - 1.0f;
+    float ix = ((g + 1.0f) * 0.5f) * 39.0f;
+    return fminf(fmaxf(ix, 0.0f), 39.0f);
+}
+
+struct Bilin {          // 4-tap footprint on a 40x40 plane, element offsets in pixels
+    int o00, o01, o10, o11;
+    float w00, w01, w10, w11;
+};
+// u indexes W (first listed plane axis), v indexes H (second)  -- decoder.py:117-122
+__device__ __forceinline__ Bilin bilin_setup(float u, float v) {
+    float fx = pix_coord(u), fy = pix_coord(v);
+    float x0f = floorf(fx), y0f = floorf(fy);
+    int x0 = (int)x0f, y0 = (int)y0f;
+    int x1 = min(x0 + 1, RES - 1), y1 = min(y0 + 1, RES - 1);
+    float ax = fx - x0f, ay = fy - y0f;      // weights as aten grid_sampler_2d computes them
+    float bx = (x0f + 1.0f) - fx, by = (y0f + 1.0f) - fy;
+    Bilin b;
+    b.o00 = y0 * RES + x0; b.o01 = y0 * RES + x1; b.o10 = y1 * RES + x0; b.o11 = y1 * RES + x1;
+    b.w00 = bx * by; b.w01 = ax * by; b.w10 = bx * ay; b.w11 = ax * ay;
+    if (x0 + 1 > RES - 1) b.w01 = b.w11 = 0.f;   // out-of-bounds taps contribute zero (never hit: xy <= 0.99999)
+    if (y0 + 1 > RES - 1) b.w10 = b.w11 = 0.f;
+    return b;
+}
+
+}  // namespace giga

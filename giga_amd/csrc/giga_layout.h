@@ -1,0 +1,150 @@
+// Shared host-side description of the GIGA network and of the packed-weight blob.
+//
+// Reference architecture (fixed by vgn.networks.GIGA, /root/reference/src/vgn/networks.py:91-115):
+//   encoder  LocalVoxelEncoder: Conv3d(1,32,3,pad=1)+ReLU -> 3 axis-mean planes (40x40x32) ->
+//            shared UNet(depth 3, start_filts 32, concat merge) -> 1x1 conv   (encoder/voxels.py, unet.py)
+//   decoders 4x LocalDecoder(c_dim=3*32, hidden 32, 5 ResnetBlockFC, out_dim 1/4/1/1) (models/decoder.py)
+//
+// The flat fp32 parameter buffer handed to giga_pack_weights() is the reference state-dict
+// flattened in its own key order (decoder_qual, decoder_rot, decoder_width, [decoder_tsdf], encoder).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace giga {
+
+constexpr int RES = 40;            // TSDF / plane resolution
+constexpr int CD = 32;             // c_dim == hidden_size
+constexpr int NBLK = 5;            // ResnetBlockFC blocks per head
+constexpr int NHEADS = 4;          // qual, rot, width, tsdf
+constexpr int HEAD_OUT[NHEADS] = {1, 4, 1, 1};
+
+// ----- flat fp32 parameter offsets (state-dict order) ---------------------------------------
+struct HeadParamOff {
+    size_t fc_c_w[NBLK], fc_c_b[NBLK];      // (32,96), (32)
+    size_t fc_p_w, fc_p_b;                  // (32,3), (32)
+    size_t fc0_w[NBLK], fc0_b[NBLK];        // (32,32), (32)
+    size_t fc1_w[NBLK], fc1_b[NBLK];
+    size_t out_w, out_b;                    // (out,32), (out)
+};
+
+enum ConvKind { CONV3 = 0, UPCONV = 1, CONV1 = 2 };
+struct ConvLayerDesc {
+    int kind, cin0, cin1, cout, H, W;       // H,W = INPUT spatial size
+    bool pool;                              // fused 2x2 max-pool output (DownConv with pooling)
+};
+constexpr int NCONV = 13;
+constexpr ConvLayerDesc kConv[NCONV] = {
+    {CONV3, 32, 0, 32, 40, 40, false},   // 0  down_convs.0.conv1
+    {CONV3, 32, 0, 32, 40, 40, true},    // 1  down_convs.0.conv2 (+pool)
+    {CONV3, 32, 0, 64, 20, 20, false},   // 2  down_convs.1.conv1
+    {CONV3, 64, 0, 64, 20, 20, true},    // 3  down_convs.1.conv2 (+pool)
+    {CONV3, 64, 0, 128, 10, 10, false},  // 4  down_convs.2.conv1
+    {CONV3, 128, 0, 128, 10, 10, false}, // 5  down_convs.2.conv2 (no pool, unet.py:190)
+    {UPCONV, 128, 0, 64, 10, 10, false}, // 6  up_convs.0.upconv  ConvTranspose2d(128,64,2,2)
+    {CONV3, 64, 64, 64, 20, 20, false},  // 7  up_convs.0.conv1   cat(from_up, from_down)
+    {CONV3, 64, 0, 64, 20, 20, false},   // 8  up_convs.0.conv2
+    {UPCONV, 64, 0, 32, 20, 20, false},  // 9  up_convs.1.upconv
+    {CONV3, 32, 32, 32, 40, 40, false},  // 10 up_convs.1.conv1
+    {CONV3, 32, 0, 32, 40, 40, false},   // 11 up_convs.1.conv2
+    {CONV1, 32, 0, 32, 40, 40, false},   // 12 conv_final (1x1, no activation, unet.py:238)
+};
+// order of the conv layers inside the state dict (down0.c1,c2, down1.., down2.., up0.upconv,c1,c2, up1.., final)
+// is identical to kConv order.
+
+struct ParamOff {
+    HeadParamOff head[NHEADS];
+    size_t conv_in_w, conv_in_b;            // (32,1,3,3,3), (32)
+    size_t conv_w[NCONV], conv_b[NCONV];
+    size_t total;
+};
+
+inline int conv_taps(const ConvLayerDesc& d) { return d.kind == CONV3 ? 9 : 1; }
+inline int conv_nsub(const ConvLayerDesc& d) { return d.kind == UPCONV ? 4 : 1; }
+inline size_t conv_w_count(const ConvLayerDesc& d) {
+    return (size_t)d.cout * (d.cin0 + d.cin1) * (d.kind == CONV3 ? 9 : d.kind == UPCONV ? 4 : 1);
+}
+
+// head_present: bit h set <=> head h's parameters are present in the flat buffer.
+inline ParamOff param_offsets(int head_present) {
+    ParamOff o{};
+    size_t at = 0;
+    for (int h = 0; h < NHEADS; ++h) {
+        if (!(head_present >> h & 1)) continue;
+        HeadParamOff& p = o.head[h];
+        for (int i = 0; i < NBLK; ++i) { p.fc_c_w[i] = at; at += CD * 3 * CD; p.fc_c_b[i] = at; at += CD; }
+        p.fc_p_w = at; at += CD * 3; p.fc_p_b = at; at += CD;
+        for (int i = 0; i < NBLK; ++i) {
+            p.fc0_w[i] = at; at += CD * CD; p.fc0_b[i] = at; at += CD;
+            p.fc1_w[i] = at; at += CD * CD; p.fc1_b[i] = at; at += CD;
+        }
+        p.out_w = at; at += HEAD_OUT[h] * CD; p.out_b = at; at += HEAD_OUT[h];
+    }
+    o.conv_in_w = at; at += CD * 27; o.conv_in_b = at; at += CD;
+    for (int l = 0; l < NCONV; ++l) {
+        o.conv_w[l] = at; at += conv_w_count(kConv[l]);
+        o.conv_b[l] = at; at += kConv[l].cout;
+    }
+    o.total = at;
+    return o;
+}
+
+// ----- packed blob ---------------------------------------------------------------------------
+// A "fragment" is the 1 KiB MFMA operand image of one wave: 64 lanes x 16 bytes, lane-linear, so a
+// wave reads it with one ds_read_b128 / global_load_dwordx4 per lane (conflict-free, coalesced).
+//   f16 fragment : lane (n = lane&31, hi = lane>>5) holds 8 halfs = k-slots (hi, j=0..7) of one
+//                  v_mfma_f32_32x32x16_f16.
+//   f32 fragment : lane holds 4 floats = its k-slot `hi` of FOUR consecutive v_mfma_f32_32x32x2_f32.
+constexpr size_t FRAG = 1024;
+
+// Decoder head blob, precision f16: fragments in order of use
+//   for blk 0..4: 6 feature frags + 1 aux frag (fc_c[blk]; aux = fc_p hi/lo (blk 0) + folded biases),
+//                 2 frags fc_0, 2 frags fc_1
+//   1 aux frag (b1 of block 4), 2 frags fc_out (rows >= out_dim zero)
+//   then the fp32 C-init table: 5 x 32 (fc_0 bias) + 32 (fc_out bias, zero padded)
+constexpr int DEC16_FRAGS = NBLK * (7 + 2 + 2) + 1 + 2;                   // 58
+constexpr size_t DEC_CTAB_BYTES = (NBLK + 1) * CD * sizeof(float);        // 768
+constexpr size_t DEC16_BYTES = DEC16_FRAGS * FRAG + DEC_CTAB_BYTES;       // 60160
+// precision f32: per block 12 feature frags (48 MFMAs) + 1 aux frag (2 MFMAs used) + 4 + 4; tail 1 + 4
+constexpr int DEC32_FRAGS = NBLK * (12 + 1 + 4 + 4) + 1 + 4;              // 110
+constexpr size_t DEC32_BYTES = DEC32_FRAGS * FRAG + DEC_CTAB_BYTES;       // 113408
+
+struct ConvPackOff { size_t w16, w32, bias; int nfrag16, nfrag32; };
+struct PackOff {
+    size_t convin_w;        // fp32 [14][64]  B operands of the 14 K-steps (27 taps + 1 zero)
+    size_t convin_b;        // fp32 [32]
+    ConvPackOff conv[NCONV];
+    size_t dec16[NHEADS], dec32[NHEADS];
+    size_t total;
+};
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+inline PackOff pack_offsets() {
+    PackOff o{};
+    size_t at = 0;
+    o.convin_w = at; at += 14 * 64 * sizeof(float);
+    o.convin_b = at; at += align_up(CD * sizeof(float), 256);
+    for (int l = 0; l < NCONV; ++l) {
+        const ConvLayerDesc& d = kConv[l];
+        const int cin = d.cin0 + d.cin1;
+        const int nblk = d.cout / 32 * conv_nsub(d);
+        o.conv[l].nfrag16 = nblk * conv_taps(d) * (cin / 16);
+        o.conv[l].nfrag32 = nblk * conv_taps(d) * (cin / 8);
+        o.conv[l].w16 = at; at += o.conv[l].nfrag16 * FRAG;
+        o.conv[l].w32 = at; at += o.conv[l].nfrag32 * FRAG;
+        o.conv[l].bias = at; at += align_up(d.cout * sizeof(float), 256);
+    }
+    for (int h = 0; h < NHEADS; ++h) {
+        o.dec16[h] = at; at += align_up(DEC16_BYTES, 256);
+        o.dec32[h] = at; at += align_up(DEC32_BYTES, 256);
+    }
+    o.total = at;
+    return o;
+}
+
+// feature index held in D-register r of lane-half hi after a 32x32 MFMA with weights as the A
+// operand (rows = output features):  row = (r&3) + 8*(r>>2) + 4*hi   (C/D map, dtype independent)
+inline int drow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+}  // namespace giga

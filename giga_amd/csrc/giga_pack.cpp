@@ -1,0 +1,190 @@
+// Host-side weight packing: reference state-dict (flat fp32, key order) -> MFMA fragment blob.
+// Cold path (once per checkpoint load, reference networks.py:21-35 `load_network`).
+//
+// K-slot conventions (must match the kernels; see DESIGN.md "MFMA operand conventions"):
+//  * 32x32 MFMA with WEIGHTS as the A operand (row n = output feature) and ACTIVATIONS as the B
+//    operand (col = point/pixel).  The contraction index may be permuted freely as long as the A
+//    and B images agree, which is what lets a layer's D registers feed the next layer's B operand
+//    without any cross-lane movement.
+#include "giga_layout.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace giga {
+
+typedef _Float16 half_t;
+
+static inline half_t f2h(float x) { return (half_t)x; }   // round-to-nearest-even
+
+// hidden-layer feature held in k-slot (hi, j) of f16 chunk c   (D regs r = 8c + j)
+static inline int hid16(int c, int hi, int j) { return drow(8 * c + j, hi); }
+// input feature (0..95, concat order xz,xy,yz) in k-slot (hi,j) of f16 feature chunk c (0..5)
+static inline int feat16(int c, int hi, int j) { return (c / 2) * 32 + (c % 2) * 16 + 8 * hi + j; }
+// input feature in k-slot hi of fp32 feature MFMA m (0..47)
+static inline int feat32(int m, int hi) { return (m / 16) * 32 + 16 * hi + (m % 16); }
+
+static void pack_head16(const float* P, const HeadParamOff& o, int out_dim, uint8_t* dst) {
+    std::memset(dst, 0, DEC16_BYTES);
+    half_t* f = reinterpret_cast<half_t*>(dst);
+    auto frag = [&](int idx, int lane, int j) -> half_t& { return f[(size_t)idx * 512 + lane * 8 + j]; };
+    auto aux = [&](int idx, const float* wp, const float* bias_a, const float* bias_b) {
+        for (int n = 0; n < 32; ++n) {
+            float b = (bias_a ? bias_a[n] : 0.f) + (bias_b ? bias_b[n] : 0.f);
+            half_t bh = f2h(b), bl = f2h(b - (float)bh);
+            for (int k = 0; k < 3; ++k) {
+                float w = wp ? wp[n * 3 + k] : 0.f;
+                half_t wh = f2h(w), wl = f2h(w - (float)wh);
+                frag(idx, n, k) = wh;          // x p_hi
+                frag(idx, n, 4 + k) = wh;      // x p_lo
+                frag(idx, 32 + n, k) = wl;     // (hi=1 lanes) x p_hi
+            }
+            frag(idx, n, 3) = bh;              // x 1.0
+            frag(idx, n, 7) = bl;              // x 1.0
+        }
+    };
+    auto dense32 = [&](int idx0, const float* W, int rows) {   // (rows,32) weight, 2 chunks
+        for (int c = 0; c < 2; ++c)
+            for (int lane = 0; lane < 64; ++lane) {
+                int n = lane & 31, hi = lane >> 5;
+                for (int j = 0; j < 8; ++j)
+                    frag(idx0 + c, lane, j) = n < rows ? f2h(W[n * 32 + hid16(c, hi, j)]) : (half_t)0;
+            }
+    };
+    int idx = 0;
+    for (int b = 0; b < NBLK; ++b) {
+        const float* Wc = P + o.fc_c_w[b];
+        for (int c = 0; c < 6; ++c, ++idx)
+            for (int lane = 0; lane < 64; ++lane) {
+                int n = lane & 31, hi = lane >> 5;
+                for (int j = 0; j < 8; ++j) frag(idx, lane, j) = f2h(Wc[n * 96 + feat16(c, hi, j)]);
+            }
+        if (b == 0) aux(idx, P + o.fc_p_w, P + o.fc_p_b, P + o.fc_c_b[0]);
+        else aux(idx, nullptr, P + o.fc_c_b[b], P + o.fc1_b[b - 1]);
+        ++idx;
+        dense32(idx, P + o.fc0_w[b], 32); idx += 2;
+        dense32(idx, P + o.fc1_w[b], 32); idx += 2;
+    }
+    aux(idx, nullptr, P + o.fc1_b[NBLK - 1], nullptr); ++idx;
+    dense32(idx, P + o.out_w, out_dim); idx += 2;
+    float* ctab = reinterpret_cast<float*>(dst + (size_t)DEC16_FRAGS * FRAG);
+    for (int b = 0; b < NBLK; ++b)
+        for (int n = 0; n < 32; ++n) ctab[b * 32 + n] = P[o.fc0_b[b] + n];
+    for (int n = 0; n < 32; ++n) ctab[NBLK * 32 + n] = n < out_dim ? P[o.out_b + n] : 0.f;
+}
+
+static void pack_head32(const float* P, const HeadParamOff& o, int out_dim, uint8_t* dst) {
+    std::memset(dst, 0, DEC32_BYTES);
+    float* f = reinterpret_cast<float*>(dst);
+    auto frag = [&](int idx, int lane, int j) -> float& { return f[(size_t)idx * 256 + lane * 4 + j]; };
+    auto aux = [&](int idx, const float* wp, const float* bias_a, const float* bias_b) {
+        for (int n = 0; n < 32; ++n) {
+            float b = (bias_a ? bias_a[n] : 0.f) + (bias_b ? bias_b[n] : 0.f);
+            frag(idx, n, 0) = wp ? wp[n * 3 + 0] : 0.f;        // MFMA0 slot0: px
+            frag(idx, 32 + n, 0) = wp ? wp[n * 3 + 1] : 0.f;   // MFMA0 slot1: py
+            frag(idx, n, 1) = wp ? wp[n * 3 + 2] : 0.f;        // MFMA1 slot0: pz
+            frag(idx, 32 + n, 1) = b;                          // MFMA1 slot1: 1.0
+        }
+    };
+    auto dense32 = [&](int idx0, const float* W, int rows) {   // 16 MFMAs = 4 frags
+        for (int q = 0; q < 4; ++q)
+            for (int lane = 0; lane < 64; ++lane) {
+                int n = lane & 31, hi = lane >> 5;
+                for (int j = 0; j < 4; ++j)
+                    frag(idx0 + q, lane, j) = n < rows ? W[n * 32 + drow(4 * q + j, hi)] : 0.f;
+            }
+    };
+    int idx = 0;
+    for (int b = 0; b < NBLK; ++b) {
+        const float* Wc = P + o.fc_c_w[b];
+        for (int q = 0; q < 12; ++q, ++idx)
+            for (int lane = 0; lane < 64; ++lane) {
+                int n = lane & 31, hi = lane >> 5;
+                for (int j = 0; j < 4; ++j) frag(idx, lane, j) = Wc[n * 96 + feat32(4 * q + j, hi)];
+            }
+        if (b == 0) {
+            // bias = fc_p.bias + fc_c[0].bias
+            aux(idx, P + o.fc_p_w, P + o.fc_p_b, P + o.fc_c_b[0]);
+        } else {
+            aux(idx, nullptr, P + o.fc_c_b[b], P + o.fc1_b[b - 1]);
+        }
+        ++idx;
+        dense32(idx, P + o.fc0_w[b], 32); idx += 4;
+        dense32(idx, P + o.fc1_w[b], 32); idx += 4;
+    }
+    aux(idx, nullptr, P + o.fc1_b[NBLK - 1], nullptr); ++idx;
+    dense32(idx, P + o.out_w, out_dim); idx += 4;
+    float* ctab = reinterpret_cast<float*>(dst + (size_t)DEC32_FRAGS * FRAG);
+    for (int b = 0; b < NBLK; ++b)
+        for (int n = 0; n < 32; ++n) ctab[b * 32 + n] = P[o.fc0_b[b] + n];
+    for (int n = 0; n < 32; ++n) ctab[NBLK * 32 + n] = n < out_dim ? P[o.out_b + n] : 0.f;
+}
+
+// weight element W[co][ci][tap] of conv layer l in reference layout
+static inline float conv_w_at(const float* W, const ConvLayerDesc& d, int co, int ci, int tap) {
+    const int cin = d.cin0 + d.cin1;
+    if (d.kind == CONV3) return W[((size_t)co * cin + ci) * 9 + tap];           // (Cout,Cin,3,3)
+    if (d.kind == UPCONV) return W[((size_t)ci * d.cout + co) * 4 + tap];       // (Cin,Cout,2,2)
+    return W[(size_t)co * cin + ci];                                            // (Cout,Cin,1,1)
+}
+
+static void pack_conv(const float* P, const ParamOff& po, const PackOff& ko, int l, uint8_t* blob) {
+    const ConvLayerDesc& d = kConv[l];
+    const float* W = P + po.conv_w[l];
+    const int cin = d.cin0 + d.cin1, taps = conv_taps(d), nsub = conv_nsub(d), nb32 = d.cout / 32;
+    half_t* f16 = reinterpret_cast<half_t*>(blob + ko.conv[l].w16);
+    float* f32 = reinterpret_cast<float*>(blob + ko.conv[l].w32);
+    // fragment order: [sub (upconv d)][nb][tap][kg]
+    size_t i16 = 0, i32 = 0;
+    for (int sub = 0; sub < nsub; ++sub)
+        for (int nb = 0; nb < nb32; ++nb)
+            for (int tap = 0; tap < taps; ++tap) {
+                const int wtap = d.kind == UPCONV ? sub : tap;
+                for (int kg = 0; kg < cin / 16; ++kg, ++i16)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        int n = lane & 31, hi = lane >> 5;
+                        for (int j = 0; j < 8; ++j)
+                            f16[i16 * 512 + lane * 8 + j] =
+                                f2h(conv_w_at(W, d, nb * 32 + n, kg * 16 + 8 * hi + j, wtap));
+                    }
+                for (int kg = 0; kg < cin / 8; ++kg, ++i32)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        int n = lane & 31, hi = lane >> 5;
+                        for (int j = 0; j < 4; ++j)
+                            f32[i32 * 256 + lane * 4 + j] =
+                                conv_w_at(W, d, nb * 32 + n, kg * 8 + 4 * hi + j, wtap);
+                    }
+            }
+    float* bias = reinterpret_cast<float*>(blob + ko.conv[l].bias);
+    for (int c = 0; c < d.cout; ++c) bias[c] = P[po.conv_b[l] + c];
+}
+
+size_t packed_bytes() { return pack_offsets().total; }
+
+// returns 0 on success
+int pack_weights_host(const float* P, size_t n_params, int head_present, uint8_t* blob, size_t blob_bytes) {
+    const ParamOff po = param_offsets(head_present);
+    const PackOff ko = pack_offsets();
+    if (n_params != po.total) return -2;
+    if (blob_bytes < ko.total) return -3;
+    std::memset(blob, 0, ko.total);
+    // conv_in: B operand of K-step s: lane (n,hi) -> W[n][tap = 2s+hi], tap 27 = 0
+    float* cw = reinterpret_cast<float*>(blob + ko.convin_w);
+    for (int s = 0; s < 14; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+            int n = lane & 31, tap = 2 * s + (lane >> 5);
+            cw[s * 64 + lane] = tap < 27 ? P[po.conv_in_w + n * 27 + tap] : 0.f;
+        }
+    float* cb = reinterpret_cast<float*>(blob + ko.convin_b);
+    for (int n = 0; n < 32; ++n) cb[n] = P[po.conv_in_b + n];
+    for (int l = 0; l < NCONV; ++l) pack_conv(P, po, ko, l, blob);
+    for (int h = 0; h < NHEADS; ++h) {
+        if (!(head_present >> h & 1)) continue;
+        pack_head16(P, po.head[h], HEAD_OUT[h], blob + ko.dec16[h]);
+        pack_head32(P, po.head[h], HEAD_OUT[h], blob + ko.dec32[h]);
+    }
+    return 0;
+}
+
+}  // namespace giga

@@ -1,0 +1,107 @@
+/* giga_hip.h -- C ABI of the MI355X-native GIGA hot path (libgiga_hip.so).
+ *
+ * The reference (UT-Austin-RPL/GIGA) has no FFI layer: the boundary it exposes for this path is the
+ * nn.Module surface consumed by scripts/train_giga.py:204 and src/vgn/detection_implicit.py:107.
+ * `giga_amd/` keeps that Python surface (same class names, kwargs, tensor layouts and state-dict
+ * keys) and calls the functions below underneath; each entry point cites the reference code it
+ * replaces (paths relative to /root/reference/src/vgn).  See INTEGRATION.md for the binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every device buffer is owned by the caller (PyTorch);
+ *     the library never allocates device memory and keeps no mutable global state, so it is
+ *     re-entrant per (stream, workspace);
+ *   - every launch is asynchronous on the caller's HIP stream `stream` (a hipStream_t);
+ *   - return value 0 = success, negative = error (giga_strerror); nothing throws across the ABI;
+ *   - `precision`: 0 = exact fp32 (v_mfma_f32_32x32x2_f32, bitwise fp32 fma chains),
+ *                  1 = f16 operands / fp32 accumulate (v_mfma_f32_32x32x16_f16);
+ *   - "NHWC planes": one buffer [3 (xz,xy,yz)][B][40 (H)][40 (W)][32 (C)] of float (precision 0) or
+ *     _Float16 (precision 1).  H/W follow the reference's plane indexing (ConvONets/common.py:246-251,
+ *     303-318): xz -> (H=z, W=x), xy -> (H=y, W=x), yz -> (H=z, W=y).
+ */
+#ifndef GIGA_HIP_H_
+#define GIGA_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GIGA_ABI_VERSION 1
+
+#define GIGA_HEAD_QUAL 1   /* decoder_qual  (out_dim 1, sigmoid epilogue)     */
+#define GIGA_HEAD_ROT 2    /* decoder_rot   (out_dim 4, L2-normalise epilogue) */
+#define GIGA_HEAD_WIDTH 4  /* decoder_width (out_dim 1)                        */
+#define GIGA_HEAD_TSDF 8   /* decoder_tsdf  (out_dim 1, raw logits)            */
+
+int giga_abi_version(void);
+const char* giga_strerror(int code);
+
+/* Number of fp32 parameters expected for a head set (bitmask of GIGA_HEAD_*): the reference
+ * state-dict flattened in its own key order (networks.py:21-35 load_network / state-dict keys of
+ * conv_onet/models/__init__.py:15-40).  giga: 581863 for all four heads. */
+size_t giga_param_count(int head_present);
+
+/* Size of the packed-weight blob produced by giga_pack_weights. */
+size_t giga_packed_bytes(void);
+
+/* HOST function: repack the flat fp32 parameters (host pointer) into MFMA operand fragments
+ * (host pointer, giga_packed_bytes() bytes).  The caller uploads the blob to the device.
+ * Replaces the weight ownership of nn.Module.load_state_dict (networks.py:33-34). */
+int giga_pack_weights(const float* params_host, size_t n_params, int head_present,
+                      void* packed_host, size_t packed_bytes);
+
+/* Scratch bytes giga_encoder_forward needs for a batch of B scenes. */
+size_t giga_encoder_workspace_bytes(int B, int precision);
+
+/* Introspection for tests: byte offsets of the 17 intermediate activations inside the encoder
+ * workspace, in order P0 (projected planes, U-Net input) A0 S0 Q0 A1 S1 Q1 A2 S2 U0 A3 A4 U1 A5 A6
+ * YZ XZ (see giga_encoder.hip).  All NHWC [3B][H][W][C] in the precision's element type
+ * (YZ/XZ: fp32 partial sums).  offsets must have room for 17 entries. */
+int giga_encoder_workspace_layout(int B, int precision, size_t* offsets);
+
+/* LocalVoxelEncoder.forward (encoder/voxels.py:89-121) + UNet.forward (encoder/unet.py:225-239):
+ * tsdf [B][40][40][40] fp32  ->  feature planes.
+ *   planes_nhwc : NHWC planes in the precision's element type (consumed by giga_decoder_forward)
+ *   planes_nchw : optional (may be NULL) fp32 [3][B][32][40][40], i.e. the reference's
+ *                 {'xz','xy','yz'} dict of (B,32,40,40) tensors stacked. */
+int giga_encoder_forward(const float* tsdf, const void* packed, void* planes_nhwc, float* planes_nchw,
+                         int B, int precision, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Repack reference-layout planes (three fp32 (B,32,40,40) tensors) into NHWC planes; used when
+ * LocalDecoder.forward(p, c_plane) (conv_onet/models/decoder.py:133) is handed foreign planes. */
+int giga_planes_pack(const float* xz, const float* xy, const float* yz, void* planes_nhwc, int B,
+                     int precision, void* stream);
+/* Inverse: NHWC planes -> fp32 [3][B][32][40][40]. */
+int giga_planes_unpack(const void* planes_nhwc, float* planes_nchw, int B, int precision, void* stream);
+
+/* Fused LocalDecoder.forward for every head in `head_mask` (decoder.py:133-176; ResnetBlockFC
+ * layers.py:39-47) over p [B][N][3] fp32 in [-0.5,0.5]^3 (any value is clamped like
+ * common.py:238-261).  Point g uses the planes of scene g / N.
+ *   qual [B*N], rot [B*N][4], width [B*N], occ [B*N]; a pointer may be NULL iff its head is not
+ *   in head_mask.
+ *   post != 0 applies the epilogues of ConvolutionalOccupancyNetwork.decode
+ *   (conv_onet/models/__init__.py:111-124): sigmoid(qual), F.normalize(rot, dim=2). */
+int giga_decoder_forward(const void* planes_nhwc, const float* p, const void* packed, int head_mask,
+                         float* qual, float* rot, float* width, float* occ, int B, int N,
+                         int precision, int post, void* stream);
+
+/* ---- measurement hooks (bench.py roofline): HIP events recorded on `stream` right before and
+ * after ONE kernel launch, so the kernel's duration is measured live on the stream it runs on.
+ * probe_stage: 0 conv_in+project, 1 plane_finalize, 2..14 = U-Net layers 0..12 (giga_layout.h kConv).
+ * The decoder variant brackets the single fused decoder launch. */
+void* giga_event_create(void);
+void giga_event_destroy(void* ev);
+int giga_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises on ev_stop */
+int giga_encoder_forward_probe(const float* tsdf, const void* packed, void* planes_nhwc, float* planes_nchw,
+                               int B, int precision, void* workspace, size_t workspace_bytes, void* stream,
+                               int probe_stage, void* ev_start, void* ev_stop);
+int giga_decoder_forward_probe(const void* planes_nhwc, const float* p, const void* packed, int head_mask,
+                               float* qual, float* rot, float* width, float* occ, int B, int N,
+                               int precision, int post, void* stream, void* ev_start, void* ev_stop);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GIGA_HIP_H_ */

@@ -91,6 +91,29 @@ def unet_forward(sd, x, prefix="encoder.unet."):
     return F.conv2d(x, sd[prefix + "conv_final.weight"], sd[prefix + "conv_final.bias"])
 
 
+def unet_stages(sd, x, prefix="encoder.unet."):
+    """Same arithmetic as unet_forward, returning every intermediate activation (NCHW) under the
+    workspace names of giga_encoder.hip (A0 S0 Q0 A1 S1 Q1 A2 S2 U0 A3 A4 U1 A5 A6 OUT)."""
+    def c3(name, t):
+        return F.relu(F.conv2d(t, sd[prefix + name + ".weight"], sd[prefix + name + ".bias"], padding=1))
+
+    def up(name, t):
+        return F.conv_transpose2d(t, sd[prefix + name + ".weight"], sd[prefix + name + ".bias"], stride=2)
+
+    st = {}
+    st["A0"] = c3("down_convs.0.conv1", x); st["S0"] = c3("down_convs.0.conv2", st["A0"])
+    st["Q0"] = F.max_pool2d(st["S0"], 2, 2)
+    st["A1"] = c3("down_convs.1.conv1", st["Q0"]); st["S1"] = c3("down_convs.1.conv2", st["A1"])
+    st["Q1"] = F.max_pool2d(st["S1"], 2, 2)
+    st["A2"] = c3("down_convs.2.conv1", st["Q1"]); st["S2"] = c3("down_convs.2.conv2", st["A2"])
+    st["U0"] = up("up_convs.0.upconv", st["S2"])
+    st["A3"] = c3("up_convs.0.conv1", torch.cat((st["U0"], st["S1"]), 1)); st["A4"] = c3("up_convs.0.conv2", st["A3"])
+    st["U1"] = up("up_convs.1.upconv", st["A4"])
+    st["A5"] = c3("up_convs.1.conv1", torch.cat((st["U1"], st["S0"]), 1)); st["A6"] = c3("up_convs.1.conv2", st["A5"])
+    st["OUT"] = F.conv2d(st["A6"], sd[prefix + "conv_final.weight"], sd[prefix + "conv_final.bias"])
+    return st
+
+
 def encoder_forward(sd, x):
     """LocalVoxelEncoder.forward voxels.py:89-121.  x (B,40,40,40) -> {'xz','xy','yz'}: (B,32,40,40)."""
     planes = project_planes(conv_in_relu(sd, x))

@@ -1,0 +1,130 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/giga_hip.h declares, the
+host-side packer and module tree behave (no compute calls: there is no GPU here)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from giga_amd import _capi, networks, weights
+from giga_amd.convonet import (ConvolutionalOccupancyNetwork, ConvolutionalOccupancyNetworkGeometry,
+                               LocalDecoder, LocalVoxelEncoder)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "giga_hip.h")).read()
+    declared = set(re.findall(r"\b(giga_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = _capi.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libgiga_hip.so does not export {name}"
+    assert declared == set(_capi.EXPORTS), declared ^ set(_capi.EXPORTS)
+    assert lib.giga_abi_version() == 1
+    assert lib.giga_strerror(0) == b"ok" and lib.giga_strerror(-4) == b"workspace too small"
+
+
+def test_param_counts_and_sizes():
+    lib = _capi.lib()
+    assert lib.giga_param_count(15) == 581863
+    assert lib.giga_param_count(7) == 581863 - 26241   # giga_aff: no occupancy head
+    assert lib.giga_param_count(8) == 476800 + 26241   # giga_geo
+    assert lib.giga_param_count(0) == 476800
+    assert lib.giga_packed_bytes() > 0
+    assert lib.giga_encoder_workspace_bytes(0, 0) == 0
+    assert lib.giga_encoder_workspace_bytes(32, 1) < lib.giga_encoder_workspace_bytes(32, 0)
+
+
+def test_argument_validation_without_gpu():
+    lib = _capi.lib()
+    assert lib.giga_encoder_forward(None, None, None, None, 1, 0, None, 0, None) == -1
+    assert lib.giga_encoder_forward(None, None, None, None, 0, 0, None, 0, None) == 0     # empty batch
+    assert lib.giga_decoder_forward(None, None, None, 7, None, None, None, None, 0, 5, 0, 1, None) == 0
+    assert lib.giga_decoder_forward(None, None, None, 7, None, None, None, None, 1, 5, 3, 1, None) == -5
+    assert lib.giga_pack_weights(None, 0, 15, None, 0) == -1
+    flat = torch.zeros(10)
+    with pytest.raises(_capi.GigaHipError):
+        _capi.pack_weights(flat, 15)
+
+
+def test_pack_is_deterministic_and_sensitive(sd7):
+    flat = torch.cat([v.reshape(-1) for v in sd7.values()])
+    a = _capi.pack_weights(flat, 15)
+    b = _capi.pack_weights(flat.clone(), 15)
+    assert torch.equal(a, b)
+    flat2 = flat.clone(); flat2[12345] += 1.0
+    assert not torch.equal(a, _capi.pack_weights(flat2, 15))
+
+
+def test_conv_fragments_round_trip(sd7):
+    """Invert the documented conv fragment layout (giga_pack.cpp) and recover the weights."""
+    flat = torch.cat([v.reshape(-1) for v in sd7.values()])
+    blob = _capi.pack_weights(flat, 15).numpy()
+    at = 14 * 64 * 4 + 256
+    W = sd7["encoder.unet.down_convs.0.conv1.weight"].numpy()         # (32,32,3,3), layer 0
+    f16 = blob[at:at + 18 * 1024].view(np.float16).reshape(9, 2, 64, 8)      # [tap][kg][lane][j]
+    f32 = blob[at + 18 * 1024:at + 54 * 1024].view(np.float32).reshape(9, 4, 64, 4)
+    for tap in (0, 4, 8):
+        for lane in (0, 17, 40, 63):
+            n, hi = lane & 31, lane >> 5
+            for kg in range(4):
+                np.testing.assert_array_equal(f32[tap, kg, lane], W[n, kg * 8 + 4 * hi:kg * 8 + 4 * hi + 4, tap // 3, tap % 3])
+            for kg in range(2):
+                np.testing.assert_array_equal(f16[tap, kg, lane],
+                                              W[n, kg * 16 + 8 * hi:kg * 16 + 8 * hi + 8, tap // 3, tap % 3].astype(np.float16))
+    # conv_in B operands: [s][lane] = W[n][tap 2s+hi]
+    ci = blob[:14 * 64 * 4].view(np.float32).reshape(14, 64)
+    Wi = sd7["encoder.conv_in.weight"].numpy().reshape(32, 27)
+    assert ci[3, 5] == Wi[5, 6] and ci[3, 37] == Wi[5, 7] and ci[13, 40] == 0.0 and ci[13, 8] == Wi[8, 26]
+
+
+def test_module_tree_matches_reference_state_dict():
+    for name, nheads in (("giga", 4), ("giga_aff", 3), ("giga_detach", 4)):
+        net = networks.get_network(name)
+        assert isinstance(net, ConvolutionalOccupancyNetwork)
+        keys = list(net.state_dict().keys())
+        ref = list(weights.giga_param_shapes(with_tsdf=nheads == 4).keys())
+        assert keys == ref
+        for k, v in net.state_dict().items():
+            assert tuple(v.shape) == weights.giga_param_shapes()[k]
+    geo = networks.get_network("giga_geo")
+    assert isinstance(geo, ConvolutionalOccupancyNetworkGeometry)
+    assert list(geo.state_dict().keys()) == list(weights.giga_param_shapes(heads=("decoder_tsdf",)).keys())
+    with pytest.raises(NotImplementedError):
+        networks.get_network("vgn")
+
+
+def test_reference_init_conventions():
+    net = networks.get_network("giga")
+    assert float(net.decoder_qual.blocks[0].fc_1.weight.abs().max()) == 0.0     # layers.py:37
+    assert float(net.encoder.unet.conv_final.bias.abs().max()) == 0.0           # unet.py:216
+    assert isinstance(net.encoder, LocalVoxelEncoder) and isinstance(net.decoder_rot, LocalDecoder)
+    assert net.decoder_rot.fc_out.weight.shape == (4, 32)
+
+
+def test_cpu_tensors_fail_loudly():
+    net = networks.get_network("giga").eval()
+    with torch.no_grad():
+        with pytest.raises(_capi.GigaHipError):
+            net(torch.zeros(1, 40, 40, 40), torch.zeros(1, 4, 3))
+        with pytest.raises(_capi.GigaHipError):
+            net.encoder(torch.zeros(1, 40, 40, 40))
+    with pytest.raises(NotImplementedError):          # autograd path is not built yet
+        net(torch.zeros(1, 40, 40, 40), torch.zeros(1, 4, 3))
+
+
+def test_unsupported_configs_are_rejected():
+    with pytest.raises(NotImplementedError):
+        LocalDecoder(c_dim=128, hidden_size=256)
+    with pytest.raises(NotImplementedError):
+        LocalVoxelEncoder(c_dim=32, unet=False)
+
+
+def test_load_network_round_trip(tmp_path, sd7):
+    path = tmp_path / "vgn_giga_7.pt"
+    torch.save(sd7, path)
+    net = networks.load_network(path, "cpu")              # model name parsed from the stem (networks.py:28-31)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, sd7[k])

@@ -1,0 +1,188 @@
+"""GPU parity: the HIP path (through the module API -> C ABI) against the CPU oracle and against the
+reference-generated golden fixtures.  Tolerances: fp32 path 1e-4 absolute on O(1) outputs (fp32
+MFMA = fp32 fma chains, summation order differs from ATen's); f16 path per the north star 1e-3 on
+the head outputs that matter (sigmoid qual / unit rot), looser on raw logits (stated per test)."""
+import numpy as np
+import pytest
+import torch
+
+from giga_amd import networks, synth, weights
+from oracle import giga_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def net(dev, sd7):
+    n = networks.get_network("giga")
+    n.load_state_dict(sd7)
+    return n.to(dev).eval()
+
+
+def maxerr(a, b):
+    return (a.detach().float().cpu() - torch.as_tensor(b).float()).abs().max().item()
+
+
+def test_native_library_is_loaded():
+    from giga_amd import _capi
+    assert _capi.lib().giga_abi_version() == 1
+    maps = open("/proc/self/maps").read()
+    assert "libgiga_hip.so" in maps
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-4), ("fp16", 2e-2)])
+def test_encoder_matches_oracle_and_g1(net, dev, sd7, golden, prec, tol):
+    net.set_precision(prec)
+    x = torch.from_numpy(synth.tsdf_batch(0, 2))
+    with torch.no_grad():
+        planes = net.encode_inputs(x.to(dev))
+        ref = O.encoder_forward(sd7, x)
+    g = golden("g1_encoder.npz")
+    for k in O.PLANES:
+        assert planes[k].shape == (2, 32, 40, 40)
+        assert maxerr(planes[k], ref[k]) < tol, k
+        assert maxerr(planes[k][:, :, ::2, ::2], g[f"plane_{k}_s2"]) < tol, k
+    # NHWC image used by the decoder is the same data
+    nhwc = planes.nhwc.permute(0, 1, 4, 2, 3).float().cpu()
+    assert (nhwc - torch.stack([ref[k] for k in O.PLANES])).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-4), ("fp16", 1e-2)])
+def test_decoder_heads_on_foreign_planes_g2b(net, dev, sd7, golden, prec, tol):
+    """LocalDecoder.forward(p, c_plane) with reference-layout planes (decoder.py:133)."""
+    g = golden("g2b_decoder_random_planes.npz")
+    rng = np.random.default_rng(int(g["plane_seed"]))
+    rp = {k: torch.from_numpy(rng.standard_normal((2, 32, 40, 40)).astype(np.float32)).to(dev)
+          for k in ("xz", "xy", "yz")}
+    p = torch.from_numpy(synth.query_points(0, 2, 2048, stream=1, half_width=0.6)).to(dev)
+    with torch.no_grad():
+        for h in weights.HEADS:
+            dec = getattr(net, h)
+            dec.precision = prec
+            out = dec(p, rp)
+            assert maxerr(out, g["raw_" + h]) < tol * max(1.0, float(np.abs(g["raw_" + h]).max())), h
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-4), ("fp16", 1e-2)])
+def test_model_forward_g2(net, dev, sd7, golden, prec, tol):
+    net.set_precision(prec)
+    g = golden("g2_decoder.npz")
+    x = torch.from_numpy(synth.tsdf_batch(0, 2)).to(dev)
+    p = torch.from_numpy(synth.query_points(0, 2, 2048, stream=1, half_width=0.6)).to(dev)
+    with torch.no_grad():
+        qual, rot, width, tsdf = net(x, p, p_tsdf=p)
+    assert qual.shape == (2, 2048) and rot.shape == (2, 2048, 4) and width.shape == (2, 2048) and tsdf.shape == (2, 2048)
+    assert maxerr(qual, g["qual"]) < tol
+    assert maxerr(rot, g["rot"]) < tol
+    assert maxerr(width, g["width"]) < tol * 2
+    assert maxerr(tsdf, g["tsdf"]) < tol * 2
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-4), ("fp16", 1e-2)])
+def test_inference_lattice_g3_and_predict(net, dev, sd7, golden, prec, tol):
+    from giga_amd.detection import predict, query_lattice
+    net.set_precision(prec)
+    g = golden("g3_lattice.npz")
+    pos = query_lattice(40, dev)
+    assert pos.shape == (1, 64000, 3)
+    q, r, w = predict(synth.tsdf_batch(int(g["scene"]), 1), pos, net, dev)
+    assert q.shape == (64000,) and r.shape == (64000, 4) and w.shape == (64000,)
+    sub = g["subset"]
+    assert np.abs(q[sub] - g["qual"]).max() < tol
+    assert np.abs(r[sub] - g["rot"]).max() < tol
+    assert np.abs(w[sub] - g["width"]).max() < tol * 2
+    if prec == "fp32":
+        for arr, name in ((q, "qual"), (r, "rot"), (w, "width")):
+            s = g[name + "_sums"]
+            assert abs(arr.astype(np.float64).sum() - s[0]) < 2e-5 * max(1.0, s[1])
+
+
+def test_edge_cases_g5(net, dev, sd7, golden):
+    net.set_precision("fp32")
+    g = golden("g5_edges.npz")
+    with torch.no_grad():
+        for name, val in (("zeros", 0.0), ("ones", 1.0)):
+            pl = net.encode_inputs(torch.full((1, 40, 40, 40), val, device=dev))
+            for k in O.PLANES:
+                assert maxerr(pl[k][:, :, ::4, ::4], g[f"{name}_plane_{k}_s4"]) < 1e-4
+        pe = torch.from_numpy(g["edge_points"]).to(dev)
+        x = torch.from_numpy(synth.tsdf_batch(int(g["edge_scene"]), 1)).to(dev)
+        q, r, w, t = net(x, pe, p_tsdf=pe)
+    assert maxerr(q, g["edge_qual"]) < 1e-4 and maxerr(r, g["edge_rot"]) < 1e-4
+    assert maxerr(w, g["edge_width"]) < 2e-4 and maxerr(t, g["edge_tsdf"]) < 2e-4
+
+
+def test_ragged_and_tiny_batches(net, dev, sd7):
+    """N not a multiple of the 32-point tile, N = 1 (train_giga's single grasp query), B = 1 and 5."""
+    net.set_precision("fp32")
+    for B, N, M in ((1, 1, 7), (5, 1, 2048), (3, 33, 95), (2, 257, 1)):
+        x = torch.from_numpy(synth.tsdf_batch(40, B))
+        p = torch.from_numpy(synth.query_points(40, B, N, stream=4))
+        pt = torch.from_numpy(synth.query_points(40, B, M, stream=5))
+        with torch.no_grad():
+            out = net(x.to(dev), p.to(dev), p_tsdf=pt.to(dev))
+            ref = O.model_forward(sd7, x, p, p_tsdf=pt)
+        for a, b in zip(out, ref):
+            assert a.shape == b.shape
+            assert maxerr(a, b) < 2e-4, (B, N, M)
+
+
+def test_scene_independence_and_determinism(net, dev):
+    """Batch dim is carried untouched: scene i of a batch == the same scene alone; reruns are bit-identical."""
+    net.set_precision("fp32")
+    x = torch.from_numpy(synth.tsdf_batch(7, 4)).to(dev)
+    p = torch.from_numpy(synth.query_points(7, 4, 500, stream=6)).to(dev)
+    with torch.no_grad():
+        full = net(x, p, p_tsdf=p)
+        again = net(x, p, p_tsdf=p)
+        one = net(x[2:3].contiguous(), p[2:3].contiguous(), p_tsdf=p[2:3].contiguous())
+    for a, b in zip(full, again):
+        assert torch.equal(a, b)
+    for a, b in zip(full, one):
+        assert maxerr(a[2:3], b.cpu()) < 1e-6
+
+
+def test_full_size_properties_c2_c4(net, dev):
+    """BASELINE sizes (B=32 x 2048, and 64 000 lattice queries): size-independent properties --
+    unit quaternions, qual in (0,1), finite outputs, fp16 within 1e-2 of fp32."""
+    x = torch.from_numpy(synth.tsdf_batch(100, 32)).to(dev)
+    p = torch.from_numpy(synth.query_points(100, 32, 2048, stream=7)).to(dev)
+    with torch.no_grad():
+        net.set_precision("fp32")
+        q, r, w, t = net(x, p, p_tsdf=p)
+        net.set_precision("fp16")
+        q16, r16, w16, t16 = net(x, p, p_tsdf=p)
+        lat = torch.from_numpy(synth.inference_lattice()).to(dev)
+        ql, rl, wl = net(x[:1].contiguous(), lat)
+    for v in (q, r, w, t, ql, rl, wl):
+        assert torch.isfinite(v).all()
+    assert (r.norm(dim=-1) - 1).abs().max().item() < 1e-5 and (rl.norm(dim=-1) - 1).abs().max().item() < 1e-3
+    assert q.min().item() > 0 and q.max().item() < 1
+    assert maxerr(q16, q.cpu()) < 1e-2 and maxerr(r16, r.cpu()) < 2e-2 and maxerr(w16, w.cpu()) < 2e-2
+    net.set_precision("fp32")
+
+
+def test_variants_aff_geo(dev):
+    """giga_aff (no occupancy head) and giga_geo (occupancy only) run on the same kernels."""
+    sd_aff = weights.make_state_dict(3, with_tsdf=False)
+    aff = networks.get_network("giga_aff"); aff.load_state_dict(sd_aff); aff = aff.to(dev).eval()
+    x = torch.from_numpy(synth.tsdf_batch(9, 2)); p = torch.from_numpy(synth.query_points(9, 2, 100))
+    with torch.no_grad():
+        out = aff(x.to(dev), p.to(dev))
+        ref = O.model_forward(sd_aff, x, p)
+    for a, b in zip(out, ref):
+        assert maxerr(a, b) < 1e-4
+    sd_geo = weights.make_state_dict(4, heads=("decoder_tsdf",))
+    geo = networks.get_network("giga_geo"); geo.load_state_dict(sd_geo); geo = geo.to(dev).eval()
+    with torch.no_grad():
+        t = geo.infer_geo(x.to(dev), p.to(dev))
+        ref_t = O.infer_geo(sd_geo, x, p)
+        occ = geo.decode_occ(p.to(dev), geo.encode_inputs(x.to(dev)))
+    assert maxerr(t, ref_t) < 1e-4
+    assert maxerr(occ.logits, ref_t) < 1e-4
