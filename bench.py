@@ -255,26 +255,47 @@ def bench_c4(net, sd, dev, L, _capi, synth, decode_heads, Bc=32, steps=10):
 
 def cpu_baseline(sd, synth, M, budget_s=20.0):
     """Time the CPU oracle (oracle/giga_oracle.py, a port of the reference's PyTorch path pinned to
-    reference-generated goldens) on a bounded sample of the same workload."""
+    reference-generated goldens) on a bounded sample of the same workload.  torch's intra-op pool
+    collapses when oversubscribed on very wide hosts, so the thread count is calibrated first
+    (best of a few candidates on a 2-scene pass) and reported as `cores`."""
     from oracle import giga_oracle as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
     Bs = 8
     x = torch.from_numpy(synth.tsdf_batch(0, Bs))
     pos = torch.from_numpy(synth.query_points(0, Bs, 1, stream=2))
     pos_occ = torch.from_numpy(synth.query_points(0, Bs, M, stream=3))
+
+    def one(n):
+        t0 = time.perf_counter()
+        O.model_forward(sd, x[:n], pos[:n], p_tsdf=pos_occ[:n])
+        return time.perf_counter() - t0
+
     with torch.no_grad():
-        O.model_forward(sd, x, pos, p_tsdf=pos_occ)          # warm-up
+        cands = sorted({c for c in (8, 16, 32, 64, avail) if c <= avail})
+        best, best_t = cands[0], None
+        for c in cands:
+            torch.set_num_threads(c)
+            one(2)
+            t = min(one(2), one(2))
+            if best_t is None or t < best_t:
+                best, best_t = c, t
+            if t > 3.0:
+                break
+        torch.set_num_threads(best)
+        one(Bs)
         times = []
         t_start = time.perf_counter()
-        while len(times) < 10 and time.perf_counter() - t_start < budget_s:
-            t0 = time.perf_counter()
-            O.model_forward(sd, x, pos, p_tsdf=pos_occ)
-            times.append(time.perf_counter() - t0)
+        while len(times) < 10 and (not times or time.perf_counter() - t_start < budget_s):
+            times.append(one(Bs))
     med = float(np.median(times))
-    return {"value": Bs / med, "unit": "scenes/s", "cores": cores, "kind": "port",
+    return {"value": Bs / med, "unit": "scenes/s", "cores": best, "kind": "port",
             "sample": f"{len(times)} passes of {Bs} scenes (1 grasp query + {M} occupancy queries each), "
-                      f"torch {torch.__version__} CPU fp32, median", "ms_per_pass": med * 1e3}
+                      f"torch {torch.__version__} CPU fp32, median; {best} intra-op threads chosen from "
+                      f"{cands} on a host with {avail} usable cores",
+            "ms_per_pass": med * 1e3}
 
 
 if __name__ == "__main__":

@@ -144,8 +144,10 @@ def test_scene_independence_and_determinism(net, dev):
         one = net(x[2:3].contiguous(), p[2:3].contiguous(), p_tsdf=p[2:3].contiguous())
     for a, b in zip(full, again):
         assert torch.equal(a, b)
+    # (not bit-identical: the number of ix-slabs of the projection kernel, hence the fp32 summation
+    #  order of the yz plane, depends on the batch size)
     for a, b in zip(full, one):
-        assert maxerr(a[2:3], b.cpu()) < 1e-6
+        assert maxerr(a[2:3], b.cpu()) < 1e-5
 
 
 def test_full_size_properties_c2_c4(net, dev):
