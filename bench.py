@@ -216,8 +216,9 @@ def bench_c4(net, sd, dev, L, _capi, synth, decode_heads, Bc=32, steps=10):
     N = 64000
     net.set_precision("fp16")
     blob = net.packed_blob(dev)
+    from giga_amd.detection import query_lattice
     x = torch.from_numpy(synth.tsdf_batch(1000, Bc)).to(dev)
-    lat = torch.from_numpy(synth.inference_lattice()).to(dev).expand(Bc, -1, -1).contiguous()
+    lat = query_lattice(40, dev)          # the VGNImplicit lattice (detection_implicit.py:28-31), shared by the batch
     ev = [(L.giga_event_create(), L.giga_event_create()) for _ in range(steps)]
 
     def step(pr=None):
@@ -244,7 +245,8 @@ def bench_c4(net, sd, dev, L, _capi, synth, decode_heads, Bc=32, steps=10):
     ach = flops / (dec_ms * 1e-3) / 1e12
     net.set_precision("fp32")
     return {
-        "workload": f"c4: batch={Bc} scenes x 64000 lattice queries, 3 grasp heads, f16 MFMA decoder + f16 encoder",
+        "workload": f"c4: batch={Bc} scenes x the 64000-point inference lattice, 3 grasp heads, f16 MFMA decoder "
+                    f"(lattice path) + f16 encoder",
         "scenes_per_sec": Bc * steps / el, "query_points_per_sec": Bc * steps * N / el,
         "ms_per_step": el / steps * 1e3, "dtype": "f16 operands / f32 accumulate",
         "roofline": {"kernel": "decoder_f16_kernel", "bound": "mfma", "achieved": ach, "peak": PEAK_F16_MFMA_TFLOPS,

@@ -51,6 +51,13 @@ _SIGNATURES = {
                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                                   ctypes.c_void_p, ctypes.c_void_p]),
+    "giga_lattice_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "giga_decoder_forward_lattice": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                    ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_void_p]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

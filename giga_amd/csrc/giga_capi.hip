@@ -18,10 +18,12 @@ int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, fl
 struct DecArgs {
     const void* planes; const float* p; const uint8_t* blob;
     size_t head_off[NHEADS]; int head_id[NHEADS]; float* out[NHEADS];
-    int nheads; int B, N; long long P; int nbatch; int post;
+    int nheads; int B, N; long long P; int nbatch; int post; const float* lin; int R;
+    float invN; unsigned mR, mR2;
 };
 int launch_decoder(const DecArgs& a, int precision, hipStream_t s, void* ev0, void* ev1);
 int launch_planes_pack(const float* xz, const float* xy, const float* yz, void* dst, int B, int precision, hipStream_t s);
+int launch_lattice_resample(const void* planes, const float* lin, void* out, int B, int R, int precision, hipStream_t s);
 int launch_planes_unpack(const void* src, float* dst, int B, int precision, hipStream_t s);
 }  // namespace giga
 
@@ -144,6 +146,39 @@ int giga_decoder_forward_probe(const void* planes_nhwc, const float* p, const vo
     }
     a.B = B; a.N = N; a.P = (long long)B * N; a.post = post;
     return launch_decoder(a, precision, static_cast<hipStream_t>(stream), ev_start, ev_stop);
+}
+
+size_t giga_lattice_workspace_bytes(int B, int R, int precision) {
+    if (B <= 0 || R <= 0) return 0;
+    return (size_t)3 * B * R * R * CD * (precision == 1 ? 2 : 4);
+}
+
+int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, const void* packed, int head_mask,
+                                 float* qual, float* rot, float* width, float* occ, int B, int R, int precision,
+                                 int post, void* workspace, size_t workspace_bytes, void* stream, void* ev_start,
+                                 void* ev_stop) {
+    if (B < 0 || R < 0 || R > 64) return -1;
+    if (precision != 0 && precision != 1) return -5;
+    if (B == 0 || R == 0 || (head_mask & 15) == 0) return 0;
+    if (!planes_nhwc || !lin || !packed || !workspace) return -1;
+    if (workspace_bytes < giga_lattice_workspace_bytes(B, R, precision)) return -4;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = launch_lattice_resample(planes_nhwc, lin, workspace, B, R, precision, s);
+    if (rc) return rc;
+    const PackOff ko = pack_offsets();
+    DecArgs a{};
+    a.planes = workspace; a.p = nullptr; a.blob = static_cast<const uint8_t*>(packed);
+    float* outs[NHEADS] = {qual, rot, width, occ};
+    for (int h = 0; h < NHEADS; ++h) {
+        if (!(head_mask >> h & 1)) continue;
+        if (!outs[h]) return -6;
+        a.head_id[a.nheads] = h;
+        a.head_off[a.nheads] = precision == 1 ? ko.dec16[h] : ko.dec32[h];
+        a.out[a.nheads] = outs[h];
+        ++a.nheads;
+    }
+    a.B = B; a.N = R * R * R; a.P = (long long)B * a.N; a.post = post; a.lin = lin; a.R = R;
+    return launch_decoder(a, precision, s, ev_start, ev_stop);
 }
 
 }  // extern "C"

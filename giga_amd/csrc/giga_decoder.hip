@@ -29,6 +29,10 @@ struct DecArgs {
     long long P;
     int nbatch;              // number of workgroup batches
     int post;                // 1: sigmoid(qual), normalize(rot)  (models/__init__.py:120-122)
+    const float* lin;        // lattice mode: the R lattice coordinates (detection_implicit.py:28-31)
+    int R;                   // lattice mode: points per axis; planes = lattice-resampled planes [3][B][R][R][32]
+    float invN;              // 1 / N
+    unsigned mR, mR2;        // ceil(2^32 / R), ceil(2^32 / R^2)   (lattice mode)
 };
 
 __device__ __forceinline__ void store_head(const DecArgs& a, int h, long long g, float d0, float d1,
@@ -55,102 +59,221 @@ __device__ __forceinline__ void stage_blob(uint8_t* smem, const uint8_t* src, in
 }
 
 // =============================== f16 MFMA path =====================================================
-template <int T>
-__global__ __launch_bounds__(256, 2) void decoder_f16_kernel(DecArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = lane & 31, hi = lane >> 5;
-    const half8* W = reinterpret_cast<const half8*>(smem);
-    const float* ctab = reinterpret_cast<const float*>(smem + (size_t)DEC16_FRAGS * FRAG);
-    const half_t* planes = reinterpret_cast<const half_t*>(a.planes);
-    const size_t plane_stride = (size_t)a.B * RES * RES * CD;
+// Persistent workgroups of 8 waves (2 per SIMD).  Round = 512 points (T=2 tiles of 32 per wave): the
+// gathered features stay in registers for all heads.  Head weight images (59 KiB) are DOUBLE-BUFFERED
+// in LDS and filled by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip): while the MFMA chain of
+// step s runs out of buffer s&1, the image of step s+1 streams into the other buffer.  One workgroup
+// barrier per step; it is both "image s has landed" and "everyone left image s-1".
+constexpr int DEC16_CHUNKS = (int)(DEC16_BYTES / FRAG);      // 59
 
-    for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
-        // ---------------- gather: 96 features -> 6 B-operand chunks per tile ----------------------
-        half8 cf[T][6], ax[T];
-        long long gidx[T];
-        bool valid[T];
+template <int NW>
+__device__ __forceinline__ void dma_head_image(const uint8_t* src, uint8_t* lds_dst, int wave, int lane) {
+    for (int c = wave; c < DEC16_CHUNKS; c += NW)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + (size_t)c * FRAG + lane * 16),
+            (__attribute__((address_space(3))) void*)(lds_dst + c * FRAG), 16, 0, 0);
+}
+
+template <int T, bool LATTICE, int NW>
+__global__ __launch_bounds__(NW * 64) void decoder_f16_kernel(DecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, hi = lane >> 5;
+    const half_t* planes = reinterpret_cast<const half_t*>(a.planes);
+    const size_t plane_stride = LATTICE ? (size_t)a.B * a.R * a.R * CD : (size_t)a.B * RES * RES * CD;
+    const int rounds = (a.nbatch - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (rounds <= 0) return;
+    // Step s uses the weight image of head s % nheads.  Waves 4..7 (the second wave of every SIMD) run
+    // one step behind waves 0..3 and visit the heads in rotated order (1,2,..,0): while one wave of a
+    // SIMD gathers features for its next 64 points, the other is inside its MFMA chain.
+    const int phase = a.nheads > 1 ? (wave >> 2) % a.nheads : 0;
+    const int work_steps = rounds * a.nheads;
+    const int max_phase = a.nheads > 1 ? ((NW / 4 - 1) < (a.nheads - 1) ? (NW / 4 - 1) : (a.nheads - 1)) : 0;
+    const int nsteps = work_steps + max_phase;
+
+    dma_head_image<NW>(a.blob + a.head_off[0], smem, wave, lane);
+
+    half8 cf[T][6], ax[T];
+    long long gidx[T];
+    bool valid[T];
+    for (int s = 0; s < nsteps; ++s) {
+        const int h = s % a.nheads;                           // head whose image is in buffer s&1
+        uint8_t* buf = smem + (a.nheads > 1 ? (s & 1) : 0) * DEC16_BYTES;
+        if (a.nheads > 1 || s == 0) {
+            // vmcnt(0): my share of image s has landed.  The BUILTIN form (not inline asm) so that hipcc's
+            // waitcnt scoreboard knows no LDS-DMA is pending afterwards; otherwise it drains vmcnt(0) at
+            // every use of an ordinary global load in the gather below (simm16: vm=0, exp=7, lgkm=15).
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();                                  // everyone's share; everyone left image s-1
+        }
+        // The LDS-DMA of the next image is issued AFTER this step's gather: with a DMA in flight hipcc
+        // waits vmcnt(0) at every use of an ordinary global load, which would serialise the 48 gather
+        // loads of a wave behind the 59 KiB transfer.  The MFMA chain below gives the DMA ~2 us to land.
+        const bool dma_next = a.nheads > 1 && s + 1 < nsteps;
+        const uint8_t* dma_src = a.blob + a.head_off[(s + 1) % a.nheads];
+        uint8_t* dma_dst = smem + ((s + 1) & 1) * DEC16_BYTES;
+        const int ls = s - phase;                             // this wave's own step counter
+        if (ls < 0 || ls >= work_steps) {                     // idle edge step of the staggered half
+            if (dma_next) dma_head_image<NW>(dma_src, dma_dst, wave, lane);
+            continue;
+        }
+        const bool new_round = ls % a.nheads == 0;
+        const int batch = (int)blockIdx.x + (ls / a.nheads) * (int)gridDim.x;
+        if (LATTICE && new_round) {
+            // ---------------- lattice gather: the planes were resampled at the R lattice coordinates
+            // (lattice_resample_kernel), so the 96 features of lattice point (ix,iy,iz) are three
+            // pixels read straight into B-operand registers: 6 x 16 B per lane, no interpolation.
+            const int R = a.R, R2 = R * R;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            long long g = ((long long)batch * 4 * T + wave * T + t) * 32 + n;
-            valid[t] = g < a.P;
-            if (!valid[t]) g = a.P - 1;
-            gidx[t] = g;
-            const float px = a.p[3 * g + 0], py = a.p[3 * g + 1], pz = a.p[3 * g + 2];
-            const int b = (int)(g / a.N);
-            const float nx = norm_coord(px), ny = norm_coord(py), nz = norm_coord(pz);
-            // aux chunk: [p_hi(3), 1, p_lo(3), 1] on hi=0 lanes, [p_hi(3), 0...] on hi=1 lanes
-            half_t xh = (half_t)px, yh = (half_t)py, zh = (half_t)pz;
-            half8 av = {xh, yh, zh, (half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0};
-            if (hi == 0) {
-                av[3] = (half_t)1.0f;
-                av[4] = (half_t)(px - (float)xh); av[5] = (half_t)(py - (float)yh);
-                av[6] = (half_t)(pz - (float)zh); av[7] = (half_t)1.0f;
-            }
-            ax[t] = av;
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                // xz: (u,v)=(x,z)  xy: (x,y)  yz: (y,z)      common.py:246-251
-                const float u = pl == 2 ? ny : nx;
-                const float v = pl == 1 ? ny : nz;
-                const Bilin bl = bilin_setup(u, v);
-                const half_t* base = planes + pl * plane_stride + (size_t)b * RES * RES * CD + 8 * hi;
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const half8 v00 = *reinterpret_cast<const half8*>(base + (size_t)bl.o00 * CD + 16 * hf);
-                    const half8 v01 = *reinterpret_cast<const half8*>(base + (size_t)bl.o01 * CD + 16 * hf);
-                    const half8 v10 = *reinterpret_cast<const half8*>(base + (size_t)bl.o10 * CD + 16 * hf);
-                    const half8 v11 = *reinterpret_cast<const half8*>(base + (size_t)bl.o11 * CD + 16 * hf);
-                    half8 r;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        float acc = (float)v00[j] * bl.w00;
-                        acc = fmaf((float)v01[j], bl.w01, acc);
-                        acc = fmaf((float)v10[j], bl.w10, acc);
-                        acc = fmaf((float)v11[j], bl.w11, acc);
-                        r[j] = (half_t)acc;
-                    }
-                    cf[t][2 * pl + hf] = r;
+            for (int t = 0; t < T; ++t) {
+                long long g = ((long long)batch * NW * T + wave * T + t) * 32 + n;
+                valid[t] = g < a.P;
+                if (!valid[t]) g = a.P - 1;
+                gidx[t] = g;
+                int b, r;
+                split_scene(g, a.N, a.invN, b, r);
+                const int ix = div_magic(r, a.mR2), rz = r - ix * R2;
+                const int iy = div_magic(rz, a.mR), iz = rz - iy * R;
+                const float px = a.lin[ix], py = a.lin[iy], pz = a.lin[iz];
+                half_t xh = (half_t)px, yh = (half_t)py, zh = (half_t)pz;
+                half8 av = {xh, yh, zh, (half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0};
+                if (hi == 0) {
+                    av[3] = (half_t)1.0f;
+                    av[4] = (half_t)(px - (float)xh); av[5] = (half_t)(py - (float)yh);
+                    av[6] = (half_t)(pz - (float)zh); av[7] = (half_t)1.0f;
                 }
+                ax[t] = av;
+                const half_t* base = planes + (size_t)b * R2 * CD + 8 * hi;
+                const int off[3] = {iz * R + ix, iy * R + ix, iz * R + iy};   // (H,W): xz->(z,x) xy->(y,x) yz->(z,y)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf)
+                        cf[t][2 * pl + hf] = *reinterpret_cast<const half8*>(base + pl * plane_stride +
+                                                                             (size_t)off[pl] * CD + 16 * hf);
             }
         }
-        // ---------------- heads --------------------------------------------------------------------
-        for (int h = 0; h < a.nheads; ++h) {
-            __syncthreads();
-            stage_blob(smem, a.blob + a.head_off[h], (int)DEC16_BYTES);
-            __syncthreads();
+        if (!LATTICE && new_round) {
+            // ---------------- gather: 96 features -> 6 B-operand chunks per tile ------------------
+            float pxs[T], pys[T], pzs[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {                    // all coordinate loads first: one round trip
+                long long g = ((long long)batch * NW * T + wave * T + t) * 32 + n;
+                valid[t] = g < a.P;
+                if (!valid[t]) g = a.P - 1;
+                gidx[t] = g;
+                pxs[t] = a.p[3 * g + 0]; pys[t] = a.p[3 * g + 1]; pzs[t] = a.p[3 * g + 2];
+            }
+            // 12 groups (tile, plane, channel half) of 4 tap loads.  Explicit software pipeline: groups
+            // 0..5 are issued up front (24 x 16 B loads in flight per lane), then group k is interpolated
+            // while group k+6 is issued; the sched_barriers pin that order (left alone, hipcc issues the
+            // second tile's taps four at a time with a full round trip each).
+            Bilin bl[T][3];
+            const half_t* pbase[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float px = pxs[t], py = pys[t], pz = pzs[t];
+                int b, rdummy;
+                split_scene(gidx[t], a.N, a.invN, b, rdummy);
+                const float nx = norm_coord(px), ny = norm_coord(py), nz = norm_coord(pz);
+                // aux chunk: [p_hi(3), 1, p_lo(3), 1] on hi=0 lanes, [p_hi(3), 0...] on hi=1 lanes
+                half_t xh = (half_t)px, yh = (half_t)py, zh = (half_t)pz;
+                half8 av = {xh, yh, zh, (half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0};
+                if (hi == 0) {
+                    av[3] = (half_t)1.0f;
+                    av[4] = (half_t)(px - (float)xh); av[5] = (half_t)(py - (float)yh);
+                    av[6] = (half_t)(pz - (float)zh); av[7] = (half_t)1.0f;
+                }
+                ax[t] = av;
+                // xz: (u,v)=(x,z)  xy: (x,y)  yz: (y,z)      common.py:246-251
+                bl[t][0] = bilin_setup(nx, nz);
+                bl[t][1] = bilin_setup(nx, ny);
+                bl[t][2] = bilin_setup(ny, nz);
+                pbase[t] = planes + (size_t)b * RES * RES * CD + 8 * hi;
+            }
+            constexpr int NG = T * 6, DEPTH = 6;
+            half8 raw[NG][4];
+            auto issue = [&](int k) {
+                const int t = k / 6, pl = (k % 6) / 2, hf = k % 2;
+                const half_t* base = pbase[t] + pl * plane_stride + 16 * hf;
+                raw[k][0] = *reinterpret_cast<const half8*>(base + (size_t)bl[t][pl].o00 * CD);
+                raw[k][1] = *reinterpret_cast<const half8*>(base + (size_t)bl[t][pl].o01 * CD);
+                raw[k][2] = *reinterpret_cast<const half8*>(base + (size_t)bl[t][pl].o10 * CD);
+                raw[k][3] = *reinterpret_cast<const half8*>(base + (size_t)bl[t][pl].o11 * CD);
+            };
+#pragma unroll
+            for (int k = 0; k < DEPTH; ++k) issue(k);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < NG; ++k) {
+                const int t = k / 6, pl = (k % 6) / 2;
+                half8 r;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float acc = (float)raw[k][0][j] * bl[t][pl].w00;
+                    acc = fmaf((float)raw[k][1][j], bl[t][pl].w01, acc);
+                    acc = fmaf((float)raw[k][2][j], bl[t][pl].w10, acc);
+                    acc = fmaf((float)raw[k][3][j], bl[t][pl].w11, acc);
+                    r[j] = (half_t)acc;
+                }
+                cf[t][k % 6] = r;
+                if (k + DEPTH < NG) issue(k + DEPTH);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (dma_next) dma_head_image<NW>(dma_src, dma_dst, wave, lane);
+        // ---------------- MFMA chain of head h out of buffer s&1 --------------------------------------
+        {
+            const half8* W = reinterpret_cast<const half8*>(buf);
+            const float* ctab = reinterpret_cast<const float*>(buf + (size_t)DEC16_FRAGS * FRAG);
+            // Fragment indices in the image: block b -> fc_c 11b..11b+6 (6 feature chunks + aux), fc_0 11b+7,8,
+            // fc_1 11b+9,10; tail: aux (fc_1 bias of the last block) 55, fc_out 56,57.
+            // Every term added to the residual stream is an accumulation into `net`, so their order is
+            // free: the 7 fc_c MFMAs of block b+1 do not depend on block b's MLP and are issued BETWEEN
+            // fc_0 and fc_1 of block b, where they fill the MFMA -> VALU (relu/cvt) -> MFMA latency bubble.
             f32x16 net[T], hh[T];
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) net[t][r] = 0.f;
-            int k = 0;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) {
+                const half8 A = W[c * 64 + lane];
+#pragma unroll
+                for (int t = 0; t < T; ++t) net[t] = mfma16(A, c < 6 ? cf[t][c] : ax[t], net[t]);
+            }
 #pragma unroll
             for (int blk = 0; blk < NBLK; ++blk) {
-#pragma unroll
-                for (int c = 0; c < 7; ++c) {
-                    const half8 A = W[(k++) * 64 + lane];
-#pragma unroll
-                    for (int t = 0; t < T; ++t) net[t] = mfma16(A, c < 6 ? cf[t][c] : ax[t], net[t]);
-                }
+                const int k = 11 * blk;
                 f32x16 c0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 v = *reinterpret_cast<const float4*>(ctab + blk * 32 + 8 * q + 4 * hi);
                     c0[4 * q + 0] = v.x; c0[4 * q + 1] = v.y; c0[4 * q + 2] = v.z; c0[4 * q + 3] = v.w;
                 }
-                {
-                    const half8 A0 = W[k * 64 + lane], A1 = W[(k + 1) * 64 + lane];
-                    k += 2;
+                {   // hh = fc_0(relu(net)) + b0 : the stream is read (packed) here ...
+                    const half8 A0 = W[(k + 7) * 64 + lane], A1 = W[(k + 8) * 64 + lane];
 #pragma unroll
                     for (int t = 0; t < T; ++t) {
                         hh[t] = mfma16(A0, pack_relu8(net[t], 0), c0);
                         hh[t] = mfma16(A1, pack_relu8(net[t], 1), hh[t]);
                     }
                 }
-                {
-                    const half8 A0 = W[k * 64 + lane], A1 = W[(k + 1) * 64 + lane];
-                    k += 2;
+                if (blk + 1 < NBLK) {   // ... so the next block's fc_c (+ folded biases) may already accumulate
+#pragma unroll
+                    for (int c = 0; c < 7; ++c) {
+                        const half8 A = W[(k + 11 + c) * 64 + lane];
+#pragma unroll
+                        for (int t = 0; t < T; ++t) net[t] = mfma16(A, c < 6 ? cf[t][c] : ax[t], net[t]);
+                    }
+                } else {                // last block: only its fc_1 bias remains (aux fragment 55)
+                    const half8 A = W[55 * 64 + lane];
+#pragma unroll
+                    for (int t = 0; t < T; ++t) net[t] = mfma16(A, ax[t], net[t]);
+                }
+                {   // net += fc_1(relu(hh))
+                    const half8 A0 = W[(k + 9) * 64 + lane], A1 = W[(k + 10) * 64 + lane];
 #pragma unroll
                     for (int t = 0; t < T; ++t) {
                         net[t] = mfma16(A0, pack_relu8(hh[t], 0), net[t]);
@@ -158,17 +281,14 @@ __global__ __launch_bounds__(256, 2) void decoder_f16_kernel(DecArgs a) {
                     }
                 }
             }
-            {   // + fc_1 bias of the last block, then fc_out(relu(net))
-                const half8 A = W[(k++) * 64 + lane];
-#pragma unroll
-                for (int t = 0; t < T; ++t) net[t] = mfma16(A, ax[t], net[t]);
+            {   // fc_out(relu(net))
                 f32x16 c0;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 v = *reinterpret_cast<const float4*>(ctab + NBLK * 32 + 8 * q + 4 * hi);
                     c0[4 * q + 0] = v.x; c0[4 * q + 1] = v.y; c0[4 * q + 2] = v.z; c0[4 * q + 3] = v.w;
                 }
-                const half8 A0 = W[k * 64 + lane], A1 = W[(k + 1) * 64 + lane];
+                const half8 A0 = W[56 * 64 + lane], A1 = W[57 * 64 + lane];
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     f32x16 o = mfma16(A0, pack_relu8(net[t], 0), c0);
@@ -183,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void decoder_f16_kernel(DecArgs a) {
 // =============================== exact fp32 MFMA path ==============================================
 // Same chain on v_mfma_f32_32x32x2_f32 (bitwise an fp32 fma chain).  B operand of MFMA s of a hidden
 // layer is simply relu(D[s]) of the previous layer: no conversion, no data movement.
-template <int T>
+template <int T, bool LATTICE>
 __global__ __launch_bounds__(256, 1) void decoder_f32_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -191,7 +311,7 @@ __global__ __launch_bounds__(256, 1) void decoder_f32_kernel(DecArgs a) {
     const float4* W = reinterpret_cast<const float4*>(smem);
     const float* ctab = reinterpret_cast<const float*>(smem + (size_t)DEC32_FRAGS * FRAG);
     const float* planes = reinterpret_cast<const float*>(a.planes);
-    const size_t plane_stride = (size_t)a.B * RES * RES * CD;
+    const size_t plane_stride = LATTICE ? (size_t)a.B * a.R * a.R * CD : (size_t)a.B * RES * RES * CD;
 
     for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
         float cf[T][48], ax0[T], ax1[T];
@@ -203,8 +323,29 @@ __global__ __launch_bounds__(256, 1) void decoder_f32_kernel(DecArgs a) {
             valid[t] = g < a.P;
             if (!valid[t]) g = a.P - 1;
             gidx[t] = g;
+            int b, r;
+            split_scene(g, a.N, a.invN, b, r);
+            if constexpr (LATTICE) {
+                // lattice-resampled planes: three pixels, no interpolation (see lattice_resample_kernel)
+                const int R = a.R, R2 = R * R;
+                const int ix = div_magic(r, a.mR2), rz = r - ix * R2;
+                const int iy = div_magic(rz, a.mR), iz = rz - iy * R;
+                const float px = a.lin[ix], py = a.lin[iy], pz = a.lin[iz];
+                ax0[t] = hi ? py : px;
+                ax1[t] = hi ? 1.0f : pz;
+                const int off[3] = {iz * R + ix, iy * R + ix, iz * R + iy};
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const float* base = planes + pl * plane_stride + ((size_t)b * R2 + off[pl]) * CD + 16 * hi;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4*>(base + 4 * q);
+                        cf[t][16 * pl + 4 * q + 0] = v.x; cf[t][16 * pl + 4 * q + 1] = v.y;
+                        cf[t][16 * pl + 4 * q + 2] = v.z; cf[t][16 * pl + 4 * q + 3] = v.w;
+                    }
+                }
+            } else {
             const float px = a.p[3 * g + 0], py = a.p[3 * g + 1], pz = a.p[3 * g + 2];
-            const int b = (int)(g / a.N);
             const float nx = norm_coord(px), ny = norm_coord(py), nz = norm_coord(pz);
             ax0[t] = hi ? py : px;       // aux MFMA 0: slots (px, py)
             ax1[t] = hi ? 1.0f : pz;     // aux MFMA 1: slots (pz, 1)
@@ -226,6 +367,7 @@ __global__ __launch_bounds__(256, 1) void decoder_f32_kernel(DecArgs a) {
                     cf[t][16 * pl + 4 * q + 2] = fmaf(v11.z, bl.w11, fmaf(v10.z, bl.w10, fmaf(v01.z, bl.w01, v00.z * bl.w00)));
                     cf[t][16 * pl + 4 * q + 3] = fmaf(v11.w, bl.w11, fmaf(v10.w, bl.w10, fmaf(v01.w, bl.w01, v00.w * bl.w00)));
                 }
+            }
             }
         }
         for (int h = 0; h < a.nheads; ++h) {
@@ -363,28 +505,95 @@ __global__ void planes_nhwc_to_nchw_kernel(const TIn* __restrict__ src, float* _
     }
 }
 
+// ------------------------------- lattice resampling --------------------------------------------------
+// Inference queries the fixed R^3 lattice (detection_implicit.py:28-31), so every plane is sampled at
+// only R*R distinct positions, each shared by R points.  One thread per (plane, scene, j, i, 8
+// channels) evaluates sample_plane_feature (decoder.py:117-122) once; out [3][B][R(v)][R(u)][32].
+template <typename TP>
+__global__ void lattice_resample_kernel(const TP* __restrict__ planes, const float* __restrict__ lin,
+                                        TP* __restrict__ out, int B, int R) {
+    const long long total = 3LL * B * R * R * 4;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cg = (int)(i & 3);
+    const long long pix = i >> 2;
+    const int iu = (int)(pix % R), iv = (int)((pix / R) % R);
+    const long long img = pix / ((long long)R * R);
+    const Bilin bl = bilin_setup(norm_coord(lin[iu]), norm_coord(lin[iv]));
+    const TP* src = planes + (size_t)img * RES * RES * CD + 8 * cg;
+    TP* dst = out + (size_t)pix * CD + 8 * cg;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float acc = (float)src[(size_t)bl.o00 * CD + c] * bl.w00;
+        acc = fmaf((float)src[(size_t)bl.o01 * CD + c], bl.w01, acc);
+        acc = fmaf((float)src[(size_t)bl.o10 * CD + c], bl.w10, acc);
+        acc = fmaf((float)src[(size_t)bl.o11 * CD + c], bl.w11, acc);
+        dst[c] = (TP)acc;
+    }
+}
+
 // ------------------------------- launchers ----------------------------------------------------------
 int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, void* ev1) {
     DecArgs a = a0;
     if (a.P <= 0 || a.nheads <= 0) return 0;
     if (ev0 && ev1) (void)hipEventRecord(static_cast<hipEvent_t>(ev0), s);
     const long long tiles = (a.P + 31) / 32;
-    if (precision == 1) {
+    const bool lat = a.R > 0;
+    a.invN = 1.0f / (float)a.N;
+    if (lat) {
+        a.mR = (unsigned)((0x100000000ULL + a.R - 1) / a.R);
+        a.mR2 = (unsigned)((0x100000000ULL + (unsigned long long)a.R * a.R - 1) / ((unsigned long long)a.R * a.R));
+    }
+    if (precision == 1 && lat) {
+        // lattice variant: 155 VGPRs -> 12 waves (3 per SIMD, phases 0/1/2 over the heads)
+        constexpr int T = 2, NW = 12;
+        a.nbatch = (int)((tiles + NW * T - 1) / (NW * T));
+        const int grid = a.nbatch < 256 ? a.nbatch : 256;      // one persistent workgroup per CU
+        auto kern = decoder_f16_kernel<T, true, NW>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(2 * DEC16_BYTES));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), 2 * DEC16_BYTES, s, a);
+    } else if (precision == 1) {
+        constexpr int T = 2, NW = 8;
+        a.nbatch = (int)((tiles + NW * T - 1) / (NW * T));
+        const int grid = a.nbatch < 256 ? a.nbatch : 256;      // one persistent workgroup per CU
+        auto kern = decoder_f16_kernel<T, false, NW>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(2 * DEC16_BYTES));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), 2 * DEC16_BYTES, s, a);
+    } else if (tiles >= 2 * 4 * 256) {
+        // enough work for two tiles per wave on every CU: the 111 KiB weight image is staged half as often
         constexpr int T = 2;
         a.nbatch = (int)((tiles + 4 * T - 1) / (4 * T));
-        const int grid = a.nbatch < 512 ? a.nbatch : 512;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_f16_kernel<T>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC16_BYTES);
-        hipLaunchKernelGGL(decoder_f16_kernel<T>, dim3(grid), dim3(256), DEC16_BYTES, s, a);
+        const int grid = a.nbatch < 256 ? a.nbatch : 256;
+        auto kern = lat ? decoder_f32_kernel<T, true> : decoder_f32_kernel<T, false>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)DEC32_BYTES);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), DEC32_BYTES, s, a);
     } else {
         constexpr int T = 1;
         a.nbatch = (int)((tiles + 4 * T - 1) / (4 * T));
         const int grid = a.nbatch < 256 ? a.nbatch : 256;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_f32_kernel<T>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)DEC32_BYTES);
-        hipLaunchKernelGGL(decoder_f32_kernel<T>, dim3(grid), dim3(256), DEC32_BYTES, s, a);
+        auto kern = lat ? decoder_f32_kernel<T, true> : decoder_f32_kernel<T, false>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)DEC32_BYTES);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), DEC32_BYTES, s, a);
     }
     if (ev0 && ev1) (void)hipEventRecord(static_cast<hipEvent_t>(ev1), s);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
+int launch_lattice_resample(const void* planes, const float* lin, void* out, int B, int R, int precision,
+                            hipStream_t s) {
+    const long long total = 3LL * B * R * R * 4;
+    if (total <= 0) return 0;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (precision == 1)
+        hipLaunchKernelGGL(lattice_resample_kernel<half_t>, dim3(grid), dim3(256), 0, s,
+                           reinterpret_cast<const half_t*>(planes), lin, reinterpret_cast<half_t*>(out), B, R);
+    else
+        hipLaunchKernelGGL(lattice_resample_kernel<float>, dim3(grid), dim3(256), 0, s,
+                           reinterpret_cast<const float*>(planes), lin, reinterpret_cast<float*>(out), B, R);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 

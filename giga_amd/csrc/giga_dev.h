@@ -25,12 +25,14 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 
 __device__ __forceinline__ float relu(float x) { return __builtin_fmaxf(x, 0.f); }
 
-// relu + round-to-nearest f16 of D registers 8c..8c+7  -> B operand of the next layer's chunk c
+// round-to-nearest f16 then relu (== relu then round) of D registers 8c..8c+7 -> B operand of the next
+// layer's chunk c.  4x v_cvt_pk_f16_f32 + 4x v_pk_max_f16 instead of 16 canonicalising v_max_f32.
 __device__ __forceinline__ half8 pack_relu8(const f32x16& d, int c) {
     half8 x;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = (half_t)relu(d[8 * c + j]);
-    return x;
+    for (int j = 0; j < 8; ++j) x[j] = (half_t)d[8 * c + j];
+    const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_elementwise_max(x, z);
 }
 
 // ---- coordinates: reference ConvONets/common.py:238-261 with padding = 0 -------------------------
@@ -48,6 +50,18 @@ __device__ __forceinline__ float pix_coord(float xy) {
     float ix = ((g + 1.0f) * 0.5f) * 39.0f;
     return fminf(fmaxf(ix, 0.0f), 39.0f);
 }
+
+// ---- cheap index arithmetic (the decoders run it per lane per round; hardware has no integer divide) ----
+// scene of point g:  b = g / N, r = g % N   via fp32 reciprocal + one fix-up step (exact for g < 2^31)
+__device__ __forceinline__ void split_scene(long long g, int N, float invN, int& b, int& r) {
+    int q = (int)((float)g * invN);
+    long long rem = g - (long long)q * N;
+    if (rem < 0) { --q; rem += N; }
+    if (rem >= N) { ++q; rem -= N; }
+    b = q; r = (int)rem;
+}
+// n / d for n * (d-1) < 2^32 with m = ceil(2^32 / d) computed on the host
+__device__ __forceinline__ int div_magic(int n, unsigned m) { return (int)__umulhi((unsigned)n, m); }
 
 struct Bilin {          // 4-tap footprint on a 40x40 plane, element offsets in pixels
     int o00, o01, o10, o11;

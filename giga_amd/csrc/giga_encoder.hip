@@ -5,173 +5,209 @@
 //   torch_scatter.scatter_mean] -> shared UNet (encoder/unet.py:225-239).
 // Kernel 1 (convin_project_kernel) fuses the 3-D conv, the ReLU and the three axis means, so the
 // 32x40^3 feature volume (8.2 MB/scene in the reference) is never written to memory.  Kernel 2
-// (conv_mfma_kernel) is one LDS-tiled implicit-GEMM convolution used for every U-Net layer.
+// (conv16_kernel) is one LDS-staged implicit-GEMM convolution used for every U-Net layer.
 #include "giga_dev.h"
 
 namespace giga {
 
 // ====================================================================================================
 // conv_in + ReLU + axis means.
-//   grid (NSLAB, B, 2), block 320 = 5 waves.  The workgroup walks SX = 40/NSLAB consecutive ix slices
-//   of one iy-half (20 rows) of a scene.  For one slice, wave w owns a strip of 4 iy rows x 40 iz =
-//   5 MFMA tiles of (4 iy x 8 iz) voxels.  GEMM per tile: D[voxel][channel] = A[voxel][tap] * Wt[tap][channel],
-//   K = 27 taps (+1 zero) = 14 x v_mfma_f32_32x32x2_f32 (exact fp32).
-//   The D-row -> voxel map is chosen so that every reduction the projection needs is in-lane:
-//     row = (r&3) + 8*(r>>2) + 4*hi ;  iz_local = r & 7 ,  iy_local = 2*(r>>3) + hi
-//   * mean over iz (plane 'xy')  : in-lane sum of 8 regs x 5 tiles                -> written directly
-//   * mean over iy (plane 'xz')  : in-lane + one cross-half add, fixed-order 5-wave LDS sum, then one
-//                                  partial per iy-half to HBM
-//   * mean over ix (plane 'yz')  : register accumulation over the slab, one partial per slab to HBM
-//   plane_finalize_kernel sums the 2 (xz) / NSLAB (yz) partials in fixed order: deterministic, no atomics.
+//   grid (NSLAB, B), block 512 = 8 waves = 4 iy-groups (10 rows each) x 2 channel halves.  The
+//   workgroup walks SX = 40/NSLAB consecutive ix slices of one scene.  Work unit = 16 voxels
+//   (2 iy x 8 iz) x 16 channels: D[voxel][channel] = A[voxel][tap] * Wt[tap][channel], K = 27 taps
+//   (+1 zero) = 7 x v_mfma_f32_16x16x4_f32 (exact fp32).  25 units per wave per slice on every one of
+//   the 8 waves: the 4 SIMDs of the CU carry exactly the same MFMA load (2 waves each).
+//   D-row -> voxel map: row v = 4g + r (g = lane>>4):  iz_local = 4*(g&1) + r ,  iy_local = g>>1, so
+//   * mean over iz (plane 'xy') : in-lane adds + one lane^16 exchange               -> written directly
+//   * mean over iy (plane 'xz') : in-lane adds + one lane^32 exchange, then a fixed-order sum of the
+//                                 4 iy-groups through LDS                            -> written directly
+//   * mean over ix (plane 'yz') : register accumulation over the slab, one fp32 partial per slab to
+//                                 HBM, summed in fixed order by plane_finalize_kernel (no atomics).
 // Plane pixel (H,W) conventions (common.py:246-251,303-318): xz -> [iz][ix], xy -> [iy][ix], yz -> [iz][iy].
 // ====================================================================================================
-constexpr int CI_ROWSTRIDE = 56;                  // floats per LDS row: 56 mod 32 = 24 -> the 4 iy rows of a tile hit disjoint banks
-constexpr int CI_ROWS = 22;                       // 20 iy rows + halo
-constexpr int CI_SLICE = CI_ROWS * CI_ROWSTRIDE;  // one haloed half-slice
-constexpr int CI_LDS_SLICES = 3 * CI_SLICE;       // ring of 3 slices (floats)
-constexpr int CI_LDS_RED = 5 * 40 * 32;           // cross-wave reduction buffer (floats)
-constexpr size_t CI_LDS_BYTES = (CI_LDS_SLICES + CI_LDS_RED) * sizeof(float);
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v mfma32_16(float a, float b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4v mfma16_16(half8 a, half8 b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+constexpr int CI_ROWSTRIDE = 56;                  // floats per LDS row (>= 42; 56 mod 32 = 24 spreads the rows over banks)
+constexpr int CI_SLICE = 42 * CI_ROWSTRIDE;       // one haloed slice
+constexpr int CI_LDS_SLICES = 4 * CI_SLICE;       // ring of 4 slices (floats): 3 in use + 1 being filled
+constexpr int CI_LDS_RED = 4 * 40 * 32;           // cross-group reduction buffer (floats), double-buffered
+constexpr size_t CI_LDS_BYTES = (CI_LDS_SLICES + 2 * CI_LDS_RED) * sizeof(float);
 
 template <typename TOut>
-__global__ __launch_bounds__(320) void convin_project_kernel(
+__global__ __launch_bounds__(512) void convin_project_kernel(
     const float* __restrict__ tsdf,        // [B][40][40][40]
-    const float* __restrict__ wpk,         // [14][64] packed B operands
+    const float* __restrict__ wpk,         // [2][7][64] packed B operands
     const float* __restrict__ bias,        // [32]
-    TOut* __restrict__ planes,             // [3][B][40][40][32] NHWC (xy written here)
-    float* __restrict__ xz_partial,        // [2][B][40(iz)][40(ix)][32]   sums over 20 iy
+    TOut* __restrict__ planes,             // [3][B][40][40][32] NHWC (xz, xy written here)
     float* __restrict__ yz_partial,        // [NSLAB][B][40(iz)][40(iy)][32] sums over SX ix
     int B, int SX) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* slices = lds;
     float* red = lds + CI_LDS_SLICES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = lane & 31, hi = lane >> 5;
-    const int slab = blockIdx.x, b = blockIdx.y, half = blockIdx.z;
-    const int ix0 = slab * SX, iy0 = half * 20;
+    const int j = lane & 15, g = lane >> 4;
+    const int chh = wave & 1, grp = wave >> 1;
+    const int slab = blockIdx.x, b = blockIdx.y;
+    const int ix0 = slab * SX;
     const float* vol = tsdf + (size_t)b * RES * RES * RES;
 
     for (int i = tid; i < CI_LDS_SLICES; i += blockDim.x) slices[i] = 0.f;   // halos stay zero
-    float wreg[14];
+    float wreg[7];
 #pragma unroll
-    for (int s = 0; s < 14; ++s) wreg[s] = wpk[s * 64 + lane];
-    const float bn = bias[n];
+    for (int s = 0; s < 7; ++s) wreg[s] = wpk[(chh * 7 + s) * 64 + lane];
+    const float bn = bias[16 * chh + j];
     __syncthreads();
 
-    // ring slot (ix+1) % 3 holds rows iy0-1 .. iy0+20 of slice ix (zeros outside the volume)
-    auto load_slice = [&](int ix) {
-        float* dst = slices + ((ix + 1) % 3) * CI_SLICE;
+    // slice ix lives in ring slot (ix+1) & 3; out-of-range slices are zero.  Each thread moves up to 4
+    // voxels of a slice (1600 = 3*512 + 64): global -> registers early, registers -> LDS late.
+    float pre[4];
+    auto fetch_slice = [&](int ix) {
         const bool in = ix >= 0 && ix < RES;
-        for (int i = tid; i < CI_ROWS * RES; i += blockDim.x) {
-            const int ly = i / RES, z = i % RES;
-            const int y = iy0 - 1 + ly;
-            dst[ly * CI_ROWSTRIDE + (z + 1)] =
-                (in && y >= 0 && y < RES) ? vol[((size_t)ix * RES + y) * RES + z] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 512 * q;
+            pre[q] = (in && i < RES * RES) ? vol[(size_t)ix * RES * RES + i] : 0.f;
         }
     };
-    load_slice(ix0 - 1);
-    load_slice(ix0);
-
-    // A-operand geometry: M-row i = lane&31 -> (iy_l, iz_l) with i bits (b0,b1,b3)->iz, (b2,b4)->iy
-    const int iz_l = (n & 3) | (((n >> 3) & 1) << 2);
-    const int iy_l = ((n >> 2) & 1) | (((n >> 4) & 1) << 1);
-    const int a_base = (wave * 4 + iy_l) * CI_ROWSTRIDE + iz_l;   // + tile*8 + tap offset (halo origin)
-
-    f32x16 acc_yz[5];
+    auto commit_slice = [&](int ix) {
+        float* dst = slices + ((ix + 1) & 3) * CI_SLICE;
 #pragma unroll
-    for (int t = 0; t < 5; ++t)
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 512 * q;         // recomputed (not kept live): the kernel sits at the VGPR limit
+            if (i < RES * RES) dst[(i / RES + 1) * CI_ROWSTRIDE + (i % RES + 1)] = pre[q];
+        }
+    };
+    fetch_slice(ix0 - 1); commit_slice(ix0 - 1);
+    fetch_slice(ix0);     commit_slice(ix0);
+    fetch_slice(ix0 + 1); commit_slice(ix0 + 1);
+    __syncthreads();
+
+    // A operand: row i = lane&15 is voxel (iy_l = i>>3, iz_l = 4*((i>>2)&1) + (i&3)); k-slot g supplies tap 4s+g
+    const int a_base = (grp * 10 + (j >> 3)) * CI_ROWSTRIDE + 4 * ((j >> 2) & 1) + (j & 3);
+    f32x4v acc_yz[5][5];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc_yz[t][r] = 0.f;
+    for (int ip = 0; ip < 5; ++ip)
+#pragma unroll
+        for (int zg = 0; zg < 5; ++zg) acc_yz[ip][zg] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     const float inv = 1.0f / RES;
     const size_t img_stride = (size_t)RES * RES * CD;
+    TOut* plane_xz = planes + ((size_t)0 * B + b) * img_stride;
     TOut* plane_xy = planes + ((size_t)1 * B + b) * img_stride;
-    float* part_xz = xz_partial + ((size_t)half * B + b) * img_stride;
+    const int ch = 16 * chh + j;
 
     for (int sx = 0; sx < SX; ++sx) {
         const int ix = ix0 + sx;
-        __syncthreads();                  // everyone finished reading the slot about to be overwritten
-        load_slice(ix + 1);
-        __syncthreads();
-        // slice ix-1+dx lives in ring slot (ix+dx) % 3 (wave-uniform -> SGPRs)
-        const int oslot[3] = {((ix + 0) % 3) * CI_SLICE, ((ix + 1) % 3) * CI_SLICE, ((ix + 2) % 3) * CI_SLICE};
-        float sum_z[2] = {0.f, 0.f};      // sum over iz for iy_local = 2*g + hi, g = 0,1
+        // Hazards are covered by the single barrier below: the slot filled this iteration (slice ix+2)
+        // was last read as slice ix-2 in the previous iteration; `red` alternates between two buffers.
+        float* redw = red + (sx & 1) * CI_LDS_RED;
+        if (sx + 1 < SX) fetch_slice(ix + 2);        // global loads fly under this slice's MFMAs
+        const int o0 = ((ix + 0) & 3) * CI_SLICE, o1 = ((ix + 1) & 3) * CI_SLICE, o2 = ((ix + 2) & 3) * CI_SLICE;
+        // k-slot g supplies tap 4s+g (tap = dx*9 + dy*3 + dz, tap 27 has zero weight).  Recomputed per
+        // slice from an opaque copy of g so the 14 per-lane constants are not kept live (VGPR limit).
+        int gq = g;
+        asm volatile("" : "+v"(gq));
+        int aoff[7];
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
-            f32x16 d;
+        for (int s = 0; s < 7; ++s) {
+            int t = 4 * s + gq;
+            t = t > 26 ? 26 : t;
+            const int dx = t / 9;
+            aoff[s] = a_base + ((t / 3) % 3) * CI_ROWSTRIDE + t % 3 + (dx == 0 ? o0 : dx == 1 ? o1 : o2);
+        }
+        float sum_z[5];                   // per iy-pair: sum over the 5 iz-groups and the 4 in-lane iz
 #pragma unroll
-            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+        for (int ip = 0; ip < 5; ++ip) sum_z[ip] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 14; ++s) {
-                // this lane supplies tap 2s+hi of K-step s; tap = dx*9 + dy*3 + dz (tap 27: zero weight)
-                const int ta = 2 * s, tb = 2 * s + 1 > 26 ? 26 : 2 * s + 1;
-                const int offa = oslot[ta / 9] + ((ta / 3) % 3) * CI_ROWSTRIDE + ta % 3 + t * 8;
-                const int offb = oslot[tb / 9] + ((tb / 3) % 3) * CI_ROWSTRIDE + tb % 3 + t * 8;
-                const float av = slices[a_base + (hi ? offb : offa)];
-                d = mfma32(av, wreg[s], d);
+        for (int zg = 0; zg < 5; ++zg) {
+            float part_y[4] = {0.f, 0.f, 0.f, 0.f};   // per r: sum over the 5 iy-pairs of this group
+#pragma unroll
+            for (int ip = 0; ip < 5; ++ip) {
+                f32x4v d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 7; ++s)
+                    d = mfma32_16(slices[aoff[s] + 2 * ip * CI_ROWSTRIDE + 8 * zg], wreg[s], d);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = relu(d[r] + bn);
+                    acc_yz[ip][zg][r] += v;
+                    sum_z[ip] += v;
+                    part_y[r] += v;
+                }
+                // two independent 7-MFMA chains in flight cover the 40-cycle latency of the 32-cycle
+                // 16x16x4 MFMA; more only multiplies the live A operands (the kernel is VGPR-bound)
+                if (ip & 1) __builtin_amdgcn_sched_barrier(0);
             }
+            // plane xz [iz][ix][c]: the other iy row of each tile lives in lane^32; 4 groups go through LDS
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = relu(d[r] + bn);
-                acc_yz[t][r] += v;
-                sum_z[r >> 3] += v;
-                d[r] = v;
+            for (int r = 0; r < 4; ++r) {
+                const float v = part_y[r] + __shfl_xor(part_y[r], 32);
+                if ((g >> 1) == 0) redw[(grp * 40 + 8 * zg + 4 * (g & 1) + r) * 32 + ch] = v;
             }
-#pragma unroll
-            for (int z = 0; z < 8; ++z) {
-                float v = d[z] + d[8 + z];                       // iy_local 0+hi and 2+hi
-                v += __shfl_xor(v, 32);                          // other half-wave: the remaining two rows
-                if (hi == 0) red[(wave * 40 + t * 8 + z) * 32 + n] = v;      // sum over this wave's 4 iy rows
-            }
-            // one tile at a time: the 14-MFMA chain is issue-bound (64 cyc each), cross-tile
-            // interleaving buys nothing and only multiplies the live accumulators
             __builtin_amdgcn_sched_barrier(0);
         }
-        // plane xy [iy][ix][c]: complete (mean over all 40 iz)
+        // plane xy [iy][ix][c]: other half of the 8 iz of each tile lives in lane^16
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int iy = iy0 + wave * 4 + 2 * g + hi;
-            plane_xy[((size_t)iy * RES + ix) * CD + n] = (TOut)(sum_z[g] * inv);
+        for (int ip = 0; ip < 5; ++ip) {
+            const float s = sum_z[ip] + __shfl_xor(sum_z[ip], 16);
+            if ((g & 1) == 0) {
+                const int iy = grp * 10 + 2 * ip + (g >> 1);
+                plane_xy[((size_t)iy * RES + ix) * CD + ch] = (TOut)(s * inv);
+            }
         }
-        // plane xz [iz][ix][c]: fixed-order sum over this half's 5 strips
+        if (sx + 1 < SX) commit_slice(ix + 2);
         __syncthreads();
         for (int i = tid; i < 40 * 32; i += blockDim.x) {
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < 5; ++w) s += red[w * 40 * 32 + i];
+            const float s = (redw[i] + redw[1280 + i]) + (redw[2560 + i] + redw[3840 + i]);
             const int iz = i >> 5, c = i & 31;
-            part_xz[((size_t)iz * RES + ix) * CD + c] = s;
+            plane_xz[((size_t)iz * RES + ix) * CD + c] = (TOut)(s * inv);
         }
     }
     // plane yz partial [iz][iy][c] for this slab
     float* part = yz_partial + ((size_t)slab * B + b) * img_stride;
 #pragma unroll
-    for (int t = 0; t < 5; ++t)
+    for (int ip = 0; ip < 5; ++ip)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int iz = t * 8 + (r & 7), iy = iy0 + wave * 4 + 2 * (r >> 3) + hi;
-            part[((size_t)iz * RES + iy) * CD + n] = acc_yz[t][r];
-        }
+        for (int zg = 0; zg < 5; ++zg)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int iz = 8 * zg + 4 * (g & 1) + r, iy = grp * 10 + 2 * ip + (g >> 1);
+                part[((size_t)iz * RES + iy) * CD + ch] = acc_yz[ip][zg][r];
+            }
 }
 
 template <typename TOut>
-__global__ void plane_finalize_kernel(const float* __restrict__ xz_partial, const float* __restrict__ yz_partial,
-                                      TOut* __restrict__ planes, int B, int nslab) {
+__global__ void plane_finalize_kernel(const float* __restrict__ yz_partial, TOut* __restrict__ planes, int B,
+                                      int nslab) {
     const size_t per = (size_t)B * RES * RES * CD;          // elements of one plane over the batch
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= per) return;
-    planes[i] = (TOut)((xz_partial[i] + xz_partial[per + i]) * (1.0f / RES));
     float s = 0.f;
     for (int k = 0; k < nslab; ++k) s += yz_partial[(size_t)k * per + i];
     planes[2 * per + i] = (TOut)(s * (1.0f / RES));
 }
 
 // ====================================================================================================
-// Generic LDS-tiled implicit-GEMM convolution on MFMA, NHWC activations.
+// U-Net convolutions: implicit GEMM on 16x16 MFMA tiles, NHWC activations, wave-independent units.
 //   D[pixel][cout] = sum_{tap,cin} X[pixel+tap][cin] * W[cout][cin][tap]
-//   A operand = pixels (32 per MFMA tile = 8 2x2 quads, so a lane's 16 D registers are 4 complete
-//   quads and the fused 2x2 max-pool is in-lane), B operand = packed weight fragments from L2.
-//   Workgroup = one (image, row strip) x one group of NB*32 output channels; input channels are
-//   staged through LDS in chunks of 32 with a 16-byte pad per pixel (conflict-free ds_read_b128).
+//   A operand = 16 pixels (a 4x4 block = 2x2 quads of 2x2 pixels; D row = 4*quad + pos, so a lane's 4
+//   D registers are one complete quad and the fused 2x2 max-pool is in-lane), B operand = packed
+//   weight fragments streamed from L2 (identical for every wave).
+//   Persistent workgroups of CONV_NW waves, one per CU.  A workgroup owns one WEIGHT GROUP (NB*16 output
+//   channels of one sub-output) whose fragments stay resident in LDS for the whole kernel (<= 72 KiB,
+//   filled once by LDS-DMA), so B operands are ds_read_b128 at LDS bandwidth instead of 1 KiB per
+//   MFMA-quad per wave through the 64 B/clk L1.  Work unit = (image, 4x4 pixel tile); EVERY WAVE IS
+//   INDEPENDENT after the weight load: it stages the haloed 6x6 input patch of its tile in a
+//   wave-private LDS region (32 channels at a time, 16-byte pad per pixel), runs the MFMA loop and
+//   writes its outputs.  No workgroup barrier in the loop, no tile->wave quantisation; units are
+//   strided over all waves of the weight group so each SIMD carries the same number of MFMAs.  The
+//   next 32-channel chunk is prefetched into registers while the current one is in the MFMA loop.
 //   KIND: CONV3 (3x3, pad 1, +bias, ReLU, optional pool), UPCONV (ConvTranspose2d k=2 s=2 as four
 //   1x1 GEMMs scattered to (2y+dy, 2x+dx)), CONV1 (1x1, +bias, no activation).
 // ====================================================================================================
@@ -185,179 +221,216 @@ struct ConvArgs {
     int nimg;
 };
 
-template <typename T> struct Prec;
-template <> struct Prec<float> { static constexpr int KG = 8; };      // channels per 16-byte k-group
-template <> struct Prec<half_t> { static constexpr int KG = 16; };
+constexpr int CONV_NW = 12;       // waves per workgroup (3 per SIMD; VGPR use is < 80)
 
-template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int ROWS, int NW, int NB, bool POOL>
-__global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(ConvArgs a) {
+template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL>
+__global__ __launch_bounds__(CONV_NW * 64) void conv16_kernel(ConvArgs a) {
     constexpr int CIN = C0 + C1;
     constexpr int TAPS = KIND == CONV3 ? 9 : 1;
     constexpr int HALO = KIND == CONV3 ? 1 : 0;
-    constexpr int KG = Prec<T>::KG;                   // channels per k-group
-    constexpr int KGC = 32 / KG;                      // k-groups per 32-channel chunk
     constexpr int NCHUNK = CIN / 32;
-    constexpr int PS = 32 * (int)sizeof(T) + 16;      // LDS pixel stride in bytes
-    constexpr int LW = W + 2 * HALO, LH = ROWS + 2 * HALO;
-    constexpr int STRIPS = H / ROWS;
-    constexpr int QUADS = (ROWS / 2) * (W / 2);
-    constexpr int TILES = (QUADS + 7) / 8;
-    constexpr int MT = (TILES + NW - 1) / NW;         // tiles per wave
+    constexpr int ES = (int)sizeof(T);
+    constexpr int PS = 32 * ES + 16;                  // LDS pixel stride in bytes
+    constexpr int LW = 4 + 2 * HALO, NPIX = LW * LW;  // haloed patch
+    constexpr int VPP = 32 * ES / 16;                 // 16-byte vectors per pixel per chunk
+    constexpr int NVEC = NPIX * VPP;                  // vectors per chunk
+    constexpr int NLD = (NVEC + 63) / 64;             // staging loads per lane
+    constexpr int REGION = (NPIX * PS + 15) / 16 * 16;
+    constexpr int TX = (W + 3) / 4, TY = (H + 3) / 4;
     constexpr int NSUB = KIND == UPCONV ? 4 : 1;
-    constexpr int NBT = COUT / 32;                    // 32-channel blocks per sub-output
-    static_assert(H % ROWS == 0 && ROWS % 2 == 0 && W % 2 == 0, "strip geometry");
-    static_assert(COUT % (32 * NB) == 0, "cout grouping");
+    constexpr int NBT = COUT / 16;                    // 16-channel blocks per sub-output
+    constexpr int CG = NBT / NB;                      // channel groups per sub-output
+    constexpr int NGRP = NSUB * CG;                   // weight groups (one per workgroup)
+    constexpr int KGC = ES == 4 ? 2 : 1;              // k-groups per 32-channel chunk (16 / 32 channels)
+    constexpr int KGT = CIN / 32 * KGC;
+    constexpr int WFRAGS = NB * TAPS * KGT;           // weight fragments resident in LDS
+    static_assert(NBT % NB == 0, "cout grouping");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = lane & 31, hi = lane >> 5;
-    const int img = blockIdx.x / STRIPS, strip = blockIdx.x % STRIPS;
-    const int y0 = strip * ROWS;
-    // blockIdx.y enumerates (sub, cout group)
-    const int sub = blockIdx.y / (NBT / NB), nb0 = (blockIdx.y % (NBT / NB)) * NB;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    uint8_t* region = smem + (size_t)WFRAGS * FRAG + wave * REGION;
 
-    // per-tile A geometry: M-row i = lane&31 : quad = i>>2, dy = (i>>1)&1, dx = i&1
-    int a_off[MT];
-    bool t_ok[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int tile = wave + m * NW;
-        const int q = tile * 8 + (n >> 2);
-        t_ok[m] = tile < TILES;
-        const int qq = q < QUADS ? q : QUADS - 1;
-        const int y = 2 * (qq / (W / 2)) + ((n >> 1) & 1), x = 2 * (qq % (W / 2)) + (n & 1);
-        a_off[m] = (y * LW + x) * PS + hi * 16;       // tap (0,0) of the haloed tile == pixel (y-1,x-1)
+    // ---- this workgroup's weight group -> LDS, once (LDS-DMA, 1 KiB per wave-instruction) ----------
+    const int grp = blockIdx.x % NGRP, wg_in_grp = blockIdx.x / NGRP, wgs_per_grp = gridDim.x / NGRP;
+    const int sub = grp / CG, nb0 = (grp % CG) * NB;
+    {
+        // fragments of (sub, nb0 .. nb0+NB-1) are contiguous in the packed blob: [sub][nb][tap][kg]
+        const uint8_t* wsrc = a.w + (size_t)(sub * NBT + nb0) * TAPS * KGT * FRAG;
+        for (int c = wave; c < WFRAGS; c += CONV_NW)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(wsrc + (size_t)c * FRAG + lane * 16),
+                (__attribute__((address_space(3))) void*)(smem + c * FRAG), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
+    const uint4* wl = reinterpret_cast<const uint4*>(smem);
 
-    f32x16 acc[MT][NB];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+    const int nwaves = wgs_per_grp * CONV_NW;
+    const int units = a.nimg * TY * TX;
 
-    const uint4* wfrag = reinterpret_cast<const uint4*>(a.w);
-    constexpr int KGT = CIN / KG;                     // k-groups over all input channels
+    // A geometry: row i = lane&15 : quad = i>>2 (qy = quad>>1, qx = quad&1), pos = i&3 (dy = pos>>1, dx = pos&1)
+    const int ay = 2 * (j >> 3) + ((j >> 1) & 1), ax = 2 * ((j >> 2) & 1) + (j & 1);
+    const int a_off = (ay * LW + ax) * PS + g * 16;
 
-    for (int cc = 0; cc < NCHUNK; ++cc) {
-        // ---- stage chunk cc (32 channels) of the haloed strip into LDS --------------------------
+    // staging geometry of this lane's NLD vectors (fixed for the whole kernel)
+    int st_lds[NLD], st_ly[NLD], st_lx[NLD], st_v[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int i = lane + 64 * q;
+        const int pix = i / VPP;
+        st_v[q] = i % VPP;
+        st_ly[q] = pix / LW; st_lx[q] = pix % LW;
+        st_lds[q] = i < NVEC ? pix * PS + st_v[q] * 16 : -1;
+    }
+    auto unit_coords = [&](int u, int& tx, int& ty, int& img) {
+        tx = u % TX; ty = (u / TX) % TY; img = u / (TX * TY);
+    };
+    uint4 stg[NLD];
+    auto issue_loads = [&](int u, int cc) {
+        int tx, ty, img;
+        unit_coords(u, tx, ty, img);
         const T* src = reinterpret_cast<const T*>(cc * 32 < C0 ? a.in0 : a.in1);
         const int csrc = cc * 32 < C0 ? C0 : C1;
         const int coff = cc * 32 < C0 ? cc * 32 : cc * 32 - C0;
-        constexpr int VPP = 32 * (int)sizeof(T) / 16;           // 16-byte vectors per pixel
-        __syncthreads();
-        for (int i = tid; i < LH * LW * VPP; i += NW * 64) {
-            const int pix = i / VPP, v = i % VPP;
-            const int ly = pix / LW, lx = pix % LW;
-            const int gy = y0 + ly - HALO, gx = lx - HALO;
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int gy = 4 * ty + st_ly[q] - HALO, gx = 4 * tx + st_lx[q] - HALO;
             uint4 val = make_uint4(0, 0, 0, 0);
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+            if (st_lds[q] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W)
                 val = *reinterpret_cast<const uint4*>(src + ((size_t)(img * H + gy) * W + gx) * csrc + coff +
-                                                      v * (16 / (int)sizeof(T)));
-            *reinterpret_cast<uint4*>(smem + pix * PS + v * 16) = val;
+                                                      st_v[q] * (16 / ES));
+            stg[q] = val;
         }
-        __syncthreads();
-        // ---- MFMA over taps x k-groups of this chunk --------------------------------------------
+    };
+
+    // global wave index = wave * (#workgroups) + workgroup: remainder units spread over all CUs/SIMDs
+    int u = wave * wgs_per_grp + wg_in_grp;
+    if (u >= units) return;
+    int cc = 0;
+    issue_loads(u, 0);
+    constexpr int NACC = NB == 1 ? 2 : 1;          // independent accumulator chains per channel block
+    f32x4v acc[NB][NACC];
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int c = 0; c < NACC; ++c) acc[n][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    while (true) {
+        // ---- registers -> wave-private LDS patch (DS ops of one wave execute in order) -----------
+#pragma unroll
+        for (int q = 0; q < NLD; ++q)
+            if (st_lds[q] >= 0) *reinterpret_cast<uint4*>(region + st_lds[q]) = stg[q];
+        // ---- prefetch the next chunk / next unit ---------------------------------------------------
+        int un = u, ccn = cc + 1;
+        if (ccn == NCHUNK) { un = u + nwaves; ccn = 0; }
+        const bool more = un < units;
+        if (more) issue_loads(un, ccn);
+        // ---- MFMA over taps x k-groups of this chunk: A from the patch, B from the resident weights --
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int toff = ((tap / 3) * LW + (tap % 3)) * PS;
 #pragma unroll
             for (int kg = 0; kg < KGC; ++kg) {
+                const uint4 av = *reinterpret_cast<const uint4*>(region + a_off + toff + kg * 64);
                 uint4 bw[NB];
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const size_t f = ((size_t)(sub * NBT + nb0 + j) * TAPS + tap) * KGT + cc * KGC + kg;
-                    bw[j] = wfrag[f * 64 + lane];
-                }
+                for (int n = 0; n < NB; ++n) bw[n] = wl[((n * TAPS + tap) * KGT + cc * KGC + kg) * 64 + lane];
+                if constexpr (ES == 2) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const uint4 av = *reinterpret_cast<const uint4*>(smem + a_off[m] + toff + kg * 32);
-                    if constexpr (sizeof(T) == 2) {
-                        const half8 A = __builtin_bit_cast(half8, av);
+                    for (int n = 0; n < NB; ++n)
+                        acc[n][kg & (NACC - 1)] = mfma16_16(__builtin_bit_cast(half8, av), __builtin_bit_cast(half8, bw[n]),
+                                                            acc[n][kg & (NACC - 1)]);
+                } else {
+                    // 16x16x4 f32: 32-cycle issue, 40-cycle dependent latency -> alternate accumulators
+                    const f32x4v A = __builtin_bit_cast(f32x4v, av);
 #pragma unroll
-                        for (int j = 0; j < NB; ++j)
-                            acc[m][j] = mfma16(A, __builtin_bit_cast(half8, bw[j]), acc[m][j]);
-                    } else {
-                        const f32x4 A = __builtin_bit_cast(f32x4, av);
+                    for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int j = 0; j < NB; ++j) {
-                            const f32x4 Bv = __builtin_bit_cast(f32x4, bw[j]);
-                            acc[m][j] = mfma32(A[0], Bv[0], acc[m][j]);
-                            acc[m][j] = mfma32(A[1], Bv[1], acc[m][j]);
-                            acc[m][j] = mfma32(A[2], Bv[2], acc[m][j]);
-                            acc[m][j] = mfma32(A[3], Bv[3], acc[m][j]);
-                        }
-                    }
+                        for (int n = 0; n < NB; ++n)
+                            acc[n][e & (NACC - 1)] = mfma32_16(A[e], __builtin_bit_cast(f32x4v, bw[n])[e], acc[n][e & (NACC - 1)]);
                 }
             }
         }
-    }
-
-    // ---- epilogue: bias (+ReLU) and stores.  Lane holds cout = nb*32 + n for 4 quads x 4 pixels ------
-    T* out = reinterpret_cast<T*>(a.out);
+        // ---- epilogue after the last chunk: lane holds cout j of quad g (4 pixels) ------------------
+        if (cc == NCHUNK - 1) {
+            int tx, ty, img;
+            unit_coords(u, tx, ty, img);
+            T* out = reinterpret_cast<T*>(a.out);
+            const int qy = 4 * ty + 2 * (g >> 1), qx = 4 * tx + 2 * (g & 1);
+            const bool qok = qy < H && qx < W;             // H, W even: a quad is in or out as a whole
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        if (!t_ok[m]) continue;
-        const int tile = wave + m * NW;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int co = (nb0 + j) * 32 + n;
-            const float bv = a.bias[co];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {                 // quad index within the tile = 2*g + hi
-                const int q = tile * 8 + 2 * g + hi;
-                if (q >= QUADS) continue;
-                const int qy = q / (W / 2), qx = q % (W / 2);
+            for (int n = 0; n < NB; ++n) {
+                const int co = (nb0 + n) * 16 + j;
+                const float bv = a.bias[co];
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = acc[m][j][4 * g + e] + bv;
+                    float sacc = acc[n][0][e];
+                    if (NACC == 2) sacc += acc[n][NACC - 1][e];
+                    v[e] = sacc + bv;
                     if (KIND == CONV3) v[e] = relu(v[e]);
+                    acc[n][0][e] = 0.f;
+                    acc[n][NACC - 1][e] = 0.f;
                 }
+                if (qok) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int y = y0 + 2 * qy + (e >> 1), x = 2 * qx + (e & 1);
-                    if (KIND == UPCONV) {
-                        const int oy = 2 * y + (sub >> 1), ox = 2 * x + (sub & 1);
-                        out[((size_t)(img * 2 * H + oy) * (2 * W) + ox) * COUT + co] = (T)v[e];
-                    } else {
-                        out[((size_t)(img * H + y) * W + x) * COUT + co] = (T)v[e];
-                        if (KIND == CONV1 && a.out_nchw)
-                            a.out_nchw[((size_t)img * COUT + co) * H * W + y * W + x] = v[e];
+                    for (int e = 0; e < 4; ++e) {
+                        const int y = qy + (e >> 1), x = qx + (e & 1);
+                        if (KIND == UPCONV) {
+                            const int oy = 2 * y + (sub >> 1), ox = 2 * x + (sub & 1);
+                            out[((size_t)(img * 2 * H + oy) * (2 * W) + ox) * COUT + co] = (T)v[e];
+                        } else {
+                            out[((size_t)(img * H + y) * W + x) * COUT + co] = (T)v[e];
+                            if (KIND == CONV1 && a.out_nchw)
+                                a.out_nchw[((size_t)img * COUT + co) * H * W + y * W + x] = v[e];
+                        }
                     }
-                }
-                if (POOL) {
-                    const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                    T* op = reinterpret_cast<T*>(a.out_pool);
-                    op[((size_t)(img * (H / 2) + y0 / 2 + qy) * (W / 2) + qx) * COUT + co] = (T)mx;
+                    if (POOL) {
+                        const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                        T* op = reinterpret_cast<T*>(a.out_pool);
+                        op[((size_t)(img * (H / 2) + qy / 2) * (W / 2) + qx / 2) * COUT + co] = (T)mx;
+                    }
                 }
             }
         }
+        if (!more) break;
+        u = un; cc = ccn;
     }
 }
 
-template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int ROWS, int NW, int NB, bool POOL>
+template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
     constexpr int HALO = KIND == CONV3 ? 1 : 0;
-    constexpr int PS = 32 * (int)sizeof(T) + 16;
-    constexpr size_t lds = (size_t)(ROWS + 2 * HALO) * (W + 2 * HALO) * PS;
+    constexpr int TAPS = KIND == CONV3 ? 9 : 1;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int PS = 32 * ES + 16;
+    constexpr int NPIX = (4 + 2 * HALO) * (4 + 2 * HALO);
+    constexpr int REGION = (NPIX * PS + 15) / 16 * 16;
     constexpr int NSUB = KIND == UPCONV ? 4 : 1;
-    auto kern = conv_mfma_kernel<T, KIND, C0, C1, COUT, H, W, ROWS, NW, NB, POOL>;
+    constexpr int NGRP = NSUB * (COUT / 16 / NB);
+    constexpr int KGT = (C0 + C1) / 32 * (ES == 4 ? 2 : 1);
+    constexpr size_t lds = (size_t)NB * TAPS * KGT * FRAG + CONV_NW * REGION;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert(256 % NGRP == 0, "weight groups must divide the CU count");
+    const int units = a.nimg * ((H + 3) / 4) * ((W + 3) / 4);        // per weight group
+    int wgs = (units + CONV_NW - 1) / CONV_NW;                        // workgroups per weight group
+    if (wgs > 256 / NGRP) wgs = 256 / NGRP;                           // one persistent workgroup per CU
+    auto kern = conv16_kernel<T, KIND, C0, C1, COUT, H, W, NB, POOL>;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid(a.nimg * (H / ROWS), NSUB * (COUT / 32 / NB));
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(wgs * NGRP), dim3(CONV_NW * 64), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
 // ----------------------------------------------------------------------------------------------------
 // Encoder driver.  Workspace carve (all NHWC, element type T):
 //   P0 planes_in [3B,40,40,32] | A0 | S0 (skip 0) | Q0 [3B,20,20,32] | A1 [..,20,20,64] | S1 | Q1 [..,10,10,64]
-//   | A2 [..,10,10,128] | S2 | U0 [..,20,20,64] | A3 | A4 | U1 [..,40,40,32] | A5 | A6 | YZ, XZ partials fp32
+//   | A2 [..,10,10,128] | S2 | U0 [..,20,20,64] | A3 | A4 | U1 [..,40,40,32] | A5 | A6 | YZ partials fp32
 // ----------------------------------------------------------------------------------------------------
 struct EncWs {
-    size_t P0, A0, S0, Q0, A1, S1, Q1, A2, S2, U0, A3, A4, U1, A5, A6, YZ, XZ, total;
+    size_t P0, A0, S0, Q0, A1, S1, Q1, A2, S2, U0, A3, A4, U1, A5, A6, YZ, XZ, total;   // XZ unused (kept for the ABI)
 };
 EncWs enc_workspace(int B, int precision, int nslab) {
     const size_t es = precision == 1 ? 2 : 4;
@@ -371,12 +444,18 @@ EncWs enc_workspace(int B, int precision, int nslab) {
     w.U0 = take(n * 400 * 64, es);  w.A3 = take(n * 400 * 64, es);  w.A4 = take(n * 400 * 64, es);
     w.U1 = take(n * 1600 * 32, es); w.A5 = take(n * 1600 * 32, es); w.A6 = take(n * 1600 * 32, es);
     w.YZ = take((size_t)nslab * B * 1600 * 32, 4);
-    w.XZ = take((size_t)2 * B * 1600 * 32, 4);
+    w.XZ = w.YZ;
     w.total = at;
     return w;
 }
 
-int enc_nslab(int B) { return B >= 8 ? 5 : B >= 4 ? 10 : 20; }
+// slabs per scene: the smallest divisor of 40 that gives >= 256 workgroups (one per CU), at most 40
+int enc_nslab(int B) {
+    const int divs[8] = {1, 2, 4, 5, 8, 10, 20, 40};
+    for (int d : divs)
+        if ((long long)B * d >= 256) return d;
+    return 40;
+}
 
 // probe: if probe_stage == k, ev0/ev1 (hipEvent_t) are recorded right before / after launch k
 // (k = 0 conv_in+project, 1 plane_finalize, 2..14 = U-Net layers 0..12).
@@ -394,19 +473,18 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     const EncWs w = enc_workspace(B, precision, nslab);
     T* P0 = reinterpret_cast<T*>(ws + w.P0);
     float* YZ = reinterpret_cast<float*>(ws + w.YZ);
-    float* XZ = reinterpret_cast<float*>(ws + w.XZ);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convin_project_kernel<T>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)CI_LDS_BYTES);
     pre();
-    hipLaunchKernelGGL(convin_project_kernel<T>, dim3(nslab, B, 2), dim3(320), CI_LDS_BYTES, s, tsdf,
+    hipLaunchKernelGGL(convin_project_kernel<T>, dim3(nslab, B), dim3(512), CI_LDS_BYTES, s, tsdf,
                        reinterpret_cast<const float*>(blob + ko.convin_w),
-                       reinterpret_cast<const float*>(blob + ko.convin_b), P0, XZ, YZ, B, RES / nslab);
+                       reinterpret_cast<const float*>(blob + ko.convin_b), P0, YZ, B, RES / nslab);
     post();
     {
         pre();
         const size_t per = (size_t)B * RES * RES * CD;
-        hipLaunchKernelGGL(plane_finalize_kernel<T>, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, XZ, YZ,
-                           P0, B, nslab);
+        hipLaunchKernelGGL(plane_finalize_kernel<T>, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, YZ, P0, B,
+                           nslab);
         post();
     }
     if (hipGetLastError() != hipSuccess) return -10;
@@ -422,23 +500,23 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     };
     uint8_t* b = ws;
     int rc = 0;
-    // template params: <T, KIND, C0, C1, COUT, H, W, ROWS, NW, NB, POOL>
-    pre(); rc |= launch_conv<T, CONV3, 32, 0, 32, 40, 40, 8, 5, 1, false>(args(0, b + w.P0, nullptr, b + w.A0, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 32, 0, 32, 40, 40, 8, 5, 1, true>(args(1, b + w.A0, nullptr, b + w.S0, b + w.Q0), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 32, 0, 64, 20, 20, 10, 4, 1, false>(args(2, b + w.Q0, nullptr, b + w.A1, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 64, 0, 64, 20, 20, 10, 4, 1, true>(args(3, b + w.A1, nullptr, b + w.S1, b + w.Q1), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 64, 0, 128, 10, 10, 10, 4, 1, false>(args(4, b + w.Q1, nullptr, b + w.A2, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 128, 0, 128, 10, 10, 10, 4, 1, false>(args(5, b + w.A2, nullptr, b + w.S2, nullptr), s); post();
-    pre(); rc |= launch_conv<T, UPCONV, 128, 0, 64, 10, 10, 10, 4, 2, false>(args(6, b + w.S2, nullptr, b + w.U0, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 64, 64, 64, 20, 20, 10, 4, 1, false>(args(7, b + w.U0, b + w.S1, b + w.A3, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 64, 0, 64, 20, 20, 10, 4, 1, false>(args(8, b + w.A3, nullptr, b + w.A4, nullptr), s); post();
-    pre(); rc |= launch_conv<T, UPCONV, 64, 0, 32, 20, 20, 10, 4, 1, false>(args(9, b + w.A4, nullptr, b + w.U1, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 32, 32, 32, 40, 40, 8, 5, 1, false>(args(10, b + w.U1, b + w.S0, b + w.A5, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 32, 0, 32, 40, 40, 8, 5, 1, false>(args(11, b + w.A5, nullptr, b + w.A6, nullptr), s); post();
+    // template params: <T, KIND, C0, C1, COUT, H, W, NB (16-channel blocks per unit), POOL>
+    pre(); rc |= launch_conv<T, CONV3, 32, 0, 32, 40, 40, 2, false>(args(0, b + w.P0, nullptr, b + w.A0, nullptr), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 32, 0, 32, 40, 40, 2, true>(args(1, b + w.A0, nullptr, b + w.S0, b + w.Q0), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 32, 0, 64, 20, 20, 1, false>(args(2, b + w.Q0, nullptr, b + w.A1, nullptr), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 64, 0, 64, 20, 20, 1, true>(args(3, b + w.A1, nullptr, b + w.S1, b + w.Q1), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 64, 0, 128, 10, 10, 1, false>(args(4, b + w.Q1, nullptr, b + w.A2, nullptr), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 128, 0, 128, 10, 10, 1, false>(args(5, b + w.A2, nullptr, b + w.S2, nullptr), s); post();
+    pre(); rc |= launch_conv<T, UPCONV, 128, 0, 64, 10, 10, 2, false>(args(6, b + w.S2, nullptr, b + w.U0, nullptr), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 64, 64, 64, 20, 20, 1, false>(args(7, b + w.U0, b + w.S1, b + w.A3, nullptr), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 64, 0, 64, 20, 20, 1, false>(args(8, b + w.A3, nullptr, b + w.A4, nullptr), s); post();
+    pre(); rc |= launch_conv<T, UPCONV, 64, 0, 32, 20, 20, 2, false>(args(9, b + w.A4, nullptr, b + w.U1, nullptr), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 32, 32, 32, 40, 40, 2, false>(args(10, b + w.U1, b + w.S0, b + w.A5, nullptr), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 32, 0, 32, 40, 40, 2, false>(args(11, b + w.A5, nullptr, b + w.A6, nullptr), s); post();
     {
         ConvArgs a = args(12, b + w.A6, nullptr, planes_nhwc, nullptr);
         a.out_nchw = planes_nchw;
-        pre(); rc |= launch_conv<T, CONV1, 32, 0, 32, 40, 40, 8, 5, 1, false>(a, s); post();
+        pre(); rc |= launch_conv<T, CONV1, 32, 0, 32, 40, 40, 2, false>(a, s); post();
     }
     return rc;
 }

@@ -104,14 +104,15 @@ constexpr size_t FRAG = 1024;
 //   then the fp32 C-init table: 5 x 32 (fc_0 bias) + 32 (fc_out bias, zero padded)
 constexpr int DEC16_FRAGS = NBLK * (7 + 2 + 2) + 1 + 2;                   // 58
 constexpr size_t DEC_CTAB_BYTES = (NBLK + 1) * CD * sizeof(float);        // 768
-constexpr size_t DEC16_BYTES = DEC16_FRAGS * FRAG + DEC_CTAB_BYTES;       // 60160
+constexpr size_t DEC16_BYTES = (DEC16_FRAGS + 1) * FRAG;                  // 59 KiB: 58 fragments + the C table in a
+                                                                          // 59th 1 KiB chunk (whole image = 59 LDS-DMA wave-chunks)
 // precision f32: per block 12 feature frags (48 MFMAs) + 1 aux frag (2 MFMAs used) + 4 + 4; tail 1 + 4
 constexpr int DEC32_FRAGS = NBLK * (12 + 1 + 4 + 4) + 1 + 4;              // 110
 constexpr size_t DEC32_BYTES = DEC32_FRAGS * FRAG + DEC_CTAB_BYTES;       // 113408
 
 struct ConvPackOff { size_t w16, w32, bias; int nfrag16, nfrag32; };
 struct PackOff {
-    size_t convin_w;        // fp32 [14][64]  B operands of the 14 K-steps (27 taps + 1 zero)
+    size_t convin_w;        // fp32 [2][7][64]  B operands (channel half, K-step of 4 taps; tap 27 = 0)
     size_t convin_b;        // fp32 [32]
     ConvPackOff conv[NCONV];
     size_t dec16[NHEADS], dec32[NHEADS];
@@ -128,9 +129,9 @@ inline PackOff pack_offsets() {
     for (int l = 0; l < NCONV; ++l) {
         const ConvLayerDesc& d = kConv[l];
         const int cin = d.cin0 + d.cin1;
-        const int nblk = d.cout / 32 * conv_nsub(d);
-        o.conv[l].nfrag16 = nblk * conv_taps(d) * (cin / 16);
-        o.conv[l].nfrag32 = nblk * conv_taps(d) * (cin / 8);
+        const int nblk = d.cout / 16 * conv_nsub(d);
+        o.conv[l].nfrag16 = nblk * conv_taps(d) * (cin / 32);
+        o.conv[l].nfrag32 = nblk * conv_taps(d) * (cin / 16);
         o.conv[l].w16 = at; at += o.conv[l].nfrag16 * FRAG;
         o.conv[l].w32 = at; at += o.conv[l].nfrag32 * FRAG;
         o.conv[l].bias = at; at += align_up(d.cout * sizeof(float), 256);

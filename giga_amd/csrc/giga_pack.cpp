@@ -130,30 +130,33 @@ static inline float conv_w_at(const float* W, const ConvLayerDesc& d, int co, in
 }
 
 static void pack_conv(const float* P, const ParamOff& po, const PackOff& ko, int l, uint8_t* blob) {
+    // 16x16 MFMA B-operand fragments: lane (j = lane&15 -> output channel, g = lane>>4 -> k-slot group)
+    //   f32 (v_mfma_f32_16x16x4_f32, 4 per fragment): 4 floats e -> W[co = nb*16+j][ci = kg*16 + 4g + e]
+    //   f16 (v_mfma_f32_16x16x32_f16, 1 per fragment): 8 halfs e -> W[co][ci = kg*32 + 8g + e]
+    // fragment order: [sub (ConvTranspose tap)][nb16][tap][kg]
     const ConvLayerDesc& d = kConv[l];
     const float* W = P + po.conv_w[l];
-    const int cin = d.cin0 + d.cin1, taps = conv_taps(d), nsub = conv_nsub(d), nb32 = d.cout / 32;
+    const int cin = d.cin0 + d.cin1, taps = conv_taps(d), nsub = conv_nsub(d), nb16 = d.cout / 16;
     half_t* f16 = reinterpret_cast<half_t*>(blob + ko.conv[l].w16);
     float* f32 = reinterpret_cast<float*>(blob + ko.conv[l].w32);
-    // fragment order: [sub (upconv d)][nb][tap][kg]
     size_t i16 = 0, i32 = 0;
     for (int sub = 0; sub < nsub; ++sub)
-        for (int nb = 0; nb < nb32; ++nb)
+        for (int nb = 0; nb < nb16; ++nb)
             for (int tap = 0; tap < taps; ++tap) {
                 const int wtap = d.kind == UPCONV ? sub : tap;
-                for (int kg = 0; kg < cin / 16; ++kg, ++i16)
+                for (int kg = 0; kg < cin / 32; ++kg, ++i16)
                     for (int lane = 0; lane < 64; ++lane) {
-                        int n = lane & 31, hi = lane >> 5;
-                        for (int j = 0; j < 8; ++j)
-                            f16[i16 * 512 + lane * 8 + j] =
-                                f2h(conv_w_at(W, d, nb * 32 + n, kg * 16 + 8 * hi + j, wtap));
+                        const int j = lane & 15, g = lane >> 4;
+                        for (int e = 0; e < 8; ++e)
+                            f16[i16 * 512 + lane * 8 + e] =
+                                f2h(conv_w_at(W, d, nb * 16 + j, kg * 32 + 8 * g + e, wtap));
                     }
-                for (int kg = 0; kg < cin / 8; ++kg, ++i32)
+                for (int kg = 0; kg < cin / 16; ++kg, ++i32)
                     for (int lane = 0; lane < 64; ++lane) {
-                        int n = lane & 31, hi = lane >> 5;
-                        for (int j = 0; j < 4; ++j)
-                            f32[i32 * 256 + lane * 4 + j] =
-                                conv_w_at(W, d, nb * 32 + n, kg * 8 + 4 * hi + j, wtap);
+                        const int j = lane & 15, g = lane >> 4;
+                        for (int e = 0; e < 4; ++e)
+                            f32[i32 * 256 + lane * 4 + e] =
+                                conv_w_at(W, d, nb * 16 + j, kg * 16 + 4 * g + e, wtap);
                     }
             }
     float* bias = reinterpret_cast<float*>(blob + ko.conv[l].bias);
@@ -169,13 +172,15 @@ int pack_weights_host(const float* P, size_t n_params, int head_present, uint8_t
     if (n_params != po.total) return -2;
     if (blob_bytes < ko.total) return -3;
     std::memset(blob, 0, ko.total);
-    // conv_in: B operand of K-step s: lane (n,hi) -> W[n][tap = 2s+hi], tap 27 = 0
+    // conv_in: B operand of K-step s (v_mfma_f32_16x16x4_f32) for channel half h:
+    //   [h][s][lane]: lane (j = lane&15, k = lane>>4) -> W[16h + j][tap = 4s + k], tap 27 = 0
     float* cw = reinterpret_cast<float*>(blob + ko.convin_w);
-    for (int s = 0; s < 14; ++s)
-        for (int lane = 0; lane < 64; ++lane) {
-            int n = lane & 31, tap = 2 * s + (lane >> 5);
-            cw[s * 64 + lane] = tap < 27 ? P[po.conv_in_w + n * 27 + tap] : 0.f;
-        }
+    for (int h = 0; h < 2; ++h)
+        for (int s = 0; s < 7; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                int n = 16 * h + (lane & 15), tap = 4 * s + (lane >> 4);
+                cw[(h * 7 + s) * 64 + lane] = tap < 27 ? P[po.conv_in_w + n * 27 + tap] : 0.f;
+            }
     float* cb = reinterpret_cast<float*>(blob + ko.convin_b);
     for (int n = 0; n < 32; ++n) cb[n] = P[po.conv_in_b + n];
     for (int l = 0; l < NCONV; ++l) pack_conv(P, po, ko, l, blob);

@@ -12,9 +12,17 @@ from . import synth
 
 
 def query_lattice(resolution=40, device=None):
-    """detection_implicit.py:28-31 -> (1, R^3, 3) float32."""
+    """detection_implicit.py:28-31 -> (1, R^3, 3) float32 (bit-identical to the reference's self.pos).
+
+    The returned tensor is registered as "the inference lattice": passing it (the same object) to the
+    network selects the lattice fast path of the decoder, which samples each plane once per lattice
+    coordinate pair instead of once per point, and it may be shared by a whole batch of scenes."""
+    from .convonet import register_lattice
     pos = torch.from_numpy(synth.inference_lattice(resolution))
-    return pos.to(device) if device is not None else pos
+    if device is not None:
+        pos = pos.to(device)
+    lin = pos[0, :: resolution * resolution, 0].clone()      # the R coordinates (x varies slowest)
+    return register_lattice(pos, lin)
 
 
 def predict(tsdf_vol, pos, net, device):
@@ -29,8 +37,9 @@ def predict(tsdf_vol, pos, net, device):
 
 def predict_batch(tsdf_batch, pos, net):
     """Batched device-resident variant: tsdf_batch (B,40,40,40) cuda tensor, pos (1|B,N,3) -> device tensors."""
+    from .convonet import _lattice_of
     B = tsdf_batch.shape[0]
-    if pos.shape[0] == 1 and B > 1:
-        pos = pos.expand(B, -1, -1).contiguous()
+    if pos.shape[0] == 1 and B > 1 and _lattice_of(pos) is None:
+        pos = pos.expand(B, -1, -1).contiguous()          # a registered lattice is shared as-is
     with torch.no_grad():
         return net(tsdf_batch, pos)

@@ -87,6 +87,19 @@ int giga_decoder_forward(const void* planes_nhwc, const float* p, const void* pa
                          float* qual, float* rot, float* width, float* occ, int B, int N,
                          int precision, int post, void* stream);
 
+/* Inference fast path for the FIXED QUERY LATTICE of VGNImplicit (detection_implicit.py:28-31,107):
+ * the R^3 points meshgrid(lin, lin, lin, 'ij') with z fastest, shared by all B scenes.  Each plane is
+ * sampled at only R*R distinct positions, so the planes are first resampled at the lattice coordinates
+ * (same arithmetic as sample_plane_feature, decoder.py:117-122) into `workspace`
+ * (giga_lattice_workspace_bytes) and the fused decoder then reads three pixels per point instead of
+ * twelve bilinear taps.  lin: device pointer to the R lattice coordinates (R <= 64).
+ * Outputs as giga_decoder_forward with N = R^3; ev_start/ev_stop (may be NULL) bracket the decoder launch. */
+size_t giga_lattice_workspace_bytes(int B, int R, int precision);
+int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, const void* packed, int head_mask,
+                                 float* qual, float* rot, float* width, float* occ, int B, int R, int precision,
+                                 int post, void* workspace, size_t workspace_bytes, void* stream,
+                                 void* ev_start, void* ev_stop);
+
 /* ---- measurement hooks (bench.py roofline): HIP events recorded on `stream` right before and
  * after ONE kernel launch, so the kernel's duration is measured live on the stream it runs on.
  * probe_stage: 0 conv_in+project, 1 plane_finalize, 2..14 = U-Net layers 0..12 (giga_layout.h kConv).

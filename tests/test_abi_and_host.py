@@ -59,25 +59,42 @@ def test_pack_is_deterministic_and_sensitive(sd7):
 
 
 def test_conv_fragments_round_trip(sd7):
-    """Invert the documented conv fragment layout (giga_pack.cpp) and recover the weights."""
+    """Invert the documented 16x16-MFMA fragment layout (giga_pack.cpp) and recover the weights."""
     flat = torch.cat([v.reshape(-1) for v in sd7.values()])
     blob = _capi.pack_weights(flat, 15).numpy()
     at = 14 * 64 * 4 + 256
     W = sd7["encoder.unet.down_convs.0.conv1.weight"].numpy()         # (32,32,3,3), layer 0
-    f16 = blob[at:at + 18 * 1024].view(np.float16).reshape(9, 2, 64, 8)      # [tap][kg][lane][j]
-    f32 = blob[at + 18 * 1024:at + 54 * 1024].view(np.float32).reshape(9, 4, 64, 4)
-    for tap in (0, 4, 8):
-        for lane in (0, 17, 40, 63):
-            n, hi = lane & 31, lane >> 5
-            for kg in range(4):
-                np.testing.assert_array_equal(f32[tap, kg, lane], W[n, kg * 8 + 4 * hi:kg * 8 + 4 * hi + 4, tap // 3, tap % 3])
-            for kg in range(2):
-                np.testing.assert_array_equal(f16[tap, kg, lane],
-                                              W[n, kg * 16 + 8 * hi:kg * 16 + 8 * hi + 8, tap // 3, tap % 3].astype(np.float16))
-    # conv_in B operands: [s][lane] = W[n][tap 2s+hi]
-    ci = blob[:14 * 64 * 4].view(np.float32).reshape(14, 64)
+    # layer 0: nb16 = 2, taps = 9; f16: kg = 1 (32 channels / fragment), f32: kg = 2 (16 channels / fragment)
+    f16 = blob[at:at + 18 * 1024].view(np.float16).reshape(2, 9, 1, 64, 8)      # [nb][tap][kg][lane][e]
+    f32 = blob[at + 18 * 1024:at + 54 * 1024].view(np.float32).reshape(2, 9, 2, 64, 4)
+    for nb in range(2):
+        for tap in (0, 4, 8):
+            for lane in (0, 17, 40, 63):
+                j, g = lane & 15, lane >> 4
+                co = nb * 16 + j
+                for kg in range(2):
+                    np.testing.assert_array_equal(
+                        f32[nb, tap, kg, lane], W[co, kg * 16 + 4 * g:kg * 16 + 4 * g + 4, tap // 3, tap % 3])
+                np.testing.assert_array_equal(
+                    f16[nb, tap, 0, lane], W[co, 8 * g:8 * g + 8, tap // 3, tap % 3].astype(np.float16))
+    # conv_in B operands: [half][s][lane] = W[16*half + (lane&15)][tap 4s + (lane>>4)], tap 27 -> 0
+    ci = blob[:14 * 64 * 4].view(np.float32).reshape(2, 7, 64)
     Wi = sd7["encoder.conv_in.weight"].numpy().reshape(32, 27)
-    assert ci[3, 5] == Wi[5, 6] and ci[3, 37] == Wi[5, 7] and ci[13, 40] == 0.0 and ci[13, 8] == Wi[8, 26]
+    assert ci[0, 3, 5] == Wi[5, 12] and ci[1, 3, 37] == Wi[16 + 5, 14] and ci[1, 6, 63] == 0.0
+    assert ci[0, 6, 40] == Wi[8, 26]
+    # ConvTranspose layer (index 6): W[ci][co][dy][dx], sub-output d = dy*2+dx is the fragment "sub"
+    off = at
+    convs = [(9, 32, 32), (9, 32, 32), (9, 32, 64), (9, 64, 64), (9, 64, 128), (9, 128, 128)]
+    for taps, cin, cout in convs:
+        nblk = cout // 16
+        off += nblk * taps * (cin // 32) * 1024 + nblk * taps * (cin // 16) * 1024 + (cout * 4 + 255) // 256 * 256
+    Wu = sd7["encoder.unet.up_convs.0.upconv.weight"].numpy()         # (128, 64, 2, 2)
+    n16 = 4 * 4 * 1 * 4                                               # subs * nb16 * taps * (128/32)
+    f32u = blob[off + n16 * 1024:off + n16 * 1024 + 4 * 4 * 8 * 1024].view(np.float32).reshape(4, 4, 1, 8, 64, 4)
+    for sub, nb, kg, lane in ((0, 0, 0, 3), (3, 2, 5, 44), (1, 3, 7, 63)):
+        j, g = lane & 15, lane >> 4
+        np.testing.assert_array_equal(f32u[sub, nb, 0, kg, lane],
+                                      Wu[kg * 16 + 4 * g:kg * 16 + 4 * g + 4, nb * 16 + j, sub // 2, sub % 2])
 
 
 def test_module_tree_matches_reference_state_dict():

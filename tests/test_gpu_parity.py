@@ -103,6 +103,27 @@ def test_inference_lattice_g3_and_predict(net, dev, sd7, golden, prec, tol):
             assert abs(arr.astype(np.float64).sum() - s[0]) < 2e-5 * max(1.0, s[1])
 
 
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("fp16", 1e-2)])
+def test_lattice_fast_path_equals_generic_path(net, dev, sd7, prec, tol):
+    """The registered inference lattice (shared by a batch of scenes) takes the resampled-plane path;
+    a plain copy of the same points takes the generic gather path.  Same arithmetic, so fp32 agrees
+    to rounding; both agree with the oracle."""
+    from giga_amd.detection import predict_batch, query_lattice
+    net.set_precision(prec)
+    lat = query_lattice(40, dev)                          # registered -> lattice path
+    x = torch.from_numpy(synth.tsdf_batch(60, 3)).to(dev)
+    plain = lat.clone().expand(3, -1, -1).contiguous()    # unregistered -> generic path
+    with torch.no_grad():
+        fast = predict_batch(x, lat, net)
+        slow = net(x, plain)
+        ref = O.model_forward(sd7, x[1:2].cpu(), lat.cpu())
+    for a, b, r in zip(fast, slow, ref):
+        assert a.shape == b.shape and a.shape[0] == 3
+        assert maxerr(a, b.cpu()) < tol
+        assert maxerr(a[1:2], r) < max(tol, 1e-4)
+    net.set_precision("fp32")
+
+
 def test_edge_cases_g5(net, dev, sd7, golden):
     net.set_precision("fp32")
     g = golden("g5_edges.npz")
