@@ -1,0 +1,29 @@
+// Kernel-argument structs shared by the launchers (giga_decoder.hip) and the C ABI (giga_capi.hip).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#include "giga_layout.h"
+
+namespace giga {
+
+struct DecArgs {
+    const void* planes;      // [3][B][40][40][32]  (plane, scene, H, W, C)  half or float
+    const float* p;          // [P][3]
+    const uint8_t* blob;     // packed weights
+    size_t head_off[NHEADS]; // byte offset of each requested head's blob (this precision)
+    int head_id[NHEADS];     // 0 qual, 1 rot, 2 width, 3 tsdf
+    float* out[NHEADS];      // output pointer per requested head
+    int nheads;
+    int B, N;                // P = B*N points; point g belongs to scene g / N
+    long long P;
+    int nbatch;              // number of workgroup batches
+    int heads_per_wg;        // fp32 kernel: heads handled by one workgroup (blockIdx.y selects the group)
+    int post;                // 1: sigmoid(qual), normalize(rot)  (models/__init__.py:120-122)
+    const float* lin;        // lattice mode: the R lattice coordinates (detection_implicit.py:28-31)
+    int R;                   // lattice mode: points per axis; planes = lattice-resampled planes [3][B][R][R][32]
+    float invN;              // 1 / N
+    unsigned mR, mR2;        // ceil(2^32 / R), ceil(2^32 / R^2)   (lattice mode)
+};
+
+}  // namespace giga

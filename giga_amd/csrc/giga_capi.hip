@@ -3,6 +3,7 @@
 
 #include "../../include/giga_hip.h"
 #include "giga_layout.h"
+#include "giga_args.h"
 
 namespace giga {
 // giga_pack.cpp
@@ -15,12 +16,6 @@ int enc_nslab(int B);
 int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, float* planes_nchw, int B,
                    int precision, uint8_t* ws, hipStream_t s, int probe_stage, void* ev0, void* ev1);
 // giga_decoder.hip
-struct DecArgs {
-    const void* planes; const float* p; const uint8_t* blob;
-    size_t head_off[NHEADS]; int head_id[NHEADS]; float* out[NHEADS];
-    int nheads; int B, N; long long P; int nbatch; int post; const float* lin; int R;
-    float invN; unsigned mR, mR2;
-};
 int launch_decoder(const DecArgs& a, int precision, hipStream_t s, void* ev0, void* ev1);
 int launch_planes_pack(const float* xz, const float* xy, const float* yz, void* dst, int B, int precision, hipStream_t s);
 int launch_lattice_resample(const void* planes, const float* lin, void* out, int B, int R, int precision, hipStream_t s);

@@ -14,26 +14,10 @@
 // so the whole 11-layer chain runs without any cross-lane traffic.  The fp32 residual stream lives
 // in the accumulator (C-in = stream), biases ride in a constant-one k-slot or in the C operand.
 #include "giga_dev.h"
+#include "giga_args.h"
 
 namespace giga {
 
-struct DecArgs {
-    const void* planes;      // [3][B][40][40][32]  (plane, scene, H, W, C)  half or float
-    const float* p;          // [P][3]
-    const uint8_t* blob;     // packed weights
-    size_t head_off[NHEADS]; // byte offset of each requested head's blob (this precision)
-    int head_id[NHEADS];     // 0 qual, 1 rot, 2 width, 3 tsdf
-    float* out[NHEADS];      // output pointer per requested head
-    int nheads;
-    int B, N;                // P = B*N points; point g belongs to scene g / N
-    long long P;
-    int nbatch;              // number of workgroup batches
-    int post;                // 1: sigmoid(qual), normalize(rot)  (models/__init__.py:120-122)
-    const float* lin;        // lattice mode: the R lattice coordinates (detection_implicit.py:28-31)
-    int R;                   // lattice mode: points per axis; planes = lattice-resampled planes [3][B][R][R][32]
-    float invN;              // 1 / N
-    unsigned mR, mR2;        // ceil(2^32 / R), ceil(2^32 / R^2)   (lattice mode)
-};
 
 __device__ __forceinline__ void store_head(const DecArgs& a, int h, long long g, float d0, float d1,
                                            float d2, float d3) {
@@ -52,11 +36,6 @@ __device__ __forceinline__ void store_head(const DecArgs& a, int h, long long g,
     }
 }
 
-__device__ __forceinline__ void stage_blob(uint8_t* smem, const uint8_t* src, int bytes) {
-    const uint4* s = reinterpret_cast<const uint4*>(src);
-    uint4* d = reinterpret_cast<uint4*>(smem);
-    for (int i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = s[i];
-}
 
 // =============================== f16 MFMA path =====================================================
 // Persistent workgroups of 8 waves (2 per SIMD).  Round = 512 points (T=2 tiles of 32 per wave): the
@@ -66,9 +45,9 @@ __device__ __forceinline__ void stage_blob(uint8_t* smem, const uint8_t* src, in
 // barrier per step; it is both "image s has landed" and "everyone left image s-1".
 constexpr int DEC16_CHUNKS = (int)(DEC16_BYTES / FRAG);      // 59
 
-template <int NW>
+template <int NW, int CHUNKS = DEC16_CHUNKS>
 __device__ __forceinline__ void dma_head_image(const uint8_t* src, uint8_t* lds_dst, int wave, int lane) {
-    for (int c = wave; c < DEC16_CHUNKS; c += NW)
+    for (int c = wave; c < CHUNKS; c += NW)
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(src + (size_t)c * FRAG + lane * 16),
             (__attribute__((address_space(3))) void*)(lds_dst + c * FRAG), 16, 0, 0);
@@ -306,7 +285,11 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16_kernel(DecArgs a) {
 template <int T, bool LATTICE>
 __global__ __launch_bounds__(256, 1) void decoder_f32_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // few point batches (e.g. train_giga's single grasp query per scene): heads are spread over blockIdx.y
+    const int h_begin = blockIdx.y * a.heads_per_wg;
+    const int h_end = h_begin + a.heads_per_wg < a.nheads ? h_begin + a.heads_per_wg : a.nheads;
     const int n = lane & 31, hi = lane >> 5;
     const float4* W = reinterpret_cast<const float4*>(smem);
     const float* ctab = reinterpret_cast<const float*>(smem + (size_t)DEC32_FRAGS * FRAG);
@@ -370,9 +353,10 @@ __global__ __launch_bounds__(256, 1) void decoder_f32_kernel(DecArgs a) {
             }
             }
         }
-        for (int h = 0; h < a.nheads; ++h) {
-            __syncthreads();
-            stage_blob(smem, a.blob + a.head_off[h], (int)DEC32_BYTES);
+        for (int h = h_begin; h < h_end; ++h) {
+            __syncthreads();                                  // everyone left the previous weight image
+            dma_head_image<4, (int)(DEC32_BYTES / FRAG)>(a.blob + a.head_off[h], smem, wave, lane);
+            __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): LDS-DMA landed (builtin: see f16 kernel)
             __syncthreads();
             f32x16 net[T], hh[T];
 #pragma unroll
@@ -567,6 +551,7 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
         a.nbatch = (int)((tiles + 4 * T - 1) / (4 * T));
         const int grid = a.nbatch < 256 ? a.nbatch : 256;
         auto kern = lat ? decoder_f32_kernel<T, true> : decoder_f32_kernel<T, false>;
+        a.heads_per_wg = a.nheads;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)DEC32_BYTES);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), DEC32_BYTES, s, a);
@@ -575,9 +560,12 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
         a.nbatch = (int)((tiles + 4 * T - 1) / (4 * T));
         const int grid = a.nbatch < 256 ? a.nbatch : 256;
         auto kern = lat ? decoder_f32_kernel<T, true> : decoder_f32_kernel<T, false>;
+        // when the point batches cannot fill the chip, give every head its own workgroups
+        const bool split = grid * a.nheads <= 256;
+        a.heads_per_wg = split ? 1 : a.nheads;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)DEC32_BYTES);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), DEC32_BYTES, s, a);
+        hipLaunchKernelGGL(kern, dim3(grid, split ? a.nheads : 1), dim3(256), DEC32_BYTES, s, a);
     }
     if (ev0 && ev1) (void)hipEventRecord(static_cast<hipEvent_t>(ev1), s);
     return hipGetLastError() == hipSuccess ? 0 : -10;

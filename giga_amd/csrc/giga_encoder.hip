@@ -163,10 +163,14 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
         }
         if (sx + 1 < SX) commit_slice(ix + 2);
         __syncthreads();
-        for (int i = tid; i < 40 * 32; i += blockDim.x) {
-            const float s = (redw[i] + redw[1280 + i]) + (redw[2560 + i] + redw[3840 + i]);
-            const int iz = i >> 5, c = i & 31;
-            plane_xz[((size_t)iz * RES + ix) * CD + c] = (TOut)(s * inv);
+        // the fixed-order sum of the 4 iy-groups is done by ONE half of the waves (alternating per slice):
+        // the sibling wave of every SIMD goes straight on to the next slice's MFMAs
+        if ((wave >> 2) == (sx & 1)) {
+            for (int i = tid & 255; i < 40 * 32; i += 256) {
+                const float s = (redw[i] + redw[1280 + i]) + (redw[2560 + i] + redw[3840 + i]);
+                const int iz = i >> 5, c = i & 31;
+                plane_xz[((size_t)iz * RES + ix) * CD + c] = (TOut)(s * inv);
+            }
         }
     }
     // plane yz partial [iz][iy][c] for this slab

@@ -108,7 +108,7 @@ constexpr size_t DEC16_BYTES = (DEC16_FRAGS + 1) * FRAG;                  // 59 
                                                                           // 59th 1 KiB chunk (whole image = 59 LDS-DMA wave-chunks)
 // precision f32: per block 12 feature frags (48 MFMAs) + 1 aux frag (2 MFMAs used) + 4 + 4; tail 1 + 4
 constexpr int DEC32_FRAGS = NBLK * (12 + 1 + 4 + 4) + 1 + 4;              // 110
-constexpr size_t DEC32_BYTES = DEC32_FRAGS * FRAG + DEC_CTAB_BYTES;       // 113408
+constexpr size_t DEC32_BYTES = (DEC32_FRAGS + 1) * FRAG;                  // 111 KiB: fragments + C table chunk (LDS-DMA image)
 
 struct ConvPackOff { size_t w16, w32, bias; int nfrag16, nfrag32; };
 struct PackOff {

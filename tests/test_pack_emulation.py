@@ -30,7 +30,7 @@ def _blob_and_offsets(sd):
     dec16, dec32 = [], []
     for _ in range(4):
         dec16.append(at); at += up(59 * 1024)          # 58 fragments + C table in a 59th 1 KiB chunk
-        dec32.append(at); at += up(110 * 1024 + 768)
+        dec32.append(at); at += up(111 * 1024)
     assert at == blob.size
     return blob, dec16, dec32
 
