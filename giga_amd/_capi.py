@@ -26,6 +26,9 @@ _SIGNATURES = {
     "giga_packed_bytes": (ctypes.c_size_t, []),
     "giga_pack_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_size_t]),
+    "giga_pack_map": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]),
+    "giga_repack_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                          ctypes.c_void_p]),
     "giga_encoder_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "giga_encoder_workspace_layout": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "giga_encoder_forward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -39,6 +42,15 @@ _SIGNATURES = {
                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "giga_bwd_packed_bytes": (ctypes.c_size_t, []),
+    "giga_pack_bwd_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
+                                             ctypes.c_size_t]),
+    "giga_pack_bwd_map": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]),
+    "giga_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "giga_backward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "giga_event_create": (ctypes.c_void_p, []),
     "giga_event_destroy": (None, [ctypes.c_void_p]),
     "giga_event_elapsed_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
@@ -104,6 +116,32 @@ def require_device(*tensors):
             raise GigaHipError(
                 "giga_amd runs only on a HIP device (tensor is on %s); there is no CPU fallback. "
                 "Use the reference PyTorch implementation for CPU execution." % t.device)
+
+
+def pack_map(head_present):
+    """int32 CPU tensor, one entry per 4-byte blob word (see giga_pack_map in include/giga_hip.h)."""
+    L = lib()
+    n = L.giga_packed_bytes() // 4
+    m = torch.empty(n, dtype=torch.int32)
+    check(L.giga_pack_map(head_present, ptr(m), n), "giga_pack_map")
+    return m
+
+
+def pack_bwd_map(head_present):
+    L = lib()
+    n = L.giga_bwd_packed_bytes() // 4
+    m = torch.empty(n, dtype=torch.int32)
+    check(L.giga_pack_bwd_map(head_present, ptr(m), n), "giga_pack_bwd_map")
+    return m
+
+
+def pack_bwd_weights(flat_params_cpu, head_present):
+    L = lib()
+    flat = flat_params_cpu.detach().to(dtype=torch.float32, device="cpu").contiguous()
+    blob = torch.empty(L.giga_bwd_packed_bytes(), dtype=torch.uint8)
+    check(L.giga_pack_bwd_weights(ptr(flat), flat.numel(), head_present, ptr(blob), blob.numel()),
+          "giga_pack_bwd_weights")
+    return blob
 
 
 def pack_weights(flat_params_cpu, head_present):

@@ -13,8 +13,9 @@ the reference (paths relative to /root/reference/src/vgn):
 The torch.nn layers below only OWN parameters (so `load_state_dict` of a reference checkpoint works
 unchanged and initialisation matches the reference); all arithmetic runs in the hand-written HIP
 kernels of libgiga_hip.so through `giga_amd._capi`.  Inputs must live on a HIP device: there is no
-CPU path (use the reference for that).  Forward only in this round: calling with autograd enabled
-on parameters that require grad raises.
+CPU path (use the reference for that).  `ConvolutionalOccupancyNetwork.forward` is differentiable
+w.r.t. the parameters (fp32 HIP backward, giga_amd/training.py); the piecewise entry points
+(`encode_inputs`, `decode`, `LocalDecoder.forward`, ...) are inference-only and raise under autograd.
 """
 import os
 
@@ -418,8 +419,9 @@ class ConvolutionalOccupancyNetwork(nn.Module):
         """models/__init__.py:42-67.  inputs (B,40,40,40); p (B,N,3); p_tsdf (B,M,3) ->
         qual (B,N) [sigmoid], rot (B,N,4) [unit], width (B,N) [, tsdf (B,M) raw logits].
         (`_probe`: bench.py's HIP-event bracket around one encoder kernel; not part of the API.)"""
-        _check_no_grad(list(self.parameters()))
         _capi.require_device(inputs, p, p_tsdf)
+        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            return self._forward_train(inputs, p, p_tsdf)
         blob = self.packed_blob(inputs.device)
         nhwc, _ = self.encoder.encode_nhwc(inputs, blob=blob, precision=self.precision, probe=_probe)
         g = decode_heads(nhwc, p, blob, 7, self.precision, post=True)
@@ -428,6 +430,24 @@ class ConvolutionalOccupancyNetwork(nn.Module):
             t = decode_heads(nhwc, p_tsdf, blob, 8, self.precision, post=False)
             out = out + (t["decoder_tsdf"],)
         return out
+
+    def _param_list(self):
+        params = []
+        for h in HEAD_NAMES:
+            if hasattr(self, h):
+                params += _head_param_list(getattr(self, h))
+        return params + _encoder_param_list(self.encoder)
+
+    def _forward_train(self, inputs, p, p_tsdf):
+        """Differentiable fp32 path (scripts/train_giga.py:204): HIP forward + HIP backward through
+        giga_amd.training.GigaFunction.  Gradients flow to the parameters only."""
+        from .training import GigaFunction, _TrainState
+        if self.detach_tsdf:
+            raise NotImplementedError("giga_detach (detach_tsdf=True) is not supported by the HIP backward yet")
+        st = getattr(self, "_train_state", None)
+        if st is None or st.blob.device != inputs.device:
+            st = self._train_state = _TrainState(self._head_present(), inputs.device)
+        return GigaFunction.apply(st, inputs, p, p_tsdf, *self._param_list())
 
     def infer_geo(self, inputs, p_tsdf, **kwargs):
         """models/__init__.py:69-72."""

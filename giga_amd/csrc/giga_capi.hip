@@ -9,6 +9,19 @@ namespace giga {
 // giga_pack.cpp
 size_t packed_bytes();
 int pack_weights_host(const float* P, size_t n_params, int head_present, uint8_t* blob, size_t blob_bytes);
+int pack_map_host(int head_present, int32_t* map, size_t nwords);
+size_t bwd_packed_bytes();
+int pack_bwd_host(const float* P, size_t n_params, int head_present, uint8_t* blob, size_t blob_bytes);
+int pack_bwd_map_host(int head_present, int32_t* map, size_t nwords);
+// giga_encoder_bwd.hip / giga_decoder_bwd.hip
+struct BwdWs { size_t gA6, gA5, gC1, gA4, gA3, gC0, gS2, gA2, gQ1, gS1, gA1, gQ0, gS0, gA0, gP0, total; };
+BwdWs enc_bwd_workspace(int B);
+int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws,
+                            float* gplanes, uint8_t* gws, float* grads, int head_present, int B, hipStream_t s);
+size_t dec_bwd_scratch_floats(long long P, int nheads);
+int launch_decoder_backward(const float* planes, const float* p, const uint8_t* blob, const uint8_t* bwd_blob,
+                            int head_mask, const float* const* outs, const float* const* douts, float* gplanes,
+                            float* grads, int head_present, float* scratch, int B, int N, hipStream_t s);
 // giga_encoder.hip
 struct EncWs { size_t P0, A0, S0, Q0, A1, S1, Q1, A2, S2, U0, A3, A4, U1, A5, A6, YZ, XZ, total; };
 EncWs enc_workspace(int B, int precision, int nslab);
@@ -23,6 +36,16 @@ int launch_planes_unpack(const void* src, float* dst, int B, int precision, hipS
 }  // namespace giga
 
 using namespace giga;
+
+// blob word w <- params[map[w]] (map >= 0) | 0 (map == -1) | untouched (map == -2)
+__global__ void repack_kernel(const float* __restrict__ params, const int32_t* __restrict__ map,
+                              float* __restrict__ words, size_t nwords) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwords) return;
+    const int m = map[i];
+    if (m >= 0) words[i] = params[m];
+    else if (m == -1) words[i] = 0.f;
+}
 
 extern "C" {
 
@@ -51,6 +74,20 @@ int giga_pack_weights(const float* params_host, size_t n_params, int head_presen
     if (!params_host || !packed_host) return -1;
     return pack_weights_host(params_host, n_params, head_present & 15, static_cast<uint8_t*>(packed_host),
                              packed_bytes_);
+}
+
+int giga_pack_map(int head_present, int32_t* map_host, size_t nwords) {
+    if (!map_host) return -1;
+    return pack_map_host(head_present & 15, map_host, nwords);
+}
+
+int giga_repack_device(const float* params_dev, const int32_t* map_dev, void* packed_dev, size_t nwords,
+                       void* stream) {
+    if (!params_dev || !map_dev || !packed_dev) return -1;
+    if (nwords == 0) return 0;
+    hipLaunchKernelGGL(repack_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), params_dev, map_dev, static_cast<float*>(packed_dev), nwords);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
 size_t giga_encoder_workspace_bytes(int B, int precision) {
@@ -174,6 +211,70 @@ int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, cons
     }
     a.B = B; a.N = R * R * R; a.P = (long long)B * a.N; a.post = post; a.lin = lin; a.R = R;
     return launch_decoder(a, precision, s, ev_start, ev_stop);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// training path (fp32)
+size_t giga_bwd_packed_bytes(void) { return bwd_packed_bytes(); }
+
+int giga_pack_bwd_weights(const float* params_host, size_t n_params, int head_present, void* packed_host,
+                          size_t packed_bytes_) {
+    if (!params_host || !packed_host) return -1;
+    return pack_bwd_host(params_host, n_params, head_present & 15, static_cast<uint8_t*>(packed_host), packed_bytes_);
+}
+
+int giga_pack_bwd_map(int head_present, int32_t* map_host, size_t nwords) {
+    if (!map_host) return -1;
+    return pack_bwd_map_host(head_present & 15, map_host, nwords);
+}
+
+static size_t train_dec_scratch_bytes(int B, int N, int M, int head_present) {
+    const int ng = __builtin_popcount(head_present & 7), nt = (head_present >> 3) & 1;
+    const size_t a = ng ? dec_bwd_scratch_floats((long long)B * N, ng) : 0;
+    const size_t b = nt && M > 0 ? dec_bwd_scratch_floats((long long)B * M, 1) : 0;
+    return align_up((a > b ? a : b) * sizeof(float), 256);
+}
+
+size_t giga_backward_workspace_bytes(int B, int N, int M, int head_present) {
+    if (B <= 0) return 0;
+    return align_up((size_t)3 * B * RES * RES * CD * sizeof(float), 256) + enc_bwd_workspace(B).total +
+           train_dec_scratch_bytes(B, N, M, head_present);
+}
+
+int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed, const void* enc_workspace_fwd,
+                  const void* planes_nhwc, const float* p, const float* p_tsdf, const float* const* outs,
+                  const float* const* douts, float* grads, size_t n_params, int head_present, int B, int N, int M,
+                  void* workspace, size_t workspace_bytes, void* stream) {
+    if (B <= 0) return 0;
+    if (!tsdf || !packed || !bwd_packed || !enc_workspace_fwd || !planes_nhwc || !outs || !douts || !grads ||
+        !workspace)
+        return -1;
+    head_present &= 15;
+    if (n_params != param_offsets(head_present).total) return -2;
+    if (workspace_bytes < giga_backward_workspace_bytes(B, N, M, head_present)) return -4;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    uint8_t* ws = static_cast<uint8_t*>(workspace);
+    const size_t gp_bytes = align_up((size_t)3 * B * RES * RES * CD * sizeof(float), 256);
+    float* gplanes = reinterpret_cast<float*>(ws);
+    uint8_t* gws = ws + gp_bytes;
+    float* scratch = reinterpret_cast<float*>(gws + enc_bwd_workspace(B).total);
+    if (hipMemsetAsync(gplanes, 0, gp_bytes, s) != hipSuccess) return -10;
+    if (hipMemsetAsync(grads, 0, n_params * sizeof(float), s) != hipSuccess) return -10;
+    const uint8_t* blob = static_cast<const uint8_t*>(packed);
+    const uint8_t* bblob = static_cast<const uint8_t*>(bwd_packed);
+    int rc = 0;
+    if ((head_present & 7) && N > 0) {
+        if (!p) return -1;
+        rc |= launch_decoder_backward(static_cast<const float*>(planes_nhwc), p, blob, bblob, head_present & 7, outs,
+                                      douts, gplanes, grads, head_present, scratch, B, N, s);
+    }
+    if ((head_present & 8) && M > 0 && p_tsdf) {
+        rc |= launch_decoder_backward(static_cast<const float*>(planes_nhwc), p_tsdf, blob, bblob, 8, outs, douts,
+                                      gplanes, grads, head_present, scratch, B, M, s);
+    }
+    rc |= launch_encoder_backward(tsdf, blob, bblob, static_cast<const uint8_t*>(enc_workspace_fwd), gplanes, gws,
+                                  grads, head_present, B, s);
+    return rc;
 }
 
 }  // extern "C"

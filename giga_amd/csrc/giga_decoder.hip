@@ -379,10 +379,12 @@ __global__ __launch_bounds__(256, 1) void decoder_f32_kernel(DecArgs a) {
                 }
                 {
                     const float4 A = W[(k++) * 64 + lane];
+                    const float one0 = hi ? 0.0f : 1.0f;       // aux MFMA 2: slots (1, 0)
 #pragma unroll
                     for (int t = 0; t < T; ++t) {
                         net[t] = mfma32(A.x, ax0[t], net[t]);
                         net[t] = mfma32(A.y, ax1[t], net[t]);
+                        net[t] = mfma32(A.z, one0, net[t]);
                     }
                 }
                 f32x16 c0;

@@ -1,0 +1,422 @@
+// Decoder backward (training path, fp32): gradients of every LocalDecoder parameter and of the feature
+// planes (reference: autograd through conv_onet/models/decoder.py:117-176, layers.py:39-47 and the epilogues
+// of models/__init__.py:111-124, driven by scripts/train_giga.py:198-211).
+//
+// decoder_bwd_kernel, per 32-point tile and head:
+//   1. recompute the forward chain (same fragments / MFMAs as decoder_f32_kernel), keeping the stream before
+//      every block (net_i') and every hidden activation (h_i) in registers;
+//   2. swap the LDS image to the TRANSPOSED matrices (backward blob) and run the gradient chain
+//         G = DN[i+1];  DH[i] = (W1_i^T G) * (h_i > 0);  DN[i] = G + (W0_i^T DH[i]) * (net_i' > 0);  dc += Wc_i^T DN[i]
+//      in the same transposed layout (lane = point, registers = features), so again no cross-lane traffic;
+//   3. write the (dY, X) pairs of every linear layer to HBM as [point][32] rows and scatter dc into the
+//      plane gradients with the bilinear weights (fp32 atomics, like aten's grid_sampler backward).
+// linear_wgrad_kernel then reduces dW = dY^T X and db = colsum(dY) for all layers of a head in ONE launch
+// (MFMA 32x32x2 over pairs of points, operands straight from HBM, one atomic per gradient element per block).
+#include "giga_args.h"
+#include "giga_dev.h"
+
+namespace giga {
+
+// per-head scratch arrays, each [P][32] fp32 (row = point, D-layout feature order restored to 0..31)
+//   0..5 DN[i]   6..10 DH[i]   11..15 XN[i]   16..20 XH[i]   21 XO   22 DO (cols >= out_dim zero)
+constexpr int DB_NARR = 23;
+// shared per call: C [P][96], PP [P][32] (cols 0..2 = p, rest zero)
+
+struct DecBwdArgs {
+    const float* planes;        // NHWC fp32 [3][B][40][40][32]
+    const float* p;             // [P][3]
+    const uint8_t* blob;        // forward blob (fp32 images)
+    const uint8_t* bwd_blob;    // backward blob (transposed matrices)
+    size_t head_off[NHEADS], bwd_off[NHEADS];
+    int head_id[NHEADS];
+    const float* out[NHEADS];   // forward outputs of the head (post-epilogue), needed for sigmoid / normalize backward
+    const float* dout[NHEADS];  // upstream gradients, same shapes
+    float* scratch[NHEADS];     // DB_NARR arrays of [P][32]
+    float* Cbuf; float* Pbuf;   // [P][96], [P][32]
+    float* gplanes;             // NHWC fp32 [3][B][40][40][32], accumulated with atomics
+    int nheads, B, N;
+    long long P;
+    int nbatch; float invN;
+};
+
+template <int CHUNKS>
+__device__ __forceinline__ void dma_image4(const uint8_t* src, uint8_t* lds_dst, int wave, int lane) {
+    for (int c = wave; c < CHUNKS; c += 4)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * FRAG + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(lds_dst + c * FRAG), 16, 0, 0);
+}
+
+// write a D-layout register image (lane = point n, registers = features drow(r,hi)) as row `g` of a [P][32] array
+__device__ __forceinline__ void store_rows(float* arr, long long g, int hi, const f32x16& v, bool ok) {
+    if (!ok) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(arr + g * 32 + 8 * q + 4 * hi) =
+            make_float4(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+__global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, hi = lane >> 5;
+    const float4* W = reinterpret_cast<const float4*>(smem);
+    const size_t plane_stride = (size_t)a.B * RES * RES * CD;
+
+    for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
+        // ---------------- gather (as decoder_f32_kernel), keep the bilinear footprints for the scatter --------
+        long long g = ((long long)batch * 4 + wave) * 32 + n;
+        const bool valid = g < a.P;
+        if (!valid) g = a.P - 1;
+        int b, rdummy;
+        split_scene(g, a.N, a.invN, b, rdummy);
+        const float px = a.p[3 * g + 0], py = a.p[3 * g + 1], pz = a.p[3 * g + 2];
+        const float nx = norm_coord(px), ny = norm_coord(py), nz = norm_coord(pz);
+        const float ax0 = hi ? py : px, ax1 = hi ? 1.0f : pz, ax2 = hi ? 0.0f : 1.0f;
+        Bilin bl[3];
+        bl[0] = bilin_setup(nx, nz); bl[1] = bilin_setup(nx, ny); bl[2] = bilin_setup(ny, nz);
+        float cf[48];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const float* base = a.planes + pl * plane_stride + (size_t)b * RES * RES * CD + 16 * hi;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v00 = *reinterpret_cast<const float4*>(base + (size_t)bl[pl].o00 * CD + 4 * q);
+                const float4 v01 = *reinterpret_cast<const float4*>(base + (size_t)bl[pl].o01 * CD + 4 * q);
+                const float4 v10 = *reinterpret_cast<const float4*>(base + (size_t)bl[pl].o10 * CD + 4 * q);
+                const float4 v11 = *reinterpret_cast<const float4*>(base + (size_t)bl[pl].o11 * CD + 4 * q);
+                cf[16 * pl + 4 * q + 0] = fmaf(v11.x, bl[pl].w11, fmaf(v10.x, bl[pl].w10, fmaf(v01.x, bl[pl].w01, v00.x * bl[pl].w00)));
+                cf[16 * pl + 4 * q + 1] = fmaf(v11.y, bl[pl].w11, fmaf(v10.y, bl[pl].w10, fmaf(v01.y, bl[pl].w01, v00.y * bl[pl].w00)));
+                cf[16 * pl + 4 * q + 2] = fmaf(v11.z, bl[pl].w11, fmaf(v10.z, bl[pl].w10, fmaf(v01.z, bl[pl].w01, v00.z * bl[pl].w00)));
+                cf[16 * pl + 4 * q + 3] = fmaf(v11.w, bl[pl].w11, fmaf(v10.w, bl[pl].w10, fmaf(v01.w, bl[pl].w01, v00.w * bl[pl].w00)));
+            }
+        }
+        // X of fc_c / fc_p: rows of C [P][96] (feature pl*32 + 16*hi + s) and PP [P][32]
+        if (valid) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(a.Cbuf + g * 96 + pl * 32 + 16 * hi + 4 * q) =
+                        make_float4(cf[16 * pl + 4 * q], cf[16 * pl + 4 * q + 1], cf[16 * pl + 4 * q + 2], cf[16 * pl + 4 * q + 3]);
+            if (hi == 0) {
+                float* pr = a.Pbuf + g * 32;
+                *reinterpret_cast<float4*>(pr) = make_float4(px, py, pz, 0.f);
+#pragma unroll
+                for (int q = 1; q < 8; ++q) *reinterpret_cast<float4*>(pr + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        f32x16 dc[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dc[pl][r] = 0.f;
+
+        for (int h = 0; h < a.nheads; ++h) {
+            float* S = a.scratch[h];
+            const size_t AS = (size_t)a.P * 32;                     // array stride
+            // ================= 1. forward recompute (fragment order of giga_pack.cpp::pack_head32) ==========
+            __syncthreads();
+            dma_image4<(int)(DEC32_BYTES / FRAG)>(a.blob + a.head_off[h], smem, wave, lane);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+            const float* ctab = reinterpret_cast<const float*>(smem + (size_t)DEC32_FRAGS * FRAG);
+            f32x16 netp[NBLK], hh[NBLK], net;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) net[r] = 0.f;
+            int k = 0;
+#pragma unroll
+            for (int blk = 0; blk < NBLK; ++blk) {
+#pragma unroll
+                for (int q = 0; q < 12; ++q) {
+                    const float4 A = W[(k++) * 64 + lane];
+                    net = mfma32(A.x, cf[4 * q + 0], net); net = mfma32(A.y, cf[4 * q + 1], net);
+                    net = mfma32(A.z, cf[4 * q + 2], net); net = mfma32(A.w, cf[4 * q + 3], net);
+                }
+                {
+                    const float4 A = W[(k++) * 64 + lane];
+                    net = mfma32(A.x, ax0, net); net = mfma32(A.y, ax1, net); net = mfma32(A.z, ax2, net);
+                }
+                netp[blk] = net;
+                f32x16 hcur;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(ctab + blk * 32 + 8 * q + 4 * hi);
+                    hcur[4 * q + 0] = v.x; hcur[4 * q + 1] = v.y; hcur[4 * q + 2] = v.z; hcur[4 * q + 3] = v.w;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 A = W[(k++) * 64 + lane];
+                    hcur = mfma32(A.x, relu(net[4 * q + 0]), hcur); hcur = mfma32(A.y, relu(net[4 * q + 1]), hcur);
+                    hcur = mfma32(A.z, relu(net[4 * q + 2]), hcur); hcur = mfma32(A.w, relu(net[4 * q + 3]), hcur);
+                }
+                hh[blk] = hcur;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 A = W[(k++) * 64 + lane];
+                    net = mfma32(A.x, relu(hcur[4 * q + 0]), net); net = mfma32(A.y, relu(hcur[4 * q + 1]), net);
+                    net = mfma32(A.z, relu(hcur[4 * q + 2]), net); net = mfma32(A.w, relu(hcur[4 * q + 3]), net);
+                }
+            }
+            {   // + fc_1 bias of the last block -> net5
+                const float4 A = W[(k++) * 64 + lane];
+                net = mfma32(A.y, ax1, net);
+            }
+            // X arrays of the weight-gradient GEMMs
+            {
+                f32x16 t;
+#pragma unroll
+                for (int blk = 0; blk < NBLK; ++blk) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t[r] = relu(netp[blk][r]);
+                    store_rows(S + (11 + blk) * AS, g, hi, t, valid);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t[r] = relu(hh[blk][r]);
+                    store_rows(S + (16 + blk) * AS, g, hi, t, valid);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = relu(net[r]);
+                store_rows(S + 21 * AS, g, hi, t, valid);
+            }
+            // ================= 2. epilogue backward: dO (<= 4 values, identical in both lane halves) ============
+            const int id = a.head_id[h];
+            float dO[4] = {0.f, 0.f, 0.f, 0.f};
+            if (id == 1) {          // rot = z / max(|z|, eps): dz = (dr - r (r.dr)) / |z|   (F.normalize backward)
+                const float4 r4 = *reinterpret_cast<const float4*>(a.out[h] + 4 * g);
+                const float4 d4 = *reinterpret_cast<const float4*>(a.dout[h] + 4 * g);
+                // |z| from the recomputed raw output would need fc_out; use r = z/|z| and z.r = |z|: recompute z below
+                dO[0] = d4.x; dO[1] = d4.y; dO[2] = d4.z; dO[3] = d4.w;
+                (void)r4;
+            } else {
+                float d = a.dout[h][g];
+                if (id == 0) { const float q = a.out[h][g]; d *= q * (1.0f - q); }      // sigmoid'
+                dO[0] = d;
+            }
+            // ================= 3. swap to the transposed image ====================================================
+            __syncthreads();
+            dma_image4<(int)(DECB_BYTES / FRAG)>(a.bwd_blob + a.bwd_off[h], smem, wave, lane);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+            const float* wout = reinterpret_cast<const float*>(smem + (size_t)DECB_FRAGS * FRAG);   // [4][32]
+            if (id == 1) {
+                // raw z = fc_out(relu(net5)) + b is needed for the normalize backward: z_o = sum_f Wout[o][f] relu(net5)[f] + b_o
+                // (this lane holds 16 of the 32 features; the other half lives in lane^32)
+                float z[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s = fmaf(wout[o * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi], relu(net[r]), s);
+                    s += __shfl_xor(s, 32);
+                    z[o] = s;
+                }
+                // bias of fc_out: forward C-table row 5 is gone from LDS; the caller passes post-normalize outputs,
+                // and r = z/|z| with |z| = z.r, so recover |z| from the bias-free part plus the known direction:
+                // z = zb + bias  =>  we instead read the bias from the forward blob in global memory
+                const float* fb = reinterpret_cast<const float*>(a.blob + a.head_off[h] + (size_t)DEC32_FRAGS * FRAG) + NBLK * 32;
+                const float4 r4 = *reinterpret_cast<const float4*>(a.out[h] + 4 * g);
+                float nrm2 = 0.f;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) { z[o] += fb[o]; nrm2 = fmaf(z[o], z[o], nrm2); }
+                const float inv = 1.0f / fmaxf(sqrtf(nrm2), 1e-12f);
+                const float rd = r4.x * dO[0] + r4.y * dO[1] + r4.z * dO[2] + r4.w * dO[3];
+                dO[0] = (dO[0] - r4.x * rd) * inv; dO[1] = (dO[1] - r4.y * rd) * inv;
+                dO[2] = (dO[2] - r4.z * rd) * inv; dO[3] = (dO[3] - r4.w * rd) * inv;
+            }
+            if (valid && hi == 0) {       // DO row: [dO0..3, 0...]
+                float* dr = S + 22 * AS + g * 32;
+                *reinterpret_cast<float4*>(dr) = make_float4(dO[0], dO[1], dO[2], dO[3]);
+#pragma unroll
+                for (int q = 1; q < 8; ++q) *reinterpret_cast<float4*>(dr + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            // DN[5] = (Wout^T dO) * (net5 > 0)
+            f32x16 G;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float v = wout[f] * dO[0] + wout[32 + f] * dO[1] + wout[64 + f] * dO[2] + wout[96 + f] * dO[3];
+                G[r] = net[r] > 0.f ? v : 0.f;
+            }
+            store_rows(S + 5 * AS, g, hi, G, valid);
+            // ================= 4. gradient chain (fragments: block b -> Wc^T 20b..20b+11, W0^T +12..15, W1^T +16..19) ====
+#pragma unroll
+            for (int blk = NBLK - 1; blk >= 0; --blk) {
+                const int kb = 20 * blk;
+                f32x16 dh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dh[r] = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                       // W1^T G
+                    const float4 A = W[(kb + 16 + q) * 64 + lane];
+                    dh = mfma32(A.x, G[4 * q + 0], dh); dh = mfma32(A.y, G[4 * q + 1], dh);
+                    dh = mfma32(A.z, G[4 * q + 2], dh); dh = mfma32(A.w, G[4 * q + 3], dh);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dh[r] = hh[blk][r] > 0.f ? dh[r] : 0.f;
+                store_rows(S + (6 + blk) * AS, g, hi, dh, valid);
+                f32x16 dn;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dn[r] = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                       // W0^T DH
+                    const float4 A = W[(kb + 12 + q) * 64 + lane];
+                    dn = mfma32(A.x, dh[4 * q + 0], dn); dn = mfma32(A.y, dh[4 * q + 1], dn);
+                    dn = mfma32(A.z, dh[4 * q + 2], dn); dn = mfma32(A.w, dh[4 * q + 3], dn);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) G[r] += netp[blk][r] > 0.f ? dn[r] : 0.f;     // DN[blk]
+                store_rows(S + blk * AS, g, hi, G, valid);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)                      // dc += Wc^T DN[blk]
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 A = W[(kb + 4 * pl + q) * 64 + lane];
+                        dc[pl] = mfma32(A.x, G[4 * q + 0], dc[pl]); dc[pl] = mfma32(A.y, G[4 * q + 1], dc[pl]);
+                        dc[pl] = mfma32(A.z, G[4 * q + 2], dc[pl]); dc[pl] = mfma32(A.w, G[4 * q + 3], dc[pl]);
+                    }
+            }
+        }
+        // ---------------- scatter dc into the plane gradients (sample_plane_feature backward) ------------------
+        if (valid) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                float* gb = a.gplanes + pl * plane_stride + (size_t)b * RES * RES * CD;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const float v = dc[pl][r];
+                    atomicAdd(gb + (size_t)bl[pl].o00 * CD + c, v * bl[pl].w00);
+                    atomicAdd(gb + (size_t)bl[pl].o01 * CD + c, v * bl[pl].w01);
+                    atomicAdd(gb + (size_t)bl[pl].o10 * CD + c, v * bl[pl].w10);
+                    atomicAdd(gb + (size_t)bl[pl].o11 * CD + c, v * bl[pl].w11);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------- batched dW = dY^T X, db = colsum(dY) ----------------------------------------
+struct LinProblem {
+    const float* R;      // dY  [P][32]
+    const float* C;      // X   [P][ncol]
+    float* dW;           // (mvalid x nvalid) row-major with row stride sM
+    float* db;           // mvalid entries (may be null)
+    int ncol, sM, mvalid, nvalid;
+};
+constexpr int LIN_MAX = 20;
+struct LinArgs { LinProblem pr[LIN_MAX]; int nprob; long long P; int pts_per_block; int ksplit; int nb_total; int nb_start[LIN_MAX + 1]; };
+
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(LinArgs a) {
+    __shared__ float red[3][64][17];
+    __shared__ float bred[4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, hi = lane >> 5;
+    const int blk = blockIdx.x % a.nb_total, ks = blockIdx.x / a.nb_total;
+    int pi = 0;
+    while (blk >= a.nb_start[pi + 1]) ++pi;
+    const LinProblem& pr = a.pr[pi];
+    const int nb = blk - a.nb_start[pi];                       // 32-column block of X
+    const long long p0 = (long long)ks * a.pts_per_block;
+    long long p1 = p0 + a.pts_per_block;
+    if (p1 > a.P) p1 = a.P;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
+    for (long long base = p0 + 8 * wave; base < p1; base += 32) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long long p = base + 2 * s + hi;
+            av[s] = p < p1 ? pr.R[p * 32 + i] : 0.f;
+            bv[s] = p < p1 ? pr.C[p * pr.ncol + nb * 32 + i] : 0.f;
+            bsum += av[s];
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma32(av[s], bv[s], acc);
+    }
+    bsum += __shfl_xor(bsum, 32);
+    if (hi == 0) bred[wave][i] = bsum;
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][lane][r] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[r] + red[0][lane][r] + red[1][lane][r] + red[2][lane][r];
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * hi, nn = nb * 32 + i;
+            if (m < pr.mvalid && nn < pr.nvalid) atomicAdd(pr.dW + (size_t)m * pr.sM + nn, v);
+        }
+        if (nb == 0 && pr.db && hi == 0 && i < pr.mvalid)
+            atomicAdd(pr.db + i, bred[0][i] + bred[1][i] + bred[2][i] + bred[3][i]);
+    }
+}
+
+// ------------------------------- launcher ------------------------------------------------------------------------
+size_t dec_bwd_scratch_floats(long long P, int nheads) { return (size_t)P * 32 * DB_NARR * nheads + (size_t)P * (96 + 32); }
+
+int launch_decoder_backward(const float* planes, const float* p, const uint8_t* blob, const uint8_t* bwd_blob,
+                            int head_mask, const float* const* outs, const float* const* douts, float* gplanes,
+                            float* grads, int head_present, float* scratch, int B, int N, hipStream_t s) {
+    const long long P = (long long)B * N;
+    if (P <= 0 || (head_mask & 15) == 0) return 0;
+    const PackOff ko = pack_offsets();
+    const BwdPackOff bo = bwd_pack_offsets();
+    const ParamOff po = param_offsets(head_present);
+    DecBwdArgs a{};
+    a.planes = planes; a.p = p; a.blob = blob; a.bwd_blob = bwd_blob; a.gplanes = gplanes;
+    a.B = B; a.N = N; a.P = P; a.invN = 1.0f / (float)N;
+    float* sc = scratch;
+    for (int h = 0; h < NHEADS; ++h) {
+        if (!(head_mask >> h & 1)) continue;
+        a.head_id[a.nheads] = h; a.head_off[a.nheads] = ko.dec32[h]; a.bwd_off[a.nheads] = bo.dec[h];
+        a.out[a.nheads] = outs[h]; a.dout[a.nheads] = douts[h];
+        a.scratch[a.nheads] = sc; sc += (size_t)P * 32 * DB_NARR;
+        ++a.nheads;
+    }
+    a.Cbuf = sc; a.Pbuf = sc + (size_t)P * 96;
+    const long long tiles = (P + 31) / 32;
+    a.nbatch = (int)((tiles + 3) / 4);
+    const int grid = a.nbatch < 256 ? a.nbatch : 256;
+    const size_t lds = DEC32_BYTES > DECB_BYTES ? DEC32_BYTES : DECB_BYTES;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    hipLaunchKernelGGL(decoder_bwd_kernel, dim3(grid), dim3(256), lds, s, a);
+    // weight / bias gradients: one launch per head
+    for (int hh = 0; hh < a.nheads; ++hh) {
+        const int h = a.head_id[hh];
+        const HeadParamOff& o = po.head[h];
+        const size_t AS = (size_t)P * 32;
+        float* S = a.scratch[hh];
+        LinArgs L{};
+        auto add = [&](const float* R, const float* C, int ncol, float* dW, float* db, int sM, int mvalid, int nvalid) {
+            LinProblem& q = L.pr[L.nprob];
+            q.R = R; q.C = C; q.ncol = ncol; q.dW = dW; q.db = db; q.sM = sM; q.mvalid = mvalid; q.nvalid = nvalid;
+            L.nb_start[L.nprob] = L.nb_total;
+            L.nb_total += ncol / 32;
+            ++L.nprob;
+        };
+        add(S + 22 * AS, S + 21 * AS, 32, grads + o.out_w, grads + o.out_b, 32, HEAD_OUT[h], 32);       // fc_out
+        for (int i = 0; i < NBLK; ++i) {
+            add(S + (i + 1) * AS, S + (16 + i) * AS, 32, grads + o.fc1_w[i], grads + o.fc1_b[i], 32, 32, 32);   // fc_1: DN[i+1], XH[i]
+            add(S + (6 + i) * AS, S + (11 + i) * AS, 32, grads + o.fc0_w[i], grads + o.fc0_b[i], 32, 32, 32);   // fc_0: DH[i], XN[i]
+            add(S + i * AS, a.Cbuf, 96, grads + o.fc_c_w[i], grads + o.fc_c_b[i], 96, 32, 96);                   // fc_c: DN[i], C
+        }
+        add(S + 0 * AS, a.Pbuf, 32, grads + o.fc_p_w, grads + o.fc_p_b, 3, 32, 3);                             // fc_p: DN[0], p
+        L.nb_start[L.nprob] = L.nb_total;
+        L.P = P;
+        int ksplit = 1024 / L.nb_total;
+        if (ksplit < 1) ksplit = 1;
+        long long ppb = (P + ksplit - 1) / ksplit;
+        ppb = (ppb + 31) / 32 * 32;
+        L.pts_per_block = (int)ppb;
+        ksplit = (int)((P + ppb - 1) / ppb);
+        L.ksplit = ksplit;
+        hipLaunchKernelGGL(linear_wgrad_kernel, dim3(L.nb_total * ksplit), dim3(256), 0, s, L);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
+}  // namespace giga

@@ -23,6 +23,15 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// 16x16 MFMA shapes: D row = 4*(lane>>4) + reg, column = lane&15; A[i=lane&15][k-slot lane>>4], B[k-slot][j=lane&15]
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v mfma32_16(float a, float b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4v mfma16_16(half8 a, half8 b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float relu(float x) { return __builtin_fmaxf(x, 0.f); }
 
 // round-to-nearest f16 then relu (== relu then round) of D registers 8c..8c+7 -> B operand of the next

@@ -7,6 +7,7 @@
 // 32x40^3 feature volume (8.2 MB/scene in the reference) is never written to memory.  Kernel 2
 // (conv16_kernel) is one LDS-staged implicit-GEMM convolution used for every U-Net layer.
 #include "giga_dev.h"
+#include "giga_conv16.h"
 
 namespace giga {
 
@@ -25,13 +26,6 @@ namespace giga {
 //                                 HBM, summed in fixed order by plane_finalize_kernel (no atomics).
 // Plane pixel (H,W) conventions (common.py:246-251,303-318): xz -> [iz][ix], xy -> [iy][ix], yz -> [iz][iy].
 // ====================================================================================================
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4v mfma32_16(float a, float b, f32x4v c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4v mfma16_16(half8 a, half8 b, f32x4v c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
 
 constexpr int CI_ROWSTRIDE = 56;                  // floats per LDS row (>= 42; 56 mod 32 = 24 spreads the rows over banks)
 constexpr int CI_SLICE = 42 * CI_ROWSTRIDE;       // one haloed slice
@@ -195,237 +189,6 @@ __global__ void plane_finalize_kernel(const float* __restrict__ yz_partial, TOut
     float s = 0.f;
     for (int k = 0; k < nslab; ++k) s += yz_partial[(size_t)k * per + i];
     planes[2 * per + i] = (TOut)(s * (1.0f / RES));
-}
-
-// ====================================================================================================
-// U-Net convolutions: implicit GEMM on 16x16 MFMA tiles, NHWC activations, wave-independent units.
-//   D[pixel][cout] = sum_{tap,cin} X[pixel+tap][cin] * W[cout][cin][tap]
-//   A operand = 16 pixels (a 4x4 block = 2x2 quads of 2x2 pixels; D row = 4*quad + pos, so a lane's 4
-//   D registers are one complete quad and the fused 2x2 max-pool is in-lane), B operand = packed
-//   weight fragments streamed from L2 (identical for every wave).
-//   Persistent workgroups of CONV_NW waves, one per CU.  A workgroup owns one WEIGHT GROUP (NB*16 output
-//   channels of one sub-output) whose fragments stay resident in LDS for the whole kernel (<= 72 KiB,
-//   filled once by LDS-DMA), so B operands are ds_read_b128 at LDS bandwidth instead of 1 KiB per
-//   MFMA-quad per wave through the 64 B/clk L1.  Work unit = (image, 4x4 pixel tile); EVERY WAVE IS
-//   INDEPENDENT after the weight load: it stages the haloed 6x6 input patch of its tile in a
-//   wave-private LDS region (32 channels at a time, 16-byte pad per pixel), runs the MFMA loop and
-//   writes its outputs.  No workgroup barrier in the loop, no tile->wave quantisation; units are
-//   strided over all waves of the weight group so each SIMD carries the same number of MFMAs.  The
-//   next 32-channel chunk is prefetched into registers while the current one is in the MFMA loop.
-//   KIND: CONV3 (3x3, pad 1, +bias, ReLU, optional pool), UPCONV (ConvTranspose2d k=2 s=2 as four
-//   1x1 GEMMs scattered to (2y+dy, 2x+dx)), CONV1 (1x1, +bias, no activation).
-// ====================================================================================================
-struct ConvArgs {
-    const void* in0; const void* in1;    // NHWC sources (cat order in0 then in1), C0 / C1 channels
-    const uint8_t* w;                    // packed fragments for this precision
-    const float* bias;
-    void* out;                           // NHWC [img][H'][W'][COUT]
-    void* out_pool;                      // NHWC [img][H/2][W/2][COUT] (POOL only)
-    float* out_nchw;                     // optional fp32 NCHW copy (CONV1 only)
-    int nimg;
-};
-
-constexpr int CONV_NW = 12;       // waves per workgroup (3 per SIMD; VGPR use is < 80)
-
-template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL>
-__global__ __launch_bounds__(CONV_NW * 64) void conv16_kernel(ConvArgs a) {
-    constexpr int CIN = C0 + C1;
-    constexpr int TAPS = KIND == CONV3 ? 9 : 1;
-    constexpr int HALO = KIND == CONV3 ? 1 : 0;
-    constexpr int NCHUNK = CIN / 32;
-    constexpr int ES = (int)sizeof(T);
-    constexpr int PS = 32 * ES + 16;                  // LDS pixel stride in bytes
-    constexpr int LW = 4 + 2 * HALO, NPIX = LW * LW;  // haloed patch
-    constexpr int VPP = 32 * ES / 16;                 // 16-byte vectors per pixel per chunk
-    constexpr int NVEC = NPIX * VPP;                  // vectors per chunk
-    constexpr int NLD = (NVEC + 63) / 64;             // staging loads per lane
-    constexpr int REGION = (NPIX * PS + 15) / 16 * 16;
-    constexpr int TX = (W + 3) / 4, TY = (H + 3) / 4;
-    constexpr int NSUB = KIND == UPCONV ? 4 : 1;
-    constexpr int NBT = COUT / 16;                    // 16-channel blocks per sub-output
-    constexpr int CG = NBT / NB;                      // channel groups per sub-output
-    constexpr int NGRP = NSUB * CG;                   // weight groups (one per workgroup)
-    constexpr int KGC = ES == 4 ? 2 : 1;              // k-groups per 32-channel chunk (16 / 32 channels)
-    constexpr int KGT = CIN / 32 * KGC;
-    constexpr int WFRAGS = NB * TAPS * KGT;           // weight fragments resident in LDS
-    static_assert(NBT % NB == 0, "cout grouping");
-
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 15, g = lane >> 4;
-    uint8_t* region = smem + (size_t)WFRAGS * FRAG + wave * REGION;
-
-    // ---- this workgroup's weight group -> LDS, once (LDS-DMA, 1 KiB per wave-instruction) ----------
-    const int grp = blockIdx.x % NGRP, wg_in_grp = blockIdx.x / NGRP, wgs_per_grp = gridDim.x / NGRP;
-    const int sub = grp / CG, nb0 = (grp % CG) * NB;
-    {
-        // fragments of (sub, nb0 .. nb0+NB-1) are contiguous in the packed blob: [sub][nb][tap][kg]
-        const uint8_t* wsrc = a.w + (size_t)(sub * NBT + nb0) * TAPS * KGT * FRAG;
-        for (int c = wave; c < WFRAGS; c += CONV_NW)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(wsrc + (size_t)c * FRAG + lane * 16),
-                (__attribute__((address_space(3))) void*)(smem + c * FRAG), 16, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    const uint4* wl = reinterpret_cast<const uint4*>(smem);
-
-    const int nwaves = wgs_per_grp * CONV_NW;
-    const int units = a.nimg * TY * TX;
-
-    // A geometry: row i = lane&15 : quad = i>>2 (qy = quad>>1, qx = quad&1), pos = i&3 (dy = pos>>1, dx = pos&1)
-    const int ay = 2 * (j >> 3) + ((j >> 1) & 1), ax = 2 * ((j >> 2) & 1) + (j & 1);
-    const int a_off = (ay * LW + ax) * PS + g * 16;
-
-    // staging geometry of this lane's NLD vectors (fixed for the whole kernel)
-    int st_lds[NLD], st_ly[NLD], st_lx[NLD], st_v[NLD];
-#pragma unroll
-    for (int q = 0; q < NLD; ++q) {
-        const int i = lane + 64 * q;
-        const int pix = i / VPP;
-        st_v[q] = i % VPP;
-        st_ly[q] = pix / LW; st_lx[q] = pix % LW;
-        st_lds[q] = i < NVEC ? pix * PS + st_v[q] * 16 : -1;
-    }
-    auto unit_coords = [&](int u, int& tx, int& ty, int& img) {
-        tx = u % TX; ty = (u / TX) % TY; img = u / (TX * TY);
-    };
-    uint4 stg[NLD];
-    auto issue_loads = [&](int u, int cc) {
-        int tx, ty, img;
-        unit_coords(u, tx, ty, img);
-        const T* src = reinterpret_cast<const T*>(cc * 32 < C0 ? a.in0 : a.in1);
-        const int csrc = cc * 32 < C0 ? C0 : C1;
-        const int coff = cc * 32 < C0 ? cc * 32 : cc * 32 - C0;
-#pragma unroll
-        for (int q = 0; q < NLD; ++q) {
-            const int gy = 4 * ty + st_ly[q] - HALO, gx = 4 * tx + st_lx[q] - HALO;
-            uint4 val = make_uint4(0, 0, 0, 0);
-            if (st_lds[q] >= 0 && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                val = *reinterpret_cast<const uint4*>(src + ((size_t)(img * H + gy) * W + gx) * csrc + coff +
-                                                      st_v[q] * (16 / ES));
-            stg[q] = val;
-        }
-    };
-
-    // global wave index = wave * (#workgroups) + workgroup: remainder units spread over all CUs/SIMDs
-    int u = wave * wgs_per_grp + wg_in_grp;
-    if (u >= units) return;
-    int cc = 0;
-    issue_loads(u, 0);
-    constexpr int NACC = NB == 1 ? 2 : 1;          // independent accumulator chains per channel block
-    f32x4v acc[NB][NACC];
-#pragma unroll
-    for (int n = 0; n < NB; ++n)
-#pragma unroll
-        for (int c = 0; c < NACC; ++c) acc[n][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
-
-    while (true) {
-        // ---- registers -> wave-private LDS patch (DS ops of one wave execute in order) -----------
-#pragma unroll
-        for (int q = 0; q < NLD; ++q)
-            if (st_lds[q] >= 0) *reinterpret_cast<uint4*>(region + st_lds[q]) = stg[q];
-        // ---- prefetch the next chunk / next unit ---------------------------------------------------
-        int un = u, ccn = cc + 1;
-        if (ccn == NCHUNK) { un = u + nwaves; ccn = 0; }
-        const bool more = un < units;
-        if (more) issue_loads(un, ccn);
-        // ---- MFMA over taps x k-groups of this chunk: A from the patch, B from the resident weights --
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int toff = ((tap / 3) * LW + (tap % 3)) * PS;
-#pragma unroll
-            for (int kg = 0; kg < KGC; ++kg) {
-                const uint4 av = *reinterpret_cast<const uint4*>(region + a_off + toff + kg * 64);
-                uint4 bw[NB];
-#pragma unroll
-                for (int n = 0; n < NB; ++n) bw[n] = wl[((n * TAPS + tap) * KGT + cc * KGC + kg) * 64 + lane];
-                if constexpr (ES == 2) {
-#pragma unroll
-                    for (int n = 0; n < NB; ++n)
-                        acc[n][kg & (NACC - 1)] = mfma16_16(__builtin_bit_cast(half8, av), __builtin_bit_cast(half8, bw[n]),
-                                                            acc[n][kg & (NACC - 1)]);
-                } else {
-                    // 16x16x4 f32: 32-cycle issue, 40-cycle dependent latency -> alternate accumulators
-                    const f32x4v A = __builtin_bit_cast(f32x4v, av);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int n = 0; n < NB; ++n)
-                            acc[n][e & (NACC - 1)] = mfma32_16(A[e], __builtin_bit_cast(f32x4v, bw[n])[e], acc[n][e & (NACC - 1)]);
-                }
-            }
-        }
-        // ---- epilogue after the last chunk: lane holds cout j of quad g (4 pixels) ------------------
-        if (cc == NCHUNK - 1) {
-            int tx, ty, img;
-            unit_coords(u, tx, ty, img);
-            T* out = reinterpret_cast<T*>(a.out);
-            const int qy = 4 * ty + 2 * (g >> 1), qx = 4 * tx + 2 * (g & 1);
-            const bool qok = qy < H && qx < W;             // H, W even: a quad is in or out as a whole
-#pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                const int co = (nb0 + n) * 16 + j;
-                const float bv = a.bias[co];
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float sacc = acc[n][0][e];
-                    if (NACC == 2) sacc += acc[n][NACC - 1][e];
-                    v[e] = sacc + bv;
-                    if (KIND == CONV3) v[e] = relu(v[e]);
-                    acc[n][0][e] = 0.f;
-                    acc[n][NACC - 1][e] = 0.f;
-                }
-                if (qok) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int y = qy + (e >> 1), x = qx + (e & 1);
-                        if (KIND == UPCONV) {
-                            const int oy = 2 * y + (sub >> 1), ox = 2 * x + (sub & 1);
-                            out[((size_t)(img * 2 * H + oy) * (2 * W) + ox) * COUT + co] = (T)v[e];
-                        } else {
-                            out[((size_t)(img * H + y) * W + x) * COUT + co] = (T)v[e];
-                            if (KIND == CONV1 && a.out_nchw)
-                                a.out_nchw[((size_t)img * COUT + co) * H * W + y * W + x] = v[e];
-                        }
-                    }
-                    if (POOL) {
-                        const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                        T* op = reinterpret_cast<T*>(a.out_pool);
-                        op[((size_t)(img * (H / 2) + qy / 2) * (W / 2) + qx / 2) * COUT + co] = (T)mx;
-                    }
-                }
-            }
-        }
-        if (!more) break;
-        u = un; cc = ccn;
-    }
-}
-
-template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL>
-static int launch_conv(const ConvArgs& a, hipStream_t s) {
-    constexpr int HALO = KIND == CONV3 ? 1 : 0;
-    constexpr int TAPS = KIND == CONV3 ? 9 : 1;
-    constexpr int ES = (int)sizeof(T);
-    constexpr int PS = 32 * ES + 16;
-    constexpr int NPIX = (4 + 2 * HALO) * (4 + 2 * HALO);
-    constexpr int REGION = (NPIX * PS + 15) / 16 * 16;
-    constexpr int NSUB = KIND == UPCONV ? 4 : 1;
-    constexpr int NGRP = NSUB * (COUT / 16 / NB);
-    constexpr int KGT = (C0 + C1) / 32 * (ES == 4 ? 2 : 1);
-    constexpr size_t lds = (size_t)NB * TAPS * KGT * FRAG + CONV_NW * REGION;
-    static_assert(lds <= 160 * 1024, "LDS budget");
-    static_assert(256 % NGRP == 0, "weight groups must divide the CU count");
-    const int units = a.nimg * ((H + 3) / 4) * ((W + 3) / 4);        // per weight group
-    int wgs = (units + CONV_NW - 1) / CONV_NW;                        // workgroups per weight group
-    if (wgs > 256 / NGRP) wgs = 256 / NGRP;                           // one persistent workgroup per CU
-    auto kern = conv16_kernel<T, KIND, C0, C1, COUT, H, W, NB, POOL>;
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(wgs * NGRP), dim3(CONV_NW * 64), lds, s, a);
-    return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
 // ----------------------------------------------------------------------------------------------------

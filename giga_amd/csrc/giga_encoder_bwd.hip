@@ -1,0 +1,414 @@
+// Encoder backward (training path, fp32): gradients of every LocalVoxelEncoder / UNet parameter
+// (reference: autograd through ConvONets/encoder/voxels.py:89-121 and encoder/unet.py:225-239, driven by
+// scripts/train_giga.py:198-211).
+//   * data gradients of the convolutions reuse conv16_kernel with flipped/transposed weight fragments
+//     (backward blob, giga_pack.cpp::pack_conv_dgrad); ConvTranspose2d's data gradient is the DOWN kind
+//   * weight gradients: conv_wgrad_kernel, an MFMA reduction over pixels D[co][ci] += dY[p][co] * X[p+tap][ci]
+//   * ReLU / max-pool / concat backward: small elementwise kernels on the saved NHWC activations
+//   * conv_in: recompute the pre-activation (never stored by the forward), mask, and reduce
+//     dW[c][tap] = sum_voxels dF[c][v] * tsdf[v + tap] on the MFMA as well.
+// Weight/bias gradients are ACCUMULATED into the flat fp32 gradient buffer (reference state-dict order) with
+// fp32 atomics (summation order is not fixed, as with PyTorch's own CUDA/HIP backward kernels).
+#include "giga_conv16.h"
+
+namespace giga {
+
+// ------------------------------- elementwise ------------------------------------------------------------
+__global__ void relu_bwd_kernel(float4* __restrict__ g, const float4* __restrict__ out, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = g[i];
+    const float4 o = out[i];
+    v.x = o.x > 0.f ? v.x : 0.f; v.y = o.y > 0.f ? v.y : 0.f;
+    v.z = o.z > 0.f ? v.z : 0.f; v.w = o.w > 0.f ? v.w : 0.f;
+    g[i] = v;
+}
+
+// dS[img][y][x][c] = dCat[img][y][x][coff + c] (skip half of the concat gradient, channel stride cs)
+//                  + (S[y][x][c] == Q[y/2][x/2][c] ? dQ[y/2][x/2][c] : 0)      (MaxPool2d(2,2) backward)
+__global__ void pool_bwd_add_kernel(float* __restrict__ dS, const float* __restrict__ dcat, int cs, int coff,
+                                    const float* __restrict__ dQ, const float* __restrict__ S,
+                                    const float* __restrict__ Q, int nimg, int H, int W, int C) {
+    const size_t total = (size_t)nimg * H * W * C;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const size_t pix = i / C;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const size_t img = pix / ((size_t)W * H);
+    const size_t qi = ((img * (H / 2) + y / 2) * (W / 2) + x / 2) * C + c;
+    const float s = S[i];
+    dS[i] = dcat[pix * cs + coff + c] + (s == Q[qi] ? dQ[qi] : 0.f);
+}
+
+// db[c] += sum over rows of g[row * cs + coff + c]
+__global__ void colsum_kernel(const float* __restrict__ g, int cs, int coff, int C, size_t rows,
+                              float* __restrict__ db) {
+    __shared__ float part[256];
+    const int c = threadIdx.x % C, lane_row = threadIdx.x / C, rpb = blockDim.x / C;   // C divides blockDim
+    float s = 0.f;
+    for (size_t r = (size_t)blockIdx.x * rpb + lane_row; r < rows; r += (size_t)gridDim.x * rpb)
+        s += g[r * cs + coff + c];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (lane_row == 0) {
+        for (int k = 1; k < rpb; ++k) s += part[k * C + c];
+        atomicAdd(db + c, s);
+    }
+}
+
+// ------------------------------- weight gradient (MFMA reduction over pixels) ----------------------------
+// D[m][n] += sum_p R[p][m] * Cc[map(p, tap)][n]   on v_mfma_f32_32x32x2_f32 (2 pixels per MFMA).
+//   CONV3 / CONV1 : R = dPre (m = co), Cc = layer input at the tap-shifted pixel (n = ci, zero outside)
+//   UPCONV        : R = layer input (m = ci), Cc = dU at (2y+dy, 2x+dx) (n = co)
+// Operands come straight from HBM/L2 (32 lanes x 4 B contiguous per pixel), no LDS staging: one MFMA
+// (64 cycles) per two 128-byte loads.  Block = (tap, 32x32 block of dW, pixel range); its 4 waves split
+// the range, partials are summed through LDS and added to the gradient buffer with one atomic per element.
+struct WgradArgs {
+    const float* R; int csR, coR;                 // row tensor, channel stride, first channel
+    const float* C0p; const float* C1p;           // column tensor(s) (concat order), channel strides / split
+    int csC0, csC1, nC0;                          // columns n < nC0 come from C0p, the rest from C1p
+    float* dW; int sM, sN, sT;                    // dW[m*sM + n*sN + tap*sT]
+    int kind, taps, Mb, Nb;                       // 32-row / 32-column blocks
+    int nimg, H, W;                               // base pixel grid (the R tensor's)
+    unsigned mHW, mW;                             // magic multipliers for / (H*W) and / W
+    long long npix; int pix_per_block;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    __shared__ float red[3][64][17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, hi = lane >> 5;
+    int b = blockIdx.x;
+    const int nb = b % a.Nb; b /= a.Nb;
+    const int mb = b % a.Mb; b /= a.Mb;
+    const int tap = b % a.taps; b /= a.taps;
+    const long long p0 = (long long)b * a.pix_per_block;
+    long long p1 = p0 + a.pix_per_block;
+    if (p1 > a.npix) p1 = a.npix;
+    const int n0 = nb * 32;
+    const float* Cc = n0 < a.nC0 ? a.C0p : a.C1p;
+    const int csC = n0 < a.nC0 ? a.csC0 : a.csC1;
+    const int cn = (n0 < a.nC0 ? n0 : n0 - a.nC0) + i;
+    const int HW = a.H * a.W;
+    const int ky = a.kind == CONV3 ? tap / 3 - 1 : 0, kx = a.kind == CONV3 ? tap % 3 - 1 : 0;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // this wave's share: pixels p0 + 8*wave + 32*k + {0..7}; lane half hi takes the odd pixel of each pair
+    for (long long base = p0 + 8 * wave; base < p1; base += 32) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const long long p = base + 2 * s + hi;
+            float x = 0.f, y = 0.f;
+            if (p < p1) {
+                x = a.R[(size_t)p * a.csR + a.coR + mb * 32 + i];
+                const int img = div_magic((int)p, a.mHW), rem = (int)p - img * HW;
+                const int py = div_magic(rem, a.mW), px = rem - py * a.W;
+                if (a.kind == UPCONV) {
+                    const size_t q = ((size_t)img * 2 * a.H + 2 * py + (tap >> 1)) * (2 * a.W) + 2 * px + (tap & 1);
+                    y = Cc[q * csC + cn];
+                } else {
+                    const int qy = py + ky, qx = px + kx;
+                    if (qy >= 0 && qy < a.H && qx >= 0 && qx < a.W)
+                        y = Cc[((size_t)img * HW + qy * a.W + qx) * csC + cn];
+                }
+            }
+            av[s] = x; bv[s] = y;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma32(av[s], bv[s], acc);
+    }
+    // D: lane (n = lane&31, hi), reg r <-> row m = drow(r, hi), column n
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][lane][r] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[r] + red[0][lane][r] + red[1][lane][r] + red[2][lane][r];
+            const int m = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, n = n0 + i;
+            atomicAdd(a.dW + (size_t)m * a.sM + (size_t)n * a.sN + (size_t)tap * a.sT, v);
+        }
+    }
+}
+
+static int launch_wgrad(WgradArgs a, hipStream_t s) {
+    a.npix = (long long)a.nimg * a.H * a.W;
+    a.mHW = (unsigned)((0x100000000ULL + (unsigned)(a.H * a.W) - 1) / (unsigned)(a.H * a.W));
+    a.mW = (unsigned)((0x100000000ULL + (unsigned)a.W - 1) / (unsigned)a.W);
+    const int blocks_wn = a.taps * a.Mb * a.Nb;
+    int ksplit = 2048 / blocks_wn;
+    if (ksplit < 1) ksplit = 1;
+    long long ppb = (a.npix + ksplit - 1) / ksplit;
+    ppb = (ppb + 31) / 32 * 32;
+    if (ppb < 32) ppb = 32;
+    a.pix_per_block = (int)ppb;
+    ksplit = (int)((a.npix + ppb - 1) / ppb);
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(blocks_wn * ksplit), dim3(256), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
+// ------------------------------- conv_in backward ----------------------------------------------------------
+// Same decomposition as convin_project_kernel (8 waves = 4 iy-groups x 2 channel halves, 16-voxel x 16-channel
+// units).  Per unit: recompute pre = conv_in(x) + b (7 MFMAs), dF = (pre > 0) * (gxz + gxy + gyz) / 40, then
+// dW^T[tap][ch] += X^T[tap][voxel] * dF[voxel][ch] as 2 tap halves x 4 k-steps = 8 more MFMAs (the D registers
+// of the forward unit ARE the B operand of these).  dW / db are reduced with atomics at the end.
+constexpr int CB_ROWSTRIDE = 56;
+constexpr int CB_SLICE = 42 * CB_ROWSTRIDE;
+constexpr size_t CB_LDS_BYTES = 4 * CB_SLICE * sizeof(float);
+
+__global__ __launch_bounds__(512) void convin_bwd_kernel(const float* __restrict__ tsdf, const float* __restrict__ wpk,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ gplanes,   // [3][B][40][40][32]
+                                                         float* __restrict__ dW,              // [32][27]
+                                                         float* __restrict__ db,              // [32]
+                                                         int B, int SX) {
+    extern __shared__ __attribute__((aligned(16))) float slices[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int chh = wave & 1, grp = wave >> 1;
+    const int slab = blockIdx.x, b = blockIdx.y;
+    const int ix0 = slab * SX;
+    const float* vol = tsdf + (size_t)b * RES * RES * RES;
+    for (int i = tid; i < 4 * CB_SLICE; i += blockDim.x) slices[i] = 0.f;
+    float wreg[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) wreg[s] = wpk[(chh * 7 + s) * 64 + lane];
+    const int ch = 16 * chh + j;
+    const float bn = bias[ch];
+    __syncthreads();
+    auto load_slice = [&](int ix) {
+        float* dst = slices + ((ix + 1) & 3) * CB_SLICE;
+        const bool in = ix >= 0 && ix < RES;
+        for (int i = tid; i < RES * RES; i += blockDim.x)
+            dst[(i / RES + 1) * CB_ROWSTRIDE + (i % RES + 1)] = in ? vol[(size_t)ix * RES * RES + i] : 0.f;
+    };
+    load_slice(ix0 - 1); load_slice(ix0);
+    const size_t img_stride = (size_t)RES * RES * CD;
+    const float* gxz = gplanes + ((size_t)0 * B + b) * img_stride;
+    const float* gxy = gplanes + ((size_t)1 * B + b) * img_stride;
+    const float* gyz = gplanes + ((size_t)2 * B + b) * img_stride;
+    const float inv = 1.0f / RES;
+    // forward A operand: row i = lane&15 is voxel (iy_l = i>>3, iz_l = 4*((i>>2)&1) + (i&3)); k-slot g -> tap 4s+g
+    const int a_base = (grp * 10 + (j >> 3)) * CB_ROWSTRIDE + 4 * ((j >> 2) & 1) + (j & 3);
+    // backward A operand: row = tap (lane&15 + 16*th), k-slot g -> voxel row 4g + r of the unit
+    const int v_base = (grp * 10 + (g >> 1)) * CB_ROWSTRIDE + 4 * (g & 1);
+
+    f32x4v accw[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
+    float accb = 0.f;
+    for (int sx = 0; sx < SX; ++sx) {
+        const int ix = ix0 + sx;
+        __syncthreads();
+        load_slice(ix + 1);
+        __syncthreads();
+        const int o[3] = {((ix + 0) & 3) * CB_SLICE, ((ix + 1) & 3) * CB_SLICE, ((ix + 2) & 3) * CB_SLICE};
+        int aoff[7], toff[2];
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            int t = 4 * s + g;
+            t = t > 26 ? 26 : t;
+            const int dx = t / 9;
+            aoff[s] = a_base + ((t / 3) % 3) * CB_ROWSTRIDE + t % 3 + (dx == 0 ? o[0] : dx == 1 ? o[1] : o[2]);
+        }
+#pragma unroll
+        for (int th = 0; th < 2; ++th) {
+            int t = j + 16 * th;
+            t = t > 26 ? 26 : t;                  // rows >= 27 of dW^T are never written back
+            const int dx = t / 9;
+            toff[th] = v_base + ((t / 3) % 3) * CB_ROWSTRIDE + t % 3 + (dx == 0 ? o[0] : dx == 1 ? o[1] : o[2]);
+        }
+#pragma unroll 1
+        for (int ip = 0; ip < 5; ++ip) {
+#pragma unroll 1
+            for (int zg = 0; zg < 5; ++zg) {
+                const int uo = 2 * ip * CB_ROWSTRIDE + 8 * zg;
+                f32x4v d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 7; ++s) d = mfma32_16(slices[aoff[s] + uo], wreg[s], d);
+                // upstream gradient of the three axis means for this lane's 4 voxels (iz = 8zg + 4(g&1) + r)
+                const int iy = grp * 10 + 2 * ip + (g >> 1), izb = 8 * zg + 4 * (g & 1);
+                const float gy_ = gxy[((size_t)iy * RES + ix) * CD + ch];
+                f32x4v dF;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int iz = izb + r;
+                    const float gsum = gxz[((size_t)iz * RES + ix) * CD + ch] + gy_ +
+                                       gyz[((size_t)iz * RES + iy) * CD + ch];
+                    dF[r] = (d[r] + bn) > 0.f ? gsum * inv : 0.f;
+                    accb += dF[r];
+                }
+#pragma unroll
+                for (int th = 0; th < 2; ++th)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accw[th] = mfma32_16(slices[toff[th] + uo + r], dF[r], accw[th]);
+            }
+        }
+    }
+    // accw[th][r]: dW^T[tap = 16th + 4g + r][ch]
+#pragma unroll
+    for (int th = 0; th < 2; ++th)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tap = 16 * th + 4 * g + r;
+            if (tap < 27) atomicAdd(dW + ch * 27 + tap, accw[th][r]);
+        }
+    accb += __shfl_xor(accb, 16);
+    accb += __shfl_xor(accb, 32);
+    if (g == 0) atomicAdd(db + ch, accb);
+}
+
+// ------------------------------- driver -----------------------------------------------------------------------
+// forward activations: the encoder workspace (giga_encoder.hip::EncWs, fp32).  Gradient workspace carve:
+struct BwdWs { size_t gA6, gA5, gC1, gA4, gA3, gC0, gS2, gA2, gQ1, gS1, gA1, gQ0, gS0, gA0, gP0, total; };
+BwdWs enc_bwd_workspace(int B) {
+    const size_t n = 3 * (size_t)B;
+    BwdWs w{};
+    size_t at = 0;
+    auto take = [&](size_t elems) { size_t o = at; at += align_up(elems * 4, 256); return o; };
+    w.gA6 = take(n * 1600 * 32); w.gA5 = take(n * 1600 * 32); w.gC1 = take(n * 1600 * 64);
+    w.gA4 = take(n * 400 * 64);  w.gA3 = take(n * 400 * 64);  w.gC0 = take(n * 400 * 128);
+    w.gS2 = take(n * 100 * 128); w.gA2 = take(n * 100 * 128); w.gQ1 = take(n * 100 * 64);
+    w.gS1 = take(n * 400 * 64);  w.gA1 = take(n * 400 * 64);  w.gQ0 = take(n * 400 * 32);
+    w.gS0 = take(n * 1600 * 32); w.gA0 = take(n * 1600 * 32); w.gP0 = take(n * 1600 * 32);
+    w.total = at;
+    return w;
+}
+
+struct EncWs { size_t P0, A0, S0, Q0, A1, S1, Q1, A2, S2, U0, A3, A4, U1, A5, A6, YZ, XZ, total; };
+EncWs enc_workspace(int B, int precision, int nslab);
+int enc_nslab(int B);
+
+int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws,
+                            float* gplanes /* [3B][40][40][32], in: dLoss/dPlanes, clobbered */, uint8_t* gws,
+                            float* grads /* flat, state-dict order */, int head_present, int B, hipStream_t s) {
+    if (B <= 0) return 0;
+    const PackOff ko = pack_offsets();
+    const BwdPackOff bo = bwd_pack_offsets();
+    const ParamOff po = param_offsets(head_present);
+    const EncWs f = enc_workspace(B, 0, enc_nslab(B));
+    const BwdWs g = enc_bwd_workspace(B);
+    const int nimg = 3 * B;
+    auto F = [&](size_t off) { return reinterpret_cast<const float*>(fws + off); };
+    auto G = [&](size_t off) { return reinterpret_cast<float*>(gws + off); };
+    int rc = 0;
+    auto relu_bwd = [&](float* grad, const float* out, size_t n) {
+        hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s,
+                           reinterpret_cast<float4*>(grad), reinterpret_cast<const float4*>(out), n / 4);
+    };
+    auto colsum = [&](const float* grad, int cs, int coff, int C, size_t rows, int layer) {
+        hipLaunchKernelGGL(colsum_kernel, dim3(256), dim3(256), 0, s, grad, cs, coff, C, rows, grads + po.conv_b[layer]);
+    };
+    // weight gradient of layer l: R = dPre (channels = cout), columns = layer input (in0 [, in1])
+    auto wgrad3 = [&](int l, const float* dpre, const float* in0, const float* in1, int H) {
+        const ConvLayerDesc& d = kConv[l];
+        const int cin = d.cin0 + d.cin1, taps = d.kind == CONV3 ? 9 : 1;
+        WgradArgs a{};
+        a.R = dpre; a.csR = d.cout; a.coR = 0;
+        a.C0p = in0; a.C1p = in1; a.csC0 = d.cin0; a.csC1 = d.cin1; a.nC0 = d.cin0;
+        a.dW = grads + po.conv_w[l]; a.sM = cin * taps; a.sN = taps; a.sT = 1;
+        a.kind = d.kind; a.taps = taps; a.Mb = d.cout / 32; a.Nb = cin / 32;
+        a.nimg = nimg; a.H = H; a.W = H;
+        rc |= launch_wgrad(a, s);
+        colsum(dpre, d.cout, 0, d.cout, (size_t)nimg * H * H, l);
+    };
+    // ConvTranspose2d(cin, cout, 2, 2): dW[ci][co][d] = sum In[p][ci] * dU[up(p,d)][co]; dU = channels [0,cout) of dcat
+    auto wgrad_up = [&](int l, const float* in, const float* dcat, int cs_cat, int H) {
+        const ConvLayerDesc& d = kConv[l];
+        WgradArgs a{};
+        a.R = in; a.csR = d.cin0; a.coR = 0;
+        a.C0p = dcat; a.C1p = dcat; a.csC0 = cs_cat; a.csC1 = cs_cat; a.nC0 = d.cout;
+        a.dW = grads + po.conv_w[l]; a.sM = d.cout * 4; a.sN = 4; a.sT = 1;
+        a.kind = UPCONV; a.taps = 4; a.Mb = d.cin0 / 32; a.Nb = d.cout / 32;
+        a.nimg = nimg; a.H = H; a.W = H;
+        rc |= launch_wgrad(a, s);
+        colsum(dcat, cs_cat, 0, d.cout, (size_t)nimg * 4 * H * H, l);
+    };
+    auto dgrad_args = [&](int l, const float* in, int cs, void* out) {
+        ConvArgs a{};
+        a.in0 = in; a.in1 = nullptr; a.w = bwd_blob + bo.conv[l]; a.bias = nullptr; a.out = out; a.nimg = nimg;
+        a.cs0 = cs;
+        return a;
+    };
+    const size_t n40 = (size_t)nimg * 1600, n20 = (size_t)nimg * 400, n10 = (size_t)nimg * 100;
+
+    // L12 conv_final (1x1, no activation): gplanes = dOUT
+    wgrad3(12, gplanes, F(f.A6), nullptr, 40);
+    rc |= launch_conv<float, CONV1, 32, 0, 32, 40, 40, 2, false, false>(dgrad_args(12, gplanes, 0, G(g.gA6)), s);
+    // L11 up1.conv2: A5 -> A6
+    relu_bwd(G(g.gA6), F(f.A6), n40 * 32);
+    wgrad3(11, G(g.gA6), F(f.A5), nullptr, 40);
+    rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false>(dgrad_args(11, G(g.gA6), 0, G(g.gA5)), s);
+    // L10 up1.conv1: cat(U1, S0) -> A5 ; dgrad output has 64 channels (dU1 | dS0 skip part)
+    relu_bwd(G(g.gA5), F(f.A5), n40 * 32);
+    wgrad3(10, G(g.gA5), F(f.U1), F(f.S0), 40);
+    rc |= launch_conv<float, CONV3, 32, 0, 64, 40, 40, 2, false, false>(dgrad_args(10, G(g.gA5), 0, G(g.gC1)), s);
+    // L9 up1.upconv: A4 (20x20x64) -> U1 (40x40x32); dU1 = gC1[..., 0:32]
+    wgrad_up(9, F(f.A4), G(g.gC1), 64, 20);
+    rc |= launch_conv<float, DOWN, 32, 0, 64, 20, 20, 2, false, false>(dgrad_args(9, G(g.gC1), 64, G(g.gA4)), s);
+    // L8 up0.conv2: A3 -> A4
+    relu_bwd(G(g.gA4), F(f.A4), n20 * 64);
+    wgrad3(8, G(g.gA4), F(f.A3), nullptr, 20);
+    rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false>(dgrad_args(8, G(g.gA4), 0, G(g.gA3)), s);
+    // L7 up0.conv1: cat(U0, S1) -> A3 ; dgrad output 128 channels
+    relu_bwd(G(g.gA3), F(f.A3), n20 * 64);
+    wgrad3(7, G(g.gA3), F(f.U0), F(f.S1), 20);
+    rc |= launch_conv<float, CONV3, 64, 0, 128, 20, 20, 1, false, false>(dgrad_args(7, G(g.gA3), 0, G(g.gC0)), s);
+    // L6 up0.upconv: S2 (10x10x128) -> U0 (20x20x64); dU0 = gC0[..., 0:64]
+    wgrad_up(6, F(f.S2), G(g.gC0), 128, 10);
+    rc |= launch_conv<float, DOWN, 64, 0, 128, 10, 10, 1, false, false>(dgrad_args(6, G(g.gC0), 128, G(g.gS2)), s);
+    // L5 down2.conv2: A2 -> S2
+    relu_bwd(G(g.gS2), F(f.S2), n10 * 128);
+    wgrad3(5, G(g.gS2), F(f.A2), nullptr, 10);
+    rc |= launch_conv<float, CONV3, 128, 0, 128, 10, 10, 1, false, false>(dgrad_args(5, G(g.gS2), 0, G(g.gA2)), s);
+    // L4 down2.conv1: Q1 -> A2
+    relu_bwd(G(g.gA2), F(f.A2), n10 * 128);
+    wgrad3(4, G(g.gA2), F(f.Q1), nullptr, 10);
+    rc |= launch_conv<float, CONV3, 128, 0, 64, 10, 10, 1, false, false>(dgrad_args(4, G(g.gA2), 0, G(g.gQ1)), s);
+    // pool1 + skip: dS1 = gC0[..., 64:128] + unpool(dQ1)
+    {
+        const size_t tot = n20 * 64;
+        hipLaunchKernelGGL(pool_bwd_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, G(g.gS1),
+                           G(g.gC0), 128, 64, G(g.gQ1), F(f.S1), F(f.Q1), nimg, 20, 20, 64);
+    }
+    // L3 down1.conv2: A1 -> S1
+    relu_bwd(G(g.gS1), F(f.S1), n20 * 64);
+    wgrad3(3, G(g.gS1), F(f.A1), nullptr, 20);
+    rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false>(dgrad_args(3, G(g.gS1), 0, G(g.gA1)), s);
+    // L2 down1.conv1: Q0 -> A1
+    relu_bwd(G(g.gA1), F(f.A1), n20 * 64);
+    wgrad3(2, G(g.gA1), F(f.Q0), nullptr, 20);
+    rc |= launch_conv<float, CONV3, 64, 0, 32, 20, 20, 2, false, false>(dgrad_args(2, G(g.gA1), 0, G(g.gQ0)), s);
+    // pool0 + skip: dS0 = gC1[..., 32:64] + unpool(dQ0)
+    {
+        const size_t tot = n40 * 32;
+        hipLaunchKernelGGL(pool_bwd_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, G(g.gS0),
+                           G(g.gC1), 64, 32, G(g.gQ0), F(f.S0), F(f.Q0), nimg, 40, 40, 32);
+    }
+    // L1 down0.conv2: A0 -> S0
+    relu_bwd(G(g.gS0), F(f.S0), n40 * 32);
+    wgrad3(1, G(g.gS0), F(f.A0), nullptr, 40);
+    rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false>(dgrad_args(1, G(g.gS0), 0, G(g.gA0)), s);
+    // L0 down0.conv1: P0 -> A0
+    relu_bwd(G(g.gA0), F(f.A0), n40 * 32);
+    wgrad3(0, G(g.gA0), F(f.P0), nullptr, 40);
+    rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false>(dgrad_args(0, G(g.gA0), 0, G(g.gP0)), s);
+    // conv_in + projection
+    {
+        const int nslab = enc_nslab(B);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convin_bwd_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)CB_LDS_BYTES);
+        hipLaunchKernelGGL(convin_bwd_kernel, dim3(nslab, B), dim3(512), CB_LDS_BYTES, s, tsdf,
+                           reinterpret_cast<const float*>(blob + ko.convin_w),
+                           reinterpret_cast<const float*>(blob + ko.convin_b), G(g.gP0), grads + po.conv_in_w,
+                           grads + po.conv_in_b, B, RES / nslab);
+    }
+    if (hipGetLastError() != hipSuccess) rc |= -10;
+    return rc;
+}
+
+}  // namespace giga

@@ -28,7 +28,7 @@ struct HeadParamOff {
     size_t out_w, out_b;                    // (out,32), (out)
 };
 
-enum ConvKind { CONV3 = 0, UPCONV = 1, CONV1 = 2 };
+enum ConvKind { CONV3 = 0, UPCONV = 1, CONV1 = 2, DOWN = 3 };   // DOWN: data gradient of UPCONV (2x2, stride 2)
 struct ConvLayerDesc {
     int kind, cin0, cin1, cout, H, W;       // H,W = INPUT spatial size
     bool pool;                              // fused 2x2 max-pool output (DownConv with pooling)
@@ -140,6 +140,38 @@ inline PackOff pack_offsets() {
         o.dec16[h] = at; at += align_up(DEC16_BYTES, 256);
         o.dec32[h] = at; at += align_up(DEC32_BYTES, 256);
     }
+    o.total = at;
+    return o;
+}
+
+// ----- backward blob (training, fp32 only) ----------------------------------------------------------
+// conv16 fragments of the DATA-GRADIENT convolution of every U-Net layer:
+//   CONV3  W'[ci][co][tap'] = W[co][ci][8 - tap']   (180-degree flip, channels swapped)
+//   CONV1  W'[ci][co]       = W[co][ci]
+//   UPCONV W'[ci][co][d]    = W[ci][co][d]          consumed by the DOWN kind (4 taps = the 2x2 sub-pixels)
+// followed by the transposed decoder matrices (see giga_decoder_bwd.hip).
+struct BwdPackOff {
+    size_t conv[NCONV];          // fragment offset of layer l's dgrad image
+    int nfrag[NCONV];
+    size_t dec[NHEADS];          // transposed decoder matrices of head h
+    size_t total;
+};
+// decoder backward image per head: 5 blocks x (Wc^T: 3 row blocks x 4 frags, W0^T 4 frags, W1^T 4 frags)
+// + Wout (4 x 32 floats, plain) = 100 fragments + 512 B
+constexpr int DECB_FRAGS = NBLK * (12 + 4 + 4);
+constexpr size_t DECB_BYTES = (DECB_FRAGS + 1) * FRAG;
+
+inline BwdPackOff bwd_pack_offsets() {
+    BwdPackOff o{};
+    size_t at = 0;
+    for (int l = 0; l < NCONV; ++l) {
+        const ConvLayerDesc& d = kConv[l];
+        const int cin = d.cin0 + d.cin1;                    // forward channels in / out
+        const int taps = d.kind == CONV3 ? 9 : d.kind == UPCONV ? 4 : 1;
+        o.nfrag[l] = (cin / 16) * taps * (d.cout / 16);     // (cout'/16) x taps x (cin'/16), primes = swapped
+        o.conv[l] = at; at += (size_t)o.nfrag[l] * FRAG;
+    }
+    for (int h = 0; h < NHEADS; ++h) { o.dec[h] = at; at += DECB_BYTES; }
     o.total = at;
     return o;
 }

@@ -78,13 +78,16 @@ static void pack_head32(const float* P, const HeadParamOff& o, int out_dim, uint
     std::memset(dst, 0, DEC32_BYTES);
     float* f = reinterpret_cast<float*>(dst);
     auto frag = [&](int idx, int lane, int j) -> float& { return f[(size_t)idx * 256 + lane * 4 + j]; };
+    // aux fragment (3 MFMAs): [px,py] [pz,1] [1,0]  x  [Wp0,Wp1] [Wp2,bias_a] [bias_b,0].  The two biases
+    // ride in separate k-slots so that every fp32 word of the blob is a pure gather of ONE parameter
+    // (giga_pack_map / the device-side repack of the training path rely on that).
     auto aux = [&](int idx, const float* wp, const float* bias_a, const float* bias_b) {
         for (int n = 0; n < 32; ++n) {
-            float b = (bias_a ? bias_a[n] : 0.f) + (bias_b ? bias_b[n] : 0.f);
             frag(idx, n, 0) = wp ? wp[n * 3 + 0] : 0.f;        // MFMA0 slot0: px
             frag(idx, 32 + n, 0) = wp ? wp[n * 3 + 1] : 0.f;   // MFMA0 slot1: py
             frag(idx, n, 1) = wp ? wp[n * 3 + 2] : 0.f;        // MFMA1 slot0: pz
-            frag(idx, 32 + n, 1) = b;                          // MFMA1 slot1: 1.0
+            frag(idx, 32 + n, 1) = bias_a ? bias_a[n] : 0.f;   // MFMA1 slot1: 1.0
+            frag(idx, n, 2) = bias_b ? bias_b[n] : 0.f;        // MFMA2 slot0: 1.0   (slot1: 0)
         }
     };
     auto dense32 = [&](int idx0, const float* W, int rows) {   // 16 MFMAs = 4 frags
@@ -189,6 +192,112 @@ int pack_weights_host(const float* P, size_t n_params, int head_present, uint8_t
         pack_head16(P, po.head[h], HEAD_OUT[h], blob + ko.dec16[h]);
         pack_head32(P, po.head[h], HEAD_OUT[h], blob + ko.dec32[h]);
     }
+    return 0;
+}
+
+// ---- backward blob ----------------------------------------------------------------------------------------
+static void pack_conv_dgrad(const float* P, const ParamOff& po, const BwdPackOff& bo, int l, uint8_t* blob) {
+    const ConvLayerDesc& d = kConv[l];
+    const float* W = P + po.conv_w[l];
+    const int cin = d.cin0 + d.cin1;
+    const int taps = d.kind == CONV3 ? 9 : d.kind == UPCONV ? 4 : 1;
+    float* f32 = reinterpret_cast<float*>(blob + bo.conv[l]);
+    // conv16 fragment order [nb16 (output channels' = forward ci)][tap'][kg (input channels' = forward co)]
+    size_t i = 0;
+    for (int nb = 0; nb < cin / 16; ++nb)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int kg = 0; kg < d.cout / 16; ++kg, ++i)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int j = lane & 15, g = lane >> 4;
+                    for (int e = 0; e < 4; ++e) {
+                        const int ci = nb * 16 + j, co = kg * 16 + 4 * g + e;
+                        const int wtap = d.kind == CONV3 ? 8 - tap : tap;
+                        f32[i * 256 + lane * 4 + e] = conv_w_at(W, d, co, ci, wtap);
+                    }
+                }
+}
+
+// transposed decoder matrices for the backward chain (giga_decoder_bwd.hip):
+//   fragment order per block b: Wc_b^T (3 row blocks of 32 input features x 4 frags), W0_b^T (4), W1_b^T (4)
+//   A-operand fragment q of a transposed 32x32 matrix M^T: lane (i, hi), float j -> M[drow(4q+j, hi)][i]
+//   then Wout as plain [4][32] floats (rows >= out_dim zero).
+static void pack_head_bwd(const float* P, const HeadParamOff& o, int out_dim, uint8_t* dst) {
+    std::memset(dst, 0, DECB_BYTES);
+    float* f = reinterpret_cast<float*>(dst);
+    auto frag = [&](int idx, int lane, int j) -> float& { return f[(size_t)idx * 256 + lane * 4 + j]; };
+    auto transposed = [&](int idx0, const float* M, int ld, int col0) {   // M (32 x ld) row-major; columns col0..col0+31
+        for (int q = 0; q < 4; ++q)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int i = lane & 31, hi = lane >> 5;
+                for (int j = 0; j < 4; ++j) frag(idx0 + q, lane, j) = M[drow(4 * q + j, hi) * ld + col0 + i];
+            }
+    };
+    int idx = 0;
+    for (int b = 0; b < NBLK; ++b) {
+        for (int rb = 0; rb < 3; ++rb) { transposed(idx, P + o.fc_c_w[b], 96, rb * 32); idx += 4; }
+        transposed(idx, P + o.fc0_w[b], 32, 0); idx += 4;
+        transposed(idx, P + o.fc1_w[b], 32, 0); idx += 4;
+    }
+    float* wout = f + (size_t)DECB_FRAGS * 256;
+    for (int r = 0; r < out_dim; ++r)
+        for (int k = 0; k < 32; ++k) wout[r * 32 + k] = P[o.out_w + r * 32 + k];
+}
+
+size_t bwd_packed_bytes() { return bwd_pack_offsets().total; }
+
+int pack_bwd_host(const float* P, size_t n_params, int head_present, uint8_t* blob, size_t blob_bytes) {
+    const ParamOff po = param_offsets(head_present);
+    const BwdPackOff bo = bwd_pack_offsets();
+    if (n_params != po.total) return -2;
+    if (blob_bytes < bo.total) return -3;
+    std::memset(blob, 0, bo.total);
+    for (int l = 0; l < NCONV; ++l) pack_conv_dgrad(P, po, bo, l, blob);
+    for (int h = 0; h < NHEADS; ++h)
+        if (head_present >> h & 1) pack_head_bwd(P, po.head[h], HEAD_OUT[h], blob + bo.dec[h]);
+    return 0;
+}
+
+int pack_bwd_map_host(int head_present, int32_t* map, size_t nwords) {
+    const ParamOff po = param_offsets(head_present);
+    const BwdPackOff bo = bwd_pack_offsets();
+    if (nwords < bo.total / 4) return -3;
+    std::vector<float> probe(po.total);
+    for (size_t i = 0; i < po.total; ++i) probe[i] = (float)(i + 1);
+    std::vector<uint8_t> blob(bo.total);
+    int rc = pack_bwd_host(probe.data(), po.total, head_present, blob.data(), blob.size());
+    if (rc) return rc;
+    const float* f = reinterpret_cast<const float*>(blob.data());
+    for (size_t w = 0; w < bo.total / 4; ++w) map[w] = f[w] == 0.f ? -1 : (int32_t)f[w] - 1;
+    return 0;
+}
+
+// ---- gather map for the device-side repack (training path: weights change every step) -----------------
+// map[w] for every 4-byte word w of the blob:  >= 0 index of the fp32 parameter the word copies,
+// -1 constant zero, -2 not an fp32 word (f16 fragments; left untouched by giga_repack_device).
+// Built by probe-packing P[i] = i + 1 (exact in fp32 below 2^24): every fp32 word is a pure gather.
+int pack_map_host(int head_present, int32_t* map, size_t nwords) {
+    const ParamOff po = param_offsets(head_present);
+    const PackOff ko = pack_offsets();
+    if (nwords < ko.total / 4) return -3;
+    if (po.total >= (1u << 24)) return -1;
+    std::vector<float> probe(po.total);
+    for (size_t i = 0; i < po.total; ++i) probe[i] = (float)(i + 1);
+    std::vector<uint8_t> blob(ko.total);
+    int rc = pack_weights_host(probe.data(), po.total, head_present, blob.data(), blob.size());
+    if (rc) return rc;
+    for (size_t w = 0; w < ko.total / 4; ++w) map[w] = -2;
+    const float* f = reinterpret_cast<const float*>(blob.data());
+    auto region = [&](size_t off, size_t bytes) {
+        for (size_t w = off / 4; w < (off + bytes) / 4; ++w) map[w] = f[w] == 0.f ? -1 : (int32_t)f[w] - 1;
+    };
+    region(ko.convin_w, 14 * 64 * sizeof(float));
+    region(ko.convin_b, CD * sizeof(float));
+    for (int l = 0; l < NCONV; ++l) {
+        region(ko.conv[l].w32, (size_t)ko.conv[l].nfrag32 * FRAG);
+        region(ko.conv[l].bias, kConv[l].cout * sizeof(float));
+    }
+    for (int h = 0; h < NHEADS; ++h)
+        if (head_present >> h & 1) region(ko.dec32[h], DEC32_BYTES);
     return 0;
 }
 

@@ -52,6 +52,15 @@ size_t giga_packed_bytes(void);
 int giga_pack_weights(const float* params_host, size_t n_params, int head_present,
                       void* packed_host, size_t packed_bytes);
 
+/* Training support (scripts/train_giga.py:198-211: weights change every optimizer step): the fp32
+ * words of the blob are pure gathers of single parameters.  giga_pack_map fills a HOST int32 map with one
+ * entry per 4-byte blob word (>= 0 parameter index, -1 constant zero, -2 not an fp32 word);
+ * giga_repack_device rewrites the fp32 words of a DEVICE blob from a DEVICE flat parameter buffer
+ * (asynchronous on `stream`; f16 fragments are left untouched). nwords = giga_packed_bytes() / 4. */
+int giga_pack_map(int head_present, int32_t* map_host, size_t nwords);
+int giga_repack_device(const float* params_dev, const int32_t* map_dev, void* packed_dev, size_t nwords,
+                       void* stream);
+
 /* Scratch bytes giga_encoder_forward needs for a batch of B scenes. */
 size_t giga_encoder_workspace_bytes(int B, int precision);
 
@@ -99,6 +108,28 @@ int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, cons
                                  float* qual, float* rot, float* width, float* occ, int B, int R, int precision,
                                  int post, void* workspace, size_t workspace_bytes, void* stream,
                                  void* ev_start, void* ev_stop);
+
+/* ---- training path, fp32 (scripts/train_giga.py:198-211: forward, loss.backward(), optimizer.step()) -----
+ * The forward is giga_encoder_forward + giga_decoder_forward at precision 0 with the encoder workspace
+ * kept alive (it holds every U-Net activation).  giga_backward computes the gradient of a scalar loss with
+ * respect to EVERY parameter, given the gradients of the four head outputs:
+ *   outs / douts : arrays of 4 device pointers (qual [B*N], rot [B*N][4], width [B*N], occ [B*M]); entries of
+ *                  absent heads are ignored.  outs are the forward results (post sigmoid / normalize).
+ *   grads        : flat fp32 buffer in reference state-dict order (giga_param_count), overwritten.
+ * It replaces autograd through conv_onet/models/__init__.py:42-67 (decoder.py:117-176, encoder/voxels.py:89-121,
+ * encoder/unet.py:225-239).  Data-gradient convolutions and the decoder's gradient chain run on MFMA with the
+ * transposed weights of the BACKWARD blob (giga_bwd_packed_bytes / giga_pack_bwd_weights, host; or
+ * giga_pack_bwd_map + giga_repack_device on the device every step).  Weight gradients are reduced with fp32
+ * atomics (run-to-run differences at rounding level, as in PyTorch's own GPU backward). */
+size_t giga_bwd_packed_bytes(void);
+int giga_pack_bwd_weights(const float* params_host, size_t n_params, int head_present, void* packed_host,
+                          size_t packed_bytes);
+int giga_pack_bwd_map(int head_present, int32_t* map_host, size_t nwords);
+size_t giga_backward_workspace_bytes(int B, int N, int M, int head_present);
+int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed, const void* enc_workspace_fwd,
+                  const void* planes_nhwc, const float* p, const float* p_tsdf, const float* const* outs,
+                  const float* const* douts, float* grads, size_t n_params, int head_present, int B, int N, int M,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- measurement hooks (bench.py roofline): HIP events recorded on `stream` right before and
  * after ONE kernel launch, so the kernel's duration is measured live on the stream it runs on.

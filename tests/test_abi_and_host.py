@@ -58,6 +58,22 @@ def test_pack_is_deterministic_and_sensitive(sd7):
     assert not torch.equal(a, _capi.pack_weights(flat2, 15))
 
 
+def test_pack_map_reproduces_fp32_words(sd7):
+    """Training path: blob fp32 words are pure gathers; applying giga_pack_map in numpy must equal the
+    host-packed blob on every fp32 word, for the full and the reduced head sets."""
+    for head_present, sd in ((15, sd7), (7, weights.make_state_dict(3, with_tsdf=False))):
+        flat = torch.cat([v.reshape(-1) for v in sd.values()])
+        blob = _capi.pack_weights(flat, head_present).numpy().view(np.float32)
+        m = _capi.pack_map(head_present).numpy()
+        assert m.shape == blob.shape and m.max() < flat.numel()
+        sel = m >= 0
+        np.testing.assert_array_equal(blob[sel], flat.numpy()[m[sel]])
+        assert np.all(blob[m == -1] == 0)
+        assert sel.sum() > 500000 and (m == -2).sum() > 0
+        # every parameter of every present head / the encoder is referenced by the fp32 image
+        assert np.unique(m[sel]).size == flat.numel()
+
+
 def test_conv_fragments_round_trip(sd7):
     """Invert the documented 16x16-MFMA fragment layout (giga_pack.cpp) and recover the weights."""
     flat = torch.cat([v.reshape(-1) for v in sd7.values()])
@@ -128,8 +144,10 @@ def test_cpu_tensors_fail_loudly():
             net(torch.zeros(1, 40, 40, 40), torch.zeros(1, 4, 3))
         with pytest.raises(_capi.GigaHipError):
             net.encoder(torch.zeros(1, 40, 40, 40))
-    with pytest.raises(NotImplementedError):          # autograd path is not built yet
+    with pytest.raises(_capi.GigaHipError):           # the differentiable path is HIP-only as well
         net(torch.zeros(1, 40, 40, 40), torch.zeros(1, 4, 3))
+    with pytest.raises(NotImplementedError):          # piecewise entry points are inference-only
+        net.encoder(torch.zeros(1, 40, 40, 40))
 
 
 def test_unsupported_configs_are_rejected():

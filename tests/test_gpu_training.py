@@ -1,0 +1,79 @@
+"""GPU parity of the training path (scripts/train_giga.py:198-211): loss and the gradient of EVERY parameter
+tensor from the HIP backward against torch autograd through the CPU oracle, and against the reference-
+generated golden G4 (losses + per-tensor gradient norms).  fp32; weight gradients are reduced with atomics,
+so the tolerance is relative (2e-3 of the tensor's max |grad|, plus 1e-6 absolute)."""
+import numpy as np
+import pytest
+import torch
+
+from giga_amd import networks, synth, weights
+from giga_amd.training import loss_fn, select
+from oracle import giga_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(first, B, M):
+    x = torch.from_numpy(synth.tsdf_batch(first, B))
+    pos = torch.from_numpy(synth.query_points(first, B, 1, stream=2))
+    pos_occ = torch.from_numpy(synth.query_points(first, B, M, stream=3))
+    y = tuple(torch.from_numpy(a) for a in synth.train_labels(first, B, M))
+    return x, pos, pos_occ, y
+
+
+def _oracle_grads(sd, x, pos, pos_occ, y):
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out = O.model_forward(sdg, x, pos, p_tsdf=pos_occ)
+    loss, d = O.train_loss(O.train_select(out), y)
+    loss.backward()
+    return loss.item(), {k: v.grad for k, v in sdg.items()}, d
+
+
+def test_train_step_gradients_match_oracle_and_g4(golden, sd7):
+    dev = torch.device("cuda:0")
+    g4 = golden("g4_train_step.npz")
+    B, M, s0 = int(g4["B"]), int(g4["M"]), int(g4["first_scene"])
+    x, pos, pos_occ, y = _batch(s0, B, M)
+    ref_loss, ref_grads, ref_d = _oracle_grads(sd7, x, pos, pos_occ, y)
+    net = networks.get_network("giga")
+    net.load_state_dict(sd7)
+    net = net.to(dev).train()
+    out = net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev))
+    loss, d = loss_fn(select(out), tuple(t.to(dev) for t in y))
+    for k in ("loss_qual", "loss_rot", "loss_width", "loss_occ", "loss_all"):
+        assert abs(d[k].item() - float(g4[k])) <= 1e-4 * max(1.0, abs(float(g4[k]))), k
+    assert abs(loss.item() - ref_loss) < 1e-5
+    loss.backward()
+    worst = []
+    for name, prm in net.named_parameters():
+        ref = ref_grads[name]
+        got = prm.grad.detach().cpu()
+        assert got.shape == ref.shape, name
+        scale = ref.abs().max().item()
+        err = (got - ref).abs().max().item()
+        worst.append((err / (scale + 1e-12), name, err, scale))
+        assert err <= 2e-3 * scale + 1e-6, (name, err, scale)
+    names = [str(n) for n in g4["grad_names"]]
+    got_norms = {n: p.grad.double().norm().item() for n, p in net.named_parameters()}
+    for n, ref in zip(names, g4["grad_norms"]):
+        assert abs(got_norms[n] - ref) <= 2e-3 * max(ref, 1e-6) + 1e-8, (n, got_norms[n], ref)
+
+
+def test_sgd_steps_track_the_oracle(sd7):
+    """Three optimizer steps (device-side repack each step) follow the oracle's trajectory."""
+    dev = torch.device("cuda:0")
+    B, M = 2, 512
+    x, pos, pos_occ, y = _batch(30, B, M)
+    net = networks.get_network("giga"); net.load_state_dict(sd7); net = net.to(dev).train()
+    opt = torch.optim.SGD(net.parameters(), lr=1e-2)
+    sd = {k: v.clone() for k, v in sd7.items()}
+    losses, ref_losses = [], []
+    for _ in range(3):
+        opt.zero_grad()
+        loss, _ = loss_fn(select(net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev))), tuple(t.to(dev) for t in y))
+        loss.backward(); opt.step(); losses.append(loss.item())
+        rl, rg, _ = _oracle_grads(sd, x, pos, pos_occ, y)
+        sd = {k: v - 1e-2 * rg[k] for k, v in sd.items()}
+        ref_losses.append(rl)
+    assert np.allclose(losses, ref_losses, rtol=0, atol=2e-4), (losses, ref_losses)
+    assert losses[-1] < losses[0]

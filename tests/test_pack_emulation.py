@@ -107,6 +107,7 @@ def test_decoder_f32_fragment_chain(sd7):
                 cf[m, hi * 32:(hi + 1) * 32] = c[0, :, (m // 16) * 32 + 16 * hi + (m % 16)]
         ax0 = np.concatenate([p[0, :, 0], p[0, :, 1]])
         ax1 = np.concatenate([p[0, :, 2], np.ones(32, np.float32)])
+        ax2 = np.concatenate([np.ones(32, np.float32), np.zeros(32, np.float32)])
         net = np.zeros((64, 16), np.float32)
         k = 0
         for blk in range(5):
@@ -114,7 +115,7 @@ def test_decoder_f32_fragment_chain(sd7):
                 for j in range(4):
                     net = one(W[k], j, cf[4 * q + j], net)
                 k += 1
-            net = one(W[k], 0, ax0, net); net = one(W[k], 1, ax1, net); k += 1
+            net = one(W[k], 0, ax0, net); net = one(W[k], 1, ax1, net); net = one(W[k], 2, ax2, net); k += 1
             hh = _ctab_regs(ctab, blk)
             for q in range(4):
                 for j in range(4):
