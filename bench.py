@@ -203,6 +203,13 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["extra"] = {"c4_error": f"{type(e).__name__}: {e}"}
 
+    # -------- extra: c5-shaped training step (fp32 here; BASELINE c5 names bf16 -- see DESIGN.md) -----------
+    if not args.no_extra:
+        try:
+            out["extra"]["c5_train_step_fp32"] = bench_train(net, dev, synth, B, M)
+        except Exception as e:  # noqa: BLE001
+            out["extra"]["c5_error"] = f"{type(e).__name__}: {e}"
+
     # -------- CPU baseline: the oracle (port of the reference path) on the host cores -------------------
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sd, synth, M)
@@ -253,6 +260,36 @@ def bench_c4(net, sd, dev, L, _capi, synth, decode_heads, Bc=32, steps=10):
                      "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": None,
                      "avg_launch_ms": dec_ms, "flops_per_launch": flops},
     }
+
+
+def bench_train(net, dev, synth, B, M, steps=10):
+    from giga_amd.training import loss_fn, select
+    net.set_precision("fp32").train()
+    x = torch.from_numpy(synth.tsdf_batch(2000, B)).to(dev)
+    pos = torch.from_numpy(synth.query_points(2000, B, 1, stream=2)).to(dev)
+    pos_occ = torch.from_numpy(synth.query_points(2000, B, M, stream=3)).to(dev)
+    y = tuple(torch.from_numpy(a).to(dev) for a in synth.train_labels(2000, B, M))
+    opt = torch.optim.Adam(net.parameters(), lr=2e-4)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss, _ = loss_fn(select(net(x, pos, p_tsdf=pos_occ)), y)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    net.eval()
+    return {"workload": f"joint GIGA training step (train_giga.py:198-211): B={B} scenes, 1 grasp query + {M} "
+                        "occupancy queries, forward + HIP backward + torch Adam, fp32, 1 GPU",
+            "ms_per_step": el * 1e3, "scenes_per_sec": B / el, "final_loss": float(loss)}
 
 
 def cpu_baseline(sd, synth, M, budget_s=20.0):

@@ -438,6 +438,15 @@ class ConvolutionalOccupancyNetwork(nn.Module):
                 params += _head_param_list(getattr(self, h))
         return params + _encoder_param_list(self.encoder)
 
+    def enable_data_parallel(self, group=None, enabled=True):
+        """Scene-sharded data-parallel training: every rank runs the same step on its own scenes and the
+        backward all-reduces (means) the flat gradient bucket once (giga_amd.training.allreduce_mean_)."""
+        self._dp = (bool(enabled), group)
+        st = getattr(self, "_train_state", None)
+        if st is not None:
+            st.data_parallel, st.group = self._dp
+        return self
+
     def _forward_train(self, inputs, p, p_tsdf):
         """Differentiable fp32 path (scripts/train_giga.py:204): HIP forward + HIP backward through
         giga_amd.training.GigaFunction.  Gradients flow to the parameters only."""
@@ -447,6 +456,7 @@ class ConvolutionalOccupancyNetwork(nn.Module):
         st = getattr(self, "_train_state", None)
         if st is None or st.blob.device != inputs.device:
             st = self._train_state = _TrainState(self._head_present(), inputs.device)
+            st.data_parallel, st.group = getattr(self, "_dp", (False, None))
         return GigaFunction.apply(st, inputs, p, p_tsdf, *self._param_list())
 
     def infer_geo(self, inputs, p_tsdf, **kwargs):

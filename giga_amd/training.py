@@ -31,6 +31,8 @@ class _TrainState:
         self.blob = torch.zeros(L.giga_packed_bytes(), dtype=torch.uint8, device=device)
         self.bwd_blob = torch.zeros(L.giga_bwd_packed_bytes(), dtype=torch.uint8, device=device)
         self.n_params = L.giga_param_count(head_present)
+        self.data_parallel = False      # set by ConvolutionalOccupancyNetwork.enable_data_parallel()
+        self.group = None
 
     def repack(self, flat):
         L = _capi.lib()
@@ -38,6 +40,17 @@ class _TrainState:
                                          self.map_fwd.numel(), _capi.stream_ptr()), "giga_repack_device")
         _capi.check(L.giga_repack_device(_capi.ptr(flat), _capi.ptr(self.map_bwd), _capi.ptr(self.bwd_blob),
                                          self.map_bwd.numel(), _capi.stream_ptr()), "giga_repack_device")
+
+
+def allreduce_mean_(flat, group=None):
+    """The single collective of data-parallel training: one all_reduce(sum) over the flat
+    581 863-element fp32 gradient bucket (2.3 MB; latency-bound over xGMI), then divide by the world size.
+    No-op when torch.distributed is not initialised."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(dist.get_world_size(group))
+    return flat
 
 
 def _ptr_array(tensors):
@@ -99,6 +112,8 @@ class GigaFunction(torch.autograd.Function):
             _capi.ptr(p), _capi.ptr(p_tsdf), _ptr_array(outs), _ptr_array(douts), _capi.ptr(grads),
             grads.numel(), state.head_present, B, N, M, _capi.ptr(wsb), wsb.numel(), _capi.stream_ptr()),
             "giga_backward")
+        if state.data_parallel:
+            allreduce_mean_(grads, state.group)
         views, at = [], 0
         for shp in ctx.shapes:
             n = 1

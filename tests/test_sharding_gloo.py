@@ -42,6 +42,28 @@ def _worker(rank, world, port, n_scenes, out_dir):
     dist.destroy_process_group()
 
 
+def _grad_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from giga_amd.training import allreduce_mean_
+    flat = torch.arange(581863, dtype=torch.float32) * (rank + 1)          # the flat gradient bucket
+    allreduce_mean_(flat)
+    np.save(os.path.join(out_dir, f"g{rank}.npy"), flat[:1000].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_gradient_allreduce_gloo(tmp_path):
+    """Data-parallel training's only collective: mean of the flat gradient bucket over 2 ranks."""
+    port = _free_port()
+    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    expect = np.arange(1000, dtype=np.float32) * 1.5
+    for r in range(2):
+        np.testing.assert_allclose(np.load(os.path.join(tmp_path, f"g{r}.npy")), expect, rtol=1e-6)
+
+
 def test_shard_maps():
     assert sharding.scene_shard(5, 0, 2) == [0, 2, 4] and sharding.scene_shard(5, 1, 2) == [1, 3]
     assert sharding.shard_sizes(256, 8) == [32] * 8
