@@ -162,6 +162,16 @@ def main():
             dist.destroy_process_group()
         return
 
+    # HBM bytes per launch of the dominant kernel: PMC counters cannot be collected from inside this process,
+    # so they come from the committed rocprofv3 PMC table of the same workload (profiles/r01_traffic_c2.json,
+    # produced by tools/gpu_traffic.sh); null when the table has no entry for this kernel / batch size.
+    traffic = None
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_c2.json")))
+        if B == 32 and STAGE_NAMES[dom] in tab["stages"]:
+            traffic = tab["stages"][STAGE_NAMES[dom]]["bytes"]
+    except (OSError, ValueError, KeyError):
+        pass
     dom_avg_ms = float(np.mean(dom_ms))
     dom_flops = stage_flops(dom, B)
     achieved = dom_flops / (dom_avg_ms * 1e-3) / 1e12
@@ -188,7 +198,7 @@ def main():
         "algorithmic_tflops": scenes_per_s * flop_scene / 1e12,
         "roofline": {
             "kernel": STAGE_NAMES[dom], "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+            "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic,
             "avg_launch_ms": dom_avg_ms, "flops_per_launch": dom_flops,
             "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) peak; events on the launch stream inside the timed steps",
         },
