@@ -70,8 +70,22 @@ _SIGNATURES = {
                                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                                     ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
                                                     ctypes.c_void_p]),
+    "giga_grasp_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "giga_grasp_select": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                         ctypes.c_void_p]),
 }
 EXPORTS = tuple(_SIGNATURES)
+
+
+class GraspParams(ctypes.Structure):
+    """struct GigaGraspParams of include/giga_hip.h."""
+    _fields_ = [("gaussian_sigma", ctypes.c_double), ("min_width", ctypes.c_float), ("max_width", ctypes.c_float),
+                ("out_th", ctypes.c_float), ("low_th", ctypes.c_float), ("threshold", ctypes.c_float),
+                ("lim_x", ctypes.c_int), ("lim_y", ctypes.c_int), ("lim_z", ctypes.c_int),
+                ("max_filter_size", ctypes.c_int), ("force_detection", ctypes.c_int)]
 
 
 class GigaHipError(RuntimeError):

@@ -1,14 +1,19 @@
 """Inference-side caller of the hot path: counterpart of the network part of the reference's
 `vgn.detection_implicit` (/root/reference/src/vgn/detection_implicit.py:17-31, 99-113).
 
-The 40^3 query lattice and `predict()` keep the reference's shapes and dtypes.  The scipy
-post-processing (`process` / `bound` / `select`, detection_implicit.py:87-174) stays on the host in
-the reference and is listed as "next" in SURVEY.md section 8f; it consumes exactly what `predict`
-returns, so the reference functions can be used unchanged on these outputs."""
+The 40^3 query lattice and `predict()` keep the reference's shapes and dtypes.  The post-processing the
+reference runs on the host with scipy (`process` / `bound` / `select`, detection_implicit.py:87-174) is
+available on the device as `grasp_select` (C ABI `giga_grasp_select`), and `VGNImplicit` chains network and
+post-processing without leaving HBM: only the surviving grasps (a few dozen floats) cross PCIe."""
+import ctypes
+import time
+
 import numpy as np
 import torch
 
-from . import synth
+from . import _capi, synth
+
+LOW_TH = 0.5       # detection_implicit.py:15
 
 
 def query_lattice(resolution=40, device=None):
@@ -43,3 +48,122 @@ def predict_batch(tsdf_batch, pos, net):
         pos = pos.expand(B, -1, -1).contiguous()          # a registered lattice is shared as-is
     with torch.no_grad():
         return net(tsdf_batch, pos)
+
+
+def bound_limits(voxel_size, limit=(0.02, 0.02, 0.055)):
+    """detection_implicit.py:87-91: the number of boundary voxels zeroed along x, y (both ends) and z (bottom)."""
+    return tuple(int(l / voxel_size) for l in limit)
+
+
+def grasp_select(tsdf, qual, rot, width, voxel_size=None, out_th=0.5, threshold=0.9, force_detection=False,
+                 max_filter_size=4, gaussian_filter_sigma=1.0, min_width=0.033, max_width=0.233,
+                 limit=(0.02, 0.02, 0.055), return_volume=False):
+    """process + bound + select (detection_implicit.py:115-143, 87-97, 146-174) for B scenes on the device.
+
+    tsdf (B,R,R,R) | (B,1,R,R,R), qual (B,R^3), rot (B,R^3,4), width (B,R^3): float32 device tensors (the
+    network outputs of `predict_batch`).  Returns a list of B dicts with numpy arrays sorted by descending
+    score: index (K,3) voxel indices, score (K,), rot (K,4) quaternions, width (K,), best_only flag; plus the
+    processed quality volume (B,R,R,R) (device tensor) when return_volume is set."""
+    _capi.require_device(tsdf, qual, rot, width)
+    B = qual.shape[0]
+    R = tsdf.shape[-1]
+    V = R * R * R
+    tsdf = tsdf.reshape(B, V).float().contiguous()
+    qual = qual.reshape(B, V).float().contiguous()
+    rot = rot.reshape(B, V, 4).float().contiguous()
+    width = width.reshape(B, V).float().contiguous()
+    if voxel_size is None:
+        voxel_size = 0.3 / R                                  # detection_implicit.py:41
+    lx, ly, lz = bound_limits(voxel_size, limit)
+    prm = _capi.GraspParams(float(gaussian_filter_sigma), min_width, max_width, out_th, LOW_TH, threshold,
+                            lx, ly, lz, int(max_filter_size), int(bool(force_detection)))
+    dev = qual.device
+    cap = V
+    qual_out = torch.empty(B, V, device=dev)
+    counters = torch.empty(B, 2, dtype=torch.int32, device=dev)
+    cand_index = torch.empty(B, cap, dtype=torch.int32, device=dev)
+    cand_score = torch.empty(B, cap, device=dev)
+    cand_rot = torch.empty(B, cap, 4, device=dev)
+    cand_width = torch.empty(B, cap, device=dev)
+    L = _capi.lib()
+    ws = torch.empty(L.giga_grasp_workspace_bytes(B, R), dtype=torch.uint8, device=dev)
+    _capi.check(L.giga_grasp_select(_capi.ptr(tsdf), _capi.ptr(qual), _capi.ptr(rot), _capi.ptr(width), B, R,
+                                    ctypes.byref(prm), _capi.ptr(qual_out), _capi.ptr(counters), cap,
+                                    _capi.ptr(cand_index), _capi.ptr(cand_score), _capi.ptr(cand_rot),
+                                    _capi.ptr(cand_width), _capi.ptr(ws), ws.numel(), _capi.stream_ptr()),
+                "giga_grasp_select")
+    cnt = counters.cpu().numpy()                              # synchronises; 8 bytes per scene
+    kmax = int(min(cnt[:, 1].max(), cap)) if B else 0
+    idx_h = cand_index[:, :kmax].cpu().numpy()
+    score_h = cand_score[:, :kmax].cpu().numpy()
+    rot_h = cand_rot[:, :kmax].cpu().numpy()
+    width_h = cand_width[:, :kmax].cpu().numpy()
+    out = []
+    for b in range(B):
+        k = int(min(cnt[b, 1], cap))
+        best_only = bool(force_detection) and cnt[b, 0] == 0
+        flat = idx_h[b, :k]
+        # the reference sorts with reversed(np.argsort(scores)) over the argwhere (ascending index) order
+        first = np.argsort(flat, kind="stable")
+        order = first[np.asarray(list(reversed(np.argsort(score_h[b, :k][first]))), dtype=np.int64)]
+        if best_only:
+            order = order[:1]
+        flat = flat[order].astype(np.int64)
+        out.append({"index": np.stack((flat // (R * R), (flat // R) % R, flat % R), -1).reshape(-1, 3),
+                    "score": score_h[b, :k][order], "rot": rot_h[b, :k][order], "width": width_h[b, :k][order],
+                    "best_only": best_only})
+    if return_volume:
+        return out, qual_out.view(B, R, R, R)
+    return out
+
+
+class VGNImplicit:
+    """Device-resident counterpart of the reference planner (detection_implicit.py:17-85): network on the 40^3
+    lattice + grasp post-processing, one D->H copy of the selected grasps.  `__call__(state)` keeps the
+    reference's contract (state.tsdf a (1,R,R,R) numpy grid or an object with get_grid()/voxel_size/size) and
+    returns (grasps, scores, toc) where each grasp is a dict {rotation (xyzw quat), translation (m), width (m)}
+    -- the fields of vgn.grasp.Grasp/Transform, which live outside this package.  `plan_batch` is the batched,
+    tensor-in form."""
+
+    def __init__(self, model_path, model_type, best=False, force_detection=False, qual_th=0.9, out_th=0.5,
+                 visualize=False, resolution=40, net=None, seed=None, **kwargs):
+        from .networks import load_network
+        self.device = torch.device("cuda")
+        self.net = net if net is not None else load_network(model_path, self.device, model_type=model_type)
+        self.qual_th, self.best, self.force_detection, self.out_th = qual_th, best, force_detection, out_th
+        self.visualize = visualize
+        self.resolution = resolution
+        self.pos = query_lattice(resolution, self.device)
+        self._rng = np.random.default_rng(seed)
+
+    def plan_batch(self, tsdf, tsdf_process=None, voxel_size=None):
+        """tsdf (B,R,R,R) device tensor -> per-scene candidate dicts (see grasp_select), lattice positions added."""
+        R = self.resolution
+        qual, rot, width = predict_batch(tsdf, self.pos, self.net)
+        sel = grasp_select(tsdf if tsdf_process is None else tsdf_process, qual, rot, width, voxel_size=voxel_size,
+                           out_th=self.out_th, threshold=self.qual_th, force_detection=self.force_detection,
+                           max_filter_size=8 if self.visualize else 4)
+        lin = self.pos[0, :: R * R, 0].cpu().numpy()
+        for s in sel:
+            s["position"] = lin[s["index"]]                    # center_vol[i, j, k], detection_implicit.py:181
+        return sel
+
+    def __call__(self, state, scene_mesh=None, aff_kwargs={}):
+        tsdf_process = state.tsdf_process if hasattr(state, "tsdf_process") else state.tsdf
+        if isinstance(state.tsdf, np.ndarray):
+            tsdf_vol, voxel_size, size = state.tsdf, 0.3 / self.resolution, 0.3
+        else:
+            tsdf_vol, voxel_size, size = state.tsdf.get_grid(), tsdf_process.voxel_size, state.tsdf.size
+            tsdf_process = tsdf_process.get_grid()
+        R = self.resolution
+        tic = time.time()
+        t = torch.from_numpy(np.ascontiguousarray(tsdf_vol, np.float32).reshape(1, R, R, R)).to(self.device)
+        tp = t if tsdf_process is tsdf_vol else torch.from_numpy(
+            np.ascontiguousarray(tsdf_process, np.float32).reshape(1, R, R, R)).to(self.device)
+        sel = self.plan_batch(t, tp, voxel_size)[0]
+        toc = time.time() - tic
+        k = len(sel["score"])
+        p = np.arange(k) if self.best else self._rng.permutation(k)       # detection_implicit.py:65-68
+        grasps = [{"rotation": sel["rot"][i], "translation": (sel["position"][i] + 0.5) * size,
+                   "width": float(sel["width"][i]) * size} for i in p]
+        return grasps, sel["score"][p], toc

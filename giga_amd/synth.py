@@ -52,3 +52,26 @@ def train_labels(first_scene, n_scenes, n_occ):
     width = rng.uniform(0.0, 0.3, size=n_scenes).astype(np.float32)
     occ = (rng.random((n_scenes, n_occ)) < 0.3).astype(np.float32)
     return label, q, width, occ
+
+
+def post_volumes(seed, R=RES):
+    """Synthetic inputs for the grasp post-processing (detection_implicit.py:115-174): a TSDF with empty,
+    near-surface and free-space regions, a smooth quality field with a few strong peaks, unit quaternions and
+    widths in [0, 0.3]."""
+    rng = np.random.default_rng([4321, seed])
+    g = np.stack(np.meshgrid(*(np.linspace(-1, 1, R),) * 3, indexing="ij"), -1)
+    blob = np.zeros((R, R, R))
+    for _ in range(6):
+        c = rng.uniform(-0.6, 0.6, 3)
+        blob += np.exp(-((g - c) ** 2).sum(-1) / rng.uniform(0.02, 0.08))
+    tsdf = np.clip(1.0 - blob, 0.0, 1.0).astype(np.float32)
+    tsdf[rng.random((R, R, R)) < 0.15] = 0.0                       # unobserved voxels
+    qual = rng.random((R, R, R))
+    for _ in range(12):
+        c = rng.uniform(-0.7, 0.7, 3)
+        qual += 6.0 * np.exp(-((g - c) ** 2).sum(-1) / 0.01)
+    qual = (1.0 / (1.0 + np.exp(-(qual - 1.5)))).astype(np.float32)
+    rot = rng.standard_normal((R, R, R, 4)).astype(np.float32)
+    rot /= np.linalg.norm(rot, axis=-1, keepdims=True)
+    width = rng.uniform(0.0, 0.3, (R, R, R)).astype(np.float32)
+    return tsdf, qual, rot, width

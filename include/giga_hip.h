@@ -131,6 +131,39 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
                   const float* const* douts, float* grads, size_t n_params, int head_present, int B, int N, int M,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- grasp post-processing (src/vgn/detection_implicit.py:115-143 process, :87-97 bound, :146-174 select) -----
+ * Replaces the host-side scipy stage that follows `predict` in VGNImplicit.__call__ (detection_implicit.py:55-58)
+ * for B scenes at once; every volume is [B][R][R][R] float32 (rot: [B][R^3][4]) on the device.
+ *   process : gaussian_filter(qual, sigma, mode="nearest"); qual = 0 where the voxel is not in the 2-iteration
+ *             masked binary dilation of (tsdf > out_th) with mask ~(1e-3 < tsdf < out_th), or where
+ *             width < min_width or width > max_width                      (detection_implicit.py:126-141)
+ *   bound   : qual = 0 for x < lim_x, x >= R-lim_x, y < lim_y, y >= R-lim_y, z < lim_z; the caller computes
+ *             lim = int(limit / voxel_size) as detection_implicit.py:89-91 does
+ *   select  : qual < low_th -> 0; if force_detection and no voxel >= threshold the scene is "best only" and
+ *             the threshold is skipped, else qual < threshold -> 0; NMS with maximum_filter(size =
+ *             max_filter_size, mode reflect); survivors are appended (unordered) to the candidate lists.
+ * Outputs: qual_out [B][R^3] = the volume after process+bound (what the reference hands to select and to its
+ * visualiser); counters [B][2] = {#voxels >= threshold (0 => best-only when force_detection), #candidates};
+ * cand_index/score/width [B][cap], cand_rot [B][cap][4] hold the first min(#candidates, cap) survivors: flat
+ * voxel index (x*R+y)*R+z, score, quaternion and width.  The caller sorts by descending score
+ * (detection_implicit.py:166-171) and keeps one entry for a best-only scene. */
+typedef struct GigaGraspParams {
+    double gaussian_sigma;     /* 1.0 */
+    float min_width;           /* 0.033 */
+    float max_width;           /* 0.233 */
+    float out_th;              /* VGNImplicit(out_th=0.5) */
+    float low_th;              /* LOW_TH = 0.5, detection_implicit.py:15 */
+    float threshold;           /* VGNImplicit(qual_th=0.9) */
+    int lim_x, lim_y, lim_z;   /* int(0.02/voxel_size), int(0.02/voxel_size), int(0.055/voxel_size) */
+    int max_filter_size;       /* 4 (8 when visualising) */
+    int force_detection;
+} GigaGraspParams;
+size_t giga_grasp_workspace_bytes(int B, int R);
+int giga_grasp_select(const float* tsdf, const float* qual, const float* rot, const float* width, int B, int R,
+                      const GigaGraspParams* params, float* qual_out, int* counters, int cap, int* cand_index,
+                      float* cand_score, float* cand_rot, float* cand_width, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* ---- measurement hooks (bench.py roofline): HIP events recorded on `stream` right before and
  * after ONE kernel launch, so the kernel's duration is measured live on the stream it runs on.
  * probe_stage: 0 conv_in+project, 1 plane_finalize, 2..14 = U-Net layers 0..12 (giga_layout.h kConv).

@@ -14,6 +14,7 @@ missing third-party packages that are irrelevant to the hot path (SURVEY.md sect
 Nothing here restates reference code: it only supplies absent *dependencies*.
 """
 import importlib.machinery
+import importlib.util
 import os
 import sys
 import types
