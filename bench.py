@@ -210,6 +210,14 @@ def main():
     if not args.no_extra:
         try:
             out["extra"] = {"c4": bench_c4(net, sd, dev, L, _capi, synth, decode_heads)}
+            # BASELINE c4 is a sweep over the scenes per GPU; the decoder's MFMA fraction per batch size
+            sweep = []
+            for bc in (1, 8, 128):
+                r = bench_c4(net, sd, dev, L, _capi, synth, decode_heads, Bc=bc, steps=10)
+                sweep.append({"scenes": bc, "scenes_per_sec": r["scenes_per_sec"], "ms_per_step": r["ms_per_step"],
+                              "decoder_ms": r["roofline"]["avg_launch_ms"], "decoder_tflops": r["roofline"]["achieved"],
+                              "decoder_frac_of_f16_mfma_peak": r["roofline"]["frac"]})
+            out["extra"]["c4_sweep"] = sweep
         except Exception as e:  # noqa: BLE001
             out["extra"] = {"c4_error": f"{type(e).__name__}: {e}"}
 
@@ -243,7 +251,7 @@ def bench_c4(net, sd, dev, L, _capi, synth, decode_heads, Bc=32, steps=10):
             nhwc, _ = net.encoder.encode_nhwc(x, blob=blob, precision="fp16")
             return decode_heads(nhwc, lat, blob, 7, "fp16", True, probe=pr)
 
-    for _ in range(3):
+    for _ in range(8):                     # also absorbs the allocator's one-off work after a change of batch size
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

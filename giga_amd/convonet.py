@@ -451,11 +451,9 @@ class ConvolutionalOccupancyNetwork(nn.Module):
         """Differentiable fp32 path (scripts/train_giga.py:204): HIP forward + HIP backward through
         giga_amd.training.GigaFunction.  Gradients flow to the parameters only."""
         from .training import GigaFunction, _TrainState
-        if self.detach_tsdf:
-            raise NotImplementedError("giga_detach (detach_tsdf=True) is not supported by the HIP backward yet")
         st = getattr(self, "_train_state", None)
         if st is None or st.blob.device != inputs.device:
-            st = self._train_state = _TrainState(self._head_present(), inputs.device)
+            st = self._train_state = _TrainState(self._head_present(), inputs.device, detach_occ=self.detach_tsdf)
             st.data_parallel, st.group = getattr(self, "_dp", (False, None))
         return GigaFunction.apply(st, inputs, p, p_tsdf, *self._param_list())
 

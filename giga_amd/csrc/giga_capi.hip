@@ -237,6 +237,7 @@ static size_t train_dec_scratch_bytes(int B, int N, int M, int head_present) {
 
 size_t giga_backward_workspace_bytes(int B, int N, int M, int head_present) {
     if (B <= 0) return 0;
+    head_present &= 15;
     return align_up((size_t)3 * B * RES * RES * CD * sizeof(float), 256) + enc_bwd_workspace(B).total +
            train_dec_scratch_bytes(B, N, M, head_present);
 }
@@ -249,6 +250,7 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
     if (!tsdf || !packed || !bwd_packed || !enc_workspace_fwd || !planes_nhwc || !outs || !douts || !grads ||
         !workspace)
         return -1;
+    const bool detach_occ = (head_present & GIGA_DETACH_OCC) != 0;     // detach_tsdf, models/__init__.py:61-63
     head_present &= 15;
     if (n_params != param_offsets(head_present).total) return -2;
     if (workspace_bytes < giga_backward_workspace_bytes(B, N, M, head_present)) return -4;
@@ -270,7 +272,7 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
     }
     if ((head_present & 8) && M > 0 && p_tsdf) {
         rc |= launch_decoder_backward(static_cast<const float*>(planes_nhwc), p_tsdf, blob, bblob, 8, outs, douts,
-                                      gplanes, grads, head_present, scratch, B, M, s);
+                                      detach_occ ? nullptr : gplanes, grads, head_present, scratch, B, M, s);
     }
     rc |= launch_encoder_backward(tsdf, blob, bblob, static_cast<const uint8_t*>(enc_workspace_fwd), gplanes, gws,
                                   grads, head_present, B, s);

@@ -33,7 +33,7 @@ struct DecBwdArgs {
     const float* dout[NHEADS];  // upstream gradients, same shapes
     float* scratch[NHEADS];     // DB_NARR arrays of [P][32]
     float* Cbuf; float* Pbuf;   // [P][96], [P][32]
-    float* gplanes;             // NHWC fp32 [3][B][40][40][32], accumulated with atomics
+    float* gplanes;             // NHWC fp32 [3][B][40][40][32], accumulated with atomics; nullptr = detached head
     int nheads, B, N;
     long long P;
     int nbatch; float invN;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdArgs a) {
             }
         }
         // ---------------- scatter dc into the plane gradients (sample_plane_feature backward) ------------------
-        if (valid) {
+        if (valid && a.gplanes) {                 // gplanes == nullptr: this head is detached from the planes
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
                 float* gb = a.gplanes + pl * plane_stride + (size_t)b * RES * RES * CD;

@@ -25,6 +25,7 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 
 // 16x16 MFMA shapes: D row = 4*(lane>>4) + reg, column = lane&15; A[i=lane&15][k-slot lane>>4], B[k-slot][j=lane&15]
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4v mfma32_16(float a, float b, f32x4v c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

@@ -11,6 +11,12 @@
 
 namespace giga {
 
+#ifdef CI_TRACE   // diagnostic build: per-wave issue timeline of workgroup (0,0) into the yz partial buffer
+#define CI_T(idx) do { if (slab == 0 && b == 0 && lane == 0) reinterpret_cast<long long*>(yz_partial)[wave * 128 + (idx)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CI_T(idx) do {} while (0)
+#endif
+
 // ====================================================================================================
 // conv_in + ReLU + axis means.
 //   grid (NSLAB, B), block 512 = 8 waves = 4 iy-groups (10 rows each) x 2 channel halves.  The
@@ -60,8 +66,7 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
 
     // slice ix lives in ring slot (ix+1) & 3; out-of-range slices are zero.  Each thread moves up to 4
     // voxels of a slice (1600 = 3*512 + 64): global -> registers early, registers -> LDS late.
-    float pre[4];
-    auto fetch_slice = [&](int ix) {
+    auto fetch_slice = [&](int ix, float (&pre)[4]) {
         const bool in = ix >= 0 && ix < RES;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
             pre[q] = (in && i < RES * RES) ? vol[(size_t)ix * RES * RES + i] : 0.f;
         }
     };
-    auto commit_slice = [&](int ix) {
+    auto commit_slice = [&](int ix, const float (&pre)[4]) {
         float* dst = slices + ((ix + 1) & 3) * CI_SLICE;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -77,13 +82,24 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
             if (i < RES * RES) dst[(i / RES + 1) * CI_ROWSTRIDE + (i % RES + 1)] = pre[q];
         }
     };
-    fetch_slice(ix0 - 1); commit_slice(ix0 - 1);
-    fetch_slice(ix0);     commit_slice(ix0);
-    fetch_slice(ix0 + 1); commit_slice(ix0 + 1);
+    {   // the three slices of the first step: one round trip, not three
+        float p0[4], p1[4], p2[4];
+        fetch_slice(ix0 - 1, p0); fetch_slice(ix0, p1); fetch_slice(ix0 + 1, p2);
+        commit_slice(ix0 - 1, p0); commit_slice(ix0, p1); commit_slice(ix0 + 1, p2);
+    }
     __syncthreads();
 
     // A operand: row i = lane&15 is voxel (iy_l = i>>3, iz_l = 4*((i>>2)&1) + (i&3)); k-slot g supplies tap 4s+g
+    // (tap = dx*9 + dy*3 + dz; tap 27 has zero weight and reads tap 26's voxel).  abase[s] is loop-invariant;
+    // only the ring slot of the tap's dx changes per slice.
     const int a_base = (grp * 10 + (j >> 3)) * CI_ROWSTRIDE + 4 * ((j >> 2) & 1) + (j & 3);
+    int abase[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        int t = 4 * s + g;
+        t = t > 26 ? 26 : t;
+        abase[s] = a_base + ((t / 3) % 3) * CI_ROWSTRIDE + t % 3;
+    }
     f32x4v acc_yz[5][5];
 #pragma unroll
     for (int ip = 0; ip < 5; ++ip)
@@ -95,100 +111,144 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
     TOut* plane_xz = planes + ((size_t)0 * B + b) * img_stride;
     TOut* plane_xy = planes + ((size_t)1 * B + b) * img_stride;
     const int ch = 16 * chh + j;
+    const f32x4v bias4 = {bn, bn, bn, bn};            // the bias rides in the C operand of the first MFMA
+    const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
 
     for (int sx = 0; sx < SX; ++sx) {
         const int ix = ix0 + sx;
         // Hazards are covered by the single barrier below: the slot filled this iteration (slice ix+2)
         // was last read as slice ix-2 in the previous iteration; `red` alternates between two buffers.
         float* redw = red + (sx & 1) * CI_LDS_RED;
-        if (sx + 1 < SX) fetch_slice(ix + 2);        // global loads fly under this slice's MFMAs
+        float pre[4];
+        if (sx + 1 < SX) fetch_slice(ix + 2, pre);   // global loads fly under this slice's MFMAs
         const int o0 = ((ix + 0) & 3) * CI_SLICE, o1 = ((ix + 1) & 3) * CI_SLICE, o2 = ((ix + 2) & 3) * CI_SLICE;
-        // k-slot g supplies tap 4s+g (tap = dx*9 + dy*3 + dz, tap 27 has zero weight).  Recomputed per
-        // slice from an opaque copy of g so the 14 per-lane constants are not kept live (VGPR limit).
-        int gq = g;
-        asm volatile("" : "+v"(gq));
-        int aoff[7];
+        int addr[7];
 #pragma unroll
         for (int s = 0; s < 7; ++s) {
-            int t = 4 * s + gq;
-            t = t > 26 ? 26 : t;
-            const int dx = t / 9;
-            aoff[s] = a_base + ((t / 3) % 3) * CI_ROWSTRIDE + t % 3 + (dx == 0 ? o0 : dx == 1 ? o1 : o2);
+            const int lo = (4 * s) / 9, hi = (4 * s + 3 > 26 ? 26 : 4 * s + 3) / 9;    // dx of k-slots 0 and 3
+            const int olo = lo == 0 ? o0 : lo == 1 ? o1 : o2, ohi = hi == 0 ? o0 : hi == 1 ? o1 : o2;
+            addr[s] = abase[s] + (lo == hi ? olo : (4 * s + g >= 9 * hi ? ohi : olo));
         }
-        float sum_z[5];                   // per iy-pair: sum over the 5 iz-groups and the 4 in-lane iz
+        f32x2v sum_z[5];                  // per iy-pair: sum over the 5 iz-groups and the 4 in-lane iz (two partials)
 #pragma unroll
-        for (int ip = 0; ip < 5; ++ip) sum_z[ip] = 0.f;
+        for (int ip = 0; ip < 5; ++ip) sum_z[ip] = f32x2v{0.f, 0.f};
+        // Software pipeline over the 5 iz-groups.  Per group: five independent 7-MFMA chains (the iy-pairs).
+        // A operands of MFMA steps 0..2 are loaded one group ahead (P), those of steps 3..6 at the top of the
+        // group (Q) under the first 15 MFMAs, so no LDS round trip is exposed.  The 35 MFMAs stay one
+        // uninterrupted burst: an extra issue slot between MFMAs costs far more than the slot itself, and the
+        // ReLU / axis-sum epilogue (packed adds) runs as its own burst under the sibling wave's MFMAs.
+        float P[3][5], Q[4][5];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int ip = 0; ip < 5; ++ip) P[s][ip] = slices[addr[s] + 2 * ip * CI_ROWSTRIDE];
+        CI_T(sx * 16 + 0);
 #pragma unroll
         for (int zg = 0; zg < 5; ++zg) {
-            float part_y[4] = {0.f, 0.f, 0.f, 0.f};   // per r: sum over the 5 iy-pairs of this group
+            f32x4v d[5];
 #pragma unroll
-            for (int ip = 0; ip < 5; ++ip) {
-                f32x4v d = {0.f, 0.f, 0.f, 0.f};
+            for (int s = 3; s < 7; ++s)
 #pragma unroll
-                for (int s = 0; s < 7; ++s)
-                    d = mfma32_16(slices[aoff[s] + 2 * ip * CI_ROWSTRIDE + 8 * zg], wreg[s], d);
+                for (int ip = 0; ip < 5; ++ip) Q[s - 3][ip] = slices[addr[s] + 2 * ip * CI_ROWSTRIDE + 8 * zg];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = relu(d[r] + bn);
-                    acc_yz[ip][zg][r] += v;
-                    sum_z[ip] += v;
-                    part_y[r] += v;
-                }
-                // two independent 7-MFMA chains in flight cover the 40-cycle latency of the 32-cycle
-                // 16x16x4 MFMA; more only multiplies the live A operands (the kernel is VGPR-bound)
-                if (ip & 1) __builtin_amdgcn_sched_barrier(0);
-            }
-            // plane xz [iz][ix][c]: the other iy row of each tile lives in lane^32; 4 groups go through LDS
+            for (int s = 0; s < 3; ++s)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = part_y[r] + __shfl_xor(part_y[r], 32);
-                if ((g >> 1) == 0) redw[(grp * 40 + 8 * zg + 4 * (g & 1) + r) * 32 + ch] = v;
+                for (int ip = 0; ip < 5; ++ip) d[ip] = mfma32_16(P[s][ip], wreg[s], s == 0 ? bias4 : d[ip]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (zg + 1 < 5) {
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#pragma unroll
+                    for (int ip = 0; ip < 5; ++ip)
+                        P[s][ip] = slices[addr[s] + 2 * ip * CI_ROWSTRIDE + 8 * (zg + 1)];
             }
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 3; s < 7; ++s)
+#pragma unroll
+                for (int ip = 0; ip < 5; ++ip) d[ip] = mfma32_16(Q[s - 3][ip], wreg[s], d[ip]);
+            __builtin_amdgcn_sched_barrier(0);
+            CI_T(sx * 16 + 1 + 2 * zg);
+            f32x4v part_y = zero4;            // per r: sum over the 5 iy-pairs of this group
+#pragma unroll
+            for (int ip = 0; ip < 5; ++ip) {
+                const f32x4v v = __builtin_elementwise_max(d[ip], zero4);
+                acc_yz[ip][zg] += v;
+                sum_z[ip] += f32x2v{v[0], v[1]} + f32x2v{v[2], v[3]};
+                part_y += v;
+            }
+            // plane xz [iz][ix][c]: the other iy row of each tile lives in lane^32; 4 groups go through LDS
+            float other[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) other[r] = __shfl_xor(part_y[r], 32);       // four exchanges, one wait
+            if ((g >> 1) == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    redw[(grp * 40 + 8 * zg + 4 * (g & 1) + r) * 32 + ch] = part_y[r] + other[r];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            CI_T(sx * 16 + 2 + 2 * zg);
         }
         // plane xy [iy][ix][c]: other half of the 8 iz of each tile lives in lane^16
 #pragma unroll
         for (int ip = 0; ip < 5; ++ip) {
-            const float s = sum_z[ip] + __shfl_xor(sum_z[ip], 16);
+            const float sl = sum_z[ip][0] + sum_z[ip][1];
+            const float sm = sl + __shfl_xor(sl, 16);
             if ((g & 1) == 0) {
                 const int iy = grp * 10 + 2 * ip + (g >> 1);
-                plane_xy[((size_t)iy * RES + ix) * CD + ch] = (TOut)(s * inv);
+                plane_xy[((size_t)iy * RES + ix) * CD + ch] = (TOut)(sm * inv);
             }
         }
-        if (sx + 1 < SX) commit_slice(ix + 2);
+        if (sx + 1 < SX) commit_slice(ix + 2, pre);
+        CI_T(sx * 16 + 11);
         __syncthreads();
+        CI_T(sx * 16 + 12);
         // the fixed-order sum of the 4 iy-groups is done by ONE half of the waves (alternating per slice):
         // the sibling wave of every SIMD goes straight on to the next slice's MFMAs
         if ((wave >> 2) == (sx & 1)) {
             for (int i = tid & 255; i < 40 * 32; i += 256) {
-                const float s = (redw[i] + redw[1280 + i]) + (redw[2560 + i] + redw[3840 + i]);
+                const float sr = (redw[i] + redw[1280 + i]) + (redw[2560 + i] + redw[3840 + i]);
                 const int iz = i >> 5, c = i & 31;
-                plane_xz[((size_t)iz * RES + ix) * CD + c] = (TOut)(s * inv);
+                plane_xz[((size_t)iz * RES + ix) * CD + c] = (TOut)(sr * inv);
             }
         }
+        CI_T(sx * 16 + 13);
     }
-    // plane yz partial [iz][iy][c] for this slab
-    float* part = yz_partial + ((size_t)slab * B + b) * img_stride;
+#ifdef CI_TRACE
+    return;
+#endif
+    // plane yz partial of this slab, in the kernel's own register order so that every store is one fully
+    // coalesced 16 B per lane: [slab][b][wave][unit = ip*5+zg][lane][r]; plane_finalize_kernel undoes the map.
+    f32x4v* part = reinterpret_cast<f32x4v*>(yz_partial + ((size_t)slab * B + b) * img_stride) + (size_t)wave * 25 * 64 + lane;
 #pragma unroll
     for (int ip = 0; ip < 5; ++ip)
 #pragma unroll
-        for (int zg = 0; zg < 5; ++zg)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int iz = 8 * zg + 4 * (g & 1) + r, iy = grp * 10 + 2 * ip + (g >> 1);
-                part[((size_t)iz * RES + iy) * CD + ch] = acc_yz[ip][zg][r];
-            }
+        for (int zg = 0; zg < 5; ++zg) part[(ip * 5 + zg) * 64] = acc_yz[ip][zg];
 }
 
 template <typename TOut>
 __global__ void plane_finalize_kernel(const float* __restrict__ yz_partial, TOut* __restrict__ planes, int B,
                                       int nslab) {
+    // one thread per (scene, iy, group of 4 iz, channel): a 16-B read per slab in convin_project's register
+    // order (see the store at its end), fixed-order sum over the slabs, four channel-contiguous row writes
     const size_t per = (size_t)B * RES * RES * CD;          // elements of one plane over the batch
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= per) return;
-    float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += yz_partial[(size_t)k * per + i];
-    planes[2 * per + i] = (TOut)(s * (1.0f / RES));
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= per / 4) return;
+    const int c = (int)(t % CD);
+    const int izq = (int)((t / CD) % 10);
+    const int iy = (int)((t / (CD * 10)) % RES);
+    const size_t b = t / ((size_t)CD * 10 * RES);
+    const int iyl = iy % 10;
+    const int wave = (iy / 10) * 2 + c / 16;
+    const int unit = (iyl / 2) * 5 + izq / 2;
+    const int lane = ((iyl & 1) * 2 + (izq & 1)) * 16 + (c & 15);
+    const f32x4v* src = reinterpret_cast<const f32x4v*>(yz_partial) + (b * 8 + wave) * 25 * 64 + unit * 64 + lane;
+    f32x4v sum = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nslab; ++k) sum += src[(size_t)k * (per / 4)];
+    TOut* dst = planes + 2 * per + ((b * RES + 4 * izq) * RES + iy) * CD + c;      // [iz][iy][c]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[(size_t)r * RES * CD] = (TOut)(sum[r] * (1.0f / RES));
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -250,7 +310,7 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     {
         pre();
         const size_t per = (size_t)B * RES * RES * CD;
-        hipLaunchKernelGGL(plane_finalize_kernel<T>, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, s, YZ, P0, B,
+        hipLaunchKernelGGL(plane_finalize_kernel<T>, dim3((unsigned)((per / 4 + 255) / 256)), dim3(256), 0, s, YZ, P0, B,
                            nslab);
         post();
     }

@@ -23,7 +23,8 @@ RES, C_DIM = 40, 32
 class _TrainState:
     """Per-module device state: gather maps and the two weight images."""
 
-    def __init__(self, head_present, device):
+    def __init__(self, head_present, device, detach_occ=False):
+        self.bwd_flags = _capi.DETACH_OCC if detach_occ else 0     # detach_tsdf (models/__init__.py:61-63)
         L = _capi.lib()
         self.head_present = head_present
         self.map_fwd = _capi.pack_map(head_present).to(device)
@@ -110,7 +111,7 @@ class GigaFunction(torch.autograd.Function):
         _capi.check(L.giga_backward(
             _capi.ptr(x), _capi.ptr(state.blob), _capi.ptr(state.bwd_blob), _capi.ptr(ws), _capi.ptr(nhwc),
             _capi.ptr(p), _capi.ptr(p_tsdf), _ptr_array(outs), _ptr_array(douts), _capi.ptr(grads),
-            grads.numel(), state.head_present, B, N, M, _capi.ptr(wsb), wsb.numel(), _capi.stream_ptr()),
+            grads.numel(), state.head_present | state.bwd_flags, B, N, M, _capi.ptr(wsb), wsb.numel(), _capi.stream_ptr()),
             "giga_backward")
         if state.data_parallel:
             allreduce_mean_(grads, state.group)

@@ -116,11 +116,15 @@ int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, cons
  *   outs / douts : arrays of 4 device pointers (qual [B*N], rot [B*N][4], width [B*N], occ [B*M]); entries of
  *                  absent heads are ignored.  outs are the forward results (post sigmoid / normalize).
  *   grads        : flat fp32 buffer in reference state-dict order (giga_param_count), overwritten.
+ *   head_present : head bits, optionally | GIGA_DETACH_OCC: the occupancy head then reads detached planes, i.e. its
+ *                  loss does not reach the encoder (detach_tsdf of `giga_detach`, models/__init__.py:61-63,
+ *                  networks.py:143-169); the three grasp heads are unaffected.
  * It replaces autograd through conv_onet/models/__init__.py:42-67 (decoder.py:117-176, encoder/voxels.py:89-121,
  * encoder/unet.py:225-239).  Data-gradient convolutions and the decoder's gradient chain run on MFMA with the
  * transposed weights of the BACKWARD blob (giga_bwd_packed_bytes / giga_pack_bwd_weights, host; or
  * giga_pack_bwd_map + giga_repack_device on the device every step).  Weight gradients are reduced with fp32
  * atomics (run-to-run differences at rounding level, as in PyTorch's own GPU backward). */
+#define GIGA_DETACH_OCC 16
 size_t giga_bwd_packed_bytes(void);
 int giga_pack_bwd_weights(const float* params_host, size_t n_params, int head_present, void* packed_host,
                           size_t packed_bytes);

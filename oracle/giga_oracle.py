@@ -166,11 +166,13 @@ def decode(sd, p, planes):
     return qual, rot, width
 
 
-def model_forward(sd, x, p, p_tsdf=None):
-    """ConvolutionalOccupancyNetwork.forward models/__init__.py:42-67 (tsdf = raw logits)."""
+def model_forward(sd, x, p, p_tsdf=None, detach_tsdf=False):
+    """ConvolutionalOccupancyNetwork.forward models/__init__.py:42-67 (tsdf = raw logits; detach_tsdf :61-63)."""
     planes = encoder_forward(sd, x)
     out = decode(sd, p, planes)
     if p_tsdf is not None:
+        if detach_tsdf:
+            planes = {k: v.detach() for k, v in planes.items()}
         out = out + (decoder_forward(sd, "decoder_tsdf", p_tsdf, planes),)
     return out
 

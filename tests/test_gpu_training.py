@@ -21,9 +21,9 @@ def _batch(first, B, M):
     return x, pos, pos_occ, y
 
 
-def _oracle_grads(sd, x, pos, pos_occ, y):
+def _oracle_grads(sd, x, pos, pos_occ, y, detach_tsdf=False):
     sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    out = O.model_forward(sdg, x, pos, p_tsdf=pos_occ)
+    out = O.model_forward(sdg, x, pos, p_tsdf=pos_occ, detach_tsdf=detach_tsdf)
     loss, d = O.train_loss(O.train_select(out), y)
     loss.backward()
     return loss.item(), {k: v.grad for k, v in sdg.items()}, d
@@ -57,6 +57,28 @@ def test_train_step_gradients_match_oracle_and_g4(golden, sd7):
     got_norms = {n: p.grad.double().norm().item() for n, p in net.named_parameters()}
     for n, ref in zip(names, g4["grad_norms"]):
         assert abs(got_norms[n] - ref) <= 2e-3 * max(ref, 1e-6) + 1e-8, (n, got_norms[n], ref)
+
+
+def test_giga_detach_gradients(sd7):
+    """giga_detach (networks.py:143-169): the occupancy loss must not reach the encoder; the heads are unchanged."""
+    dev = torch.device("cuda:0")
+    x, pos, pos_occ, y = _batch(50, 3, 257)
+    ref_loss, ref_grads, _ = _oracle_grads(sd7, x, pos, pos_occ, y, detach_tsdf=True)
+    _, attached, _ = _oracle_grads(sd7, x, pos, pos_occ, y)
+    net = networks.get_network("giga_detach")
+    net.load_state_dict(sd7)
+    net = net.to(dev).train()
+    loss, _ = loss_fn(select(net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev))), tuple(t.to(dev) for t in y))
+    assert abs(loss.item() - ref_loss) < 1e-5
+    loss.backward()
+    differs = 0
+    for name, prm in net.named_parameters():
+        ref, got = ref_grads[name], prm.grad.detach().cpu()
+        scale = ref.abs().max().item()
+        assert (got - ref).abs().max().item() <= 2e-3 * scale + 1e-6, name
+        if name.startswith("encoder.") and (attached[name] - ref).abs().max().item() > 1e-2 * scale:
+            differs += 1
+    assert differs > 0          # the detached and attached encoder gradients really are different
 
 
 def test_sgd_steps_track_the_oracle(sd7):
