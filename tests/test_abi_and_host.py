@@ -163,3 +163,10 @@ def test_load_network_round_trip(tmp_path, sd7):
     net = networks.load_network(path, "cpu")              # model name parsed from the stem (networks.py:28-31)
     for k, v in net.state_dict().items():
         assert torch.equal(v, sd7[k])
+
+
+def test_feed_and_generation_have_no_cpu_path():
+    from giga_amd._capi import GigaHipError
+    from giga_amd.feed import TSDFFeed
+    with pytest.raises(GigaHipError):
+        TSDFFeed([], device="cpu")

@@ -209,3 +209,42 @@ def test_variants_aff_geo(dev):
         occ = geo.decode_occ(p.to(dev), geo.encode_inputs(x.to(dev)))
     assert maxerr(t, ref_t) < 1e-4
     assert maxerr(occ.logits, ref_t) < 1e-4
+
+
+@pytest.mark.gpu
+def test_generation_eval_points_and_grid(sd7):
+    """encode once, query occupancy many times (generation.py:326-358) == oracle decoder_tsdf."""
+    from giga_amd.generation import Generator3D
+    dev = torch.device("cuda:0")
+    net = networks.get_network("giga")
+    net.load_state_dict(sd7)
+    net = net.to(dev).eval()
+    gen = Generator3D(net, device=dev)
+    x = torch.from_numpy(synth.tsdf_batch(70, 2))
+    c = gen.encode(x)
+    planes = O.encoder_forward(sd7, x)
+    for rnd, n in enumerate((1, 777, 4096)):               # MISE-like rounds on the cached planes
+        p = torch.from_numpy(synth.query_points(70, 2, n, stream=10 + rnd, half_width=0.55))
+        ref = O.decoder_forward(sd7, "decoder_tsdf", p, planes)
+        got = gen.eval_points(p, c).cpu()
+        assert got.shape == ref.shape
+        assert (got - ref).abs().max().item() < 1e-4
+    one = gen.eval_points(p[0], {k: v[:1] for k, v in c.items()}).cpu()      # (N,3) form, reference-style dict
+    assert (one - ref[0]).abs().max().item() < 1e-4
+    grid = gen.occupancy_grid(c, resolution=16).cpu()
+    ref_grid = O.decoder_forward(sd7, "decoder_tsdf", gen.grid_points(16).cpu().expand(2, -1, -1), planes)
+    assert (grid.reshape(2, -1) - ref_grid).abs().max().item() < 1e-4
+
+
+@pytest.mark.gpu
+def test_tsdf_feed_pinned_double_buffer(sd7):
+    """the pinned, double-buffered H->D feed delivers every batch intact and in order."""
+    from giga_amd.feed import TSDFFeed
+    dev = torch.device("cuda:0")
+    host = [(synth.tsdf_batch(10 * i, 3)[:, None], torch.from_numpy(synth.query_points(10 * i, 3, 5))) for i in range(5)]
+    seen = 0
+    for i, (xb, pb) in enumerate(TSDFFeed(host, dev)):
+        assert xb.is_cuda and pb.is_cuda and xb.shape == (3, 1, 40, 40, 40)
+        assert torch.equal(xb.cpu(), torch.from_numpy(host[i][0])) and torch.equal(pb.cpu(), host[i][1])
+        seen += 1
+    assert seen == 5
