@@ -61,7 +61,13 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16_kernel(DecArgs a) {
     const int n = lane & 31, hi = lane >> 5;
     const half_t* planes = reinterpret_cast<const half_t*>(a.planes);
     const size_t plane_stride = LATTICE ? (size_t)a.B * a.R * a.R * CD : (size_t)a.B * RES * RES * CD;
-    const int rounds = (a.nbatch - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // Every workgroup owns one contiguous, equally sized range of 32-point tiles and walks it in rounds of NW*T
+    // tiles, so the ragged last round is a PARTIAL round on every CU (fewer active waves per SIMD) instead of a
+    // full extra round on some CUs while the others idle.
+    const long long tiles_total = (a.P + 31) / 32;
+    const long long tile_lo = tiles_total * blockIdx.x / gridDim.x;
+    const long long tile_hi = tiles_total * (blockIdx.x + 1) / gridDim.x;
+    const int rounds = (int)((tile_hi - tile_lo + NW * T - 1) / (NW * T));
     if (rounds <= 0) return;
     // Step s uses the weight image of head s % nheads.  Waves 4..7 (the second wave of every SIMD) run
     // one step behind waves 0..3 and visit the heads in rotated order (1,2,..,0): while one wave of a
@@ -93,12 +99,14 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16_kernel(DecArgs a) {
         const uint8_t* dma_src = a.blob + a.head_off[(s + 1) % a.nheads];
         uint8_t* dma_dst = smem + ((s + 1) & 1) * DEC16_BYTES;
         const int ls = s - phase;                             // this wave's own step counter
-        if (ls < 0 || ls >= work_steps) {                     // idle edge step of the staggered half
+        // first tile of this wave in its current round; a wave without tiles (staggered edge step, or the
+        // ragged last round) only keeps the image pipeline going
+        const long long tile0 = tile_lo + ((long long)(ls / a.nheads) * NW + wave) * T;
+        if (ls < 0 || ls >= work_steps || tile0 >= tile_hi) {
             if (dma_next) dma_head_image<NW>(dma_src, dma_dst, wave, lane);
             continue;
         }
         const bool new_round = ls % a.nheads == 0;
-        const int batch = (int)blockIdx.x + (ls / a.nheads) * (int)gridDim.x;
         if (LATTICE && new_round) {
             // ---------------- lattice gather: the planes were resampled at the R lattice coordinates
             // (lattice_resample_kernel), so the 96 features of lattice point (ix,iy,iz) are three
@@ -106,8 +114,8 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16_kernel(DecArgs a) {
             const int R = a.R, R2 = R * R;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                long long g = ((long long)batch * NW * T + wave * T + t) * 32 + n;
-                valid[t] = g < a.P;
+                long long g = (tile0 + t) * 32 + n;
+                valid[t] = tile0 + t < tile_hi && g < a.P;
                 if (!valid[t]) g = a.P - 1;
                 gidx[t] = g;
                 int b, r;
@@ -138,8 +146,8 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16_kernel(DecArgs a) {
             float pxs[T], pys[T], pzs[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) {                    // all coordinate loads first: one round trip
-                long long g = ((long long)batch * NW * T + wave * T + t) * 32 + n;
-                valid[t] = g < a.P;
+                long long g = (tile0 + t) * 32 + n;
+                valid[t] = tile0 + t < tile_hi && g < a.P;
                 if (!valid[t]) g = a.P - 1;
                 gidx[t] = g;
                 pxs[t] = a.p[3 * g + 0]; pys[t] = a.p[3 * g + 1]; pzs[t] = a.p[3 * g + 2];
