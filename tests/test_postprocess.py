@@ -98,3 +98,30 @@ def test_device_postprocess_batched_and_edges():
     idx, sc = post_oracle.select_indices(tq)
     assert len(sel[0]["score"]) == len(sc) == 36 * 36 * 33
     assert np.array_equal(np.sort(sel[0]["index"].view("i8,i8,i8"), axis=0), np.sort(idx.astype(np.int64).view("i8,i8,i8"), axis=0))
+
+
+@pytest.mark.gpu
+def test_planner_hipgraph_replay_matches_eager(sd7):
+    """VGNImplicit(use_graph=True) replays the network as one hipGraph; results must equal the eager launches,
+    also when the input changes between replays."""
+    from giga_amd import networks
+    from giga_amd.detection import VGNImplicit
+    dev = torch.device("cuda:0")
+    net = networks.get_network("giga")
+    net.load_state_dict(sd7)
+    net = net.to(dev).eval()
+    kw = dict(net=net, force_detection=True, qual_th=0.6, out_th=0.1, best=True)
+    eager, graphed = VGNImplicit(None, "giga", **kw), VGNImplicit(None, "giga", use_graph=True, **kw)
+
+    class State:
+        pass
+    for scene in (0, 1, 2, 0):
+        st = State()
+        st.tsdf = synth.tsdf_batch(scene, 1, realistic=True)
+        ga, sa, _ = eager(st)
+        gb, sb, _ = graphed(st)
+        assert len(ga) == len(gb) and len(ga) > 0
+        assert np.array_equal(sa, sb)
+        for a, b in zip(ga, gb):
+            assert np.array_equal(a["rotation"], b["rotation"]) and np.array_equal(a["translation"], b["translation"])
+            assert a["width"] == b["width"]

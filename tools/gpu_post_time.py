@@ -24,9 +24,10 @@ for B in (1, 32):
 net = get_network("giga").to(dev)
 net.load_state_dict(make_state_dict(7))
 net.eval()
-for prec in ("fp32", "fp16"):
+import itertools
+for prec, graph in itertools.product(("fp32", "fp16"), (False, True)):
     net.set_precision(prec)
-    planner = VGNImplicit(None, "giga", net=net, force_detection=True, qual_th=0.6, out_th=0.1, best=True)
+    planner = VGNImplicit(None, "giga", net=net, force_detection=True, qual_th=0.6, out_th=0.1, best=True, use_graph=graph)
     class S: pass
     s = S(); s.tsdf = synth.tsdf_batch(0, 1, realistic=True)
     for _ in range(3):
@@ -35,7 +36,7 @@ for prec in ("fp32", "fp16"):
     for _ in range(20):
         g, sc, toc = planner(s)
     dt = (time.time() - t0) / 20
-    print(f"VGNImplicit.__call__ {prec}: {dt*1e3:.3f} ms/plan, {len(g)} grasps")
+    print(f"VGNImplicit.__call__ {prec} graph={graph}: {dt*1e3:.3f} ms/plan, {len(g)} grasps, best score {sc[0]:.6f}")
     tb = torch.from_numpy(synth.tsdf_batch(0, 32, realistic=True)).to(dev)
     for _ in range(3):
         planner.plan_batch(tb)
@@ -43,4 +44,4 @@ for prec in ("fp32", "fp16"):
     for _ in range(10):
         planner.plan_batch(tb)
     torch.cuda.synchronize(); dt = (time.time() - t0) / 10
-    print(f"plan_batch B=32 {prec}: {dt*1e3:.3f} ms ({32/dt:.0f} scenes/s)")
+    print(f"plan_batch B=32 {prec} graph={graph}: {dt*1e3:.3f} ms ({32/dt:.0f} scenes/s)")
