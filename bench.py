@@ -157,9 +157,25 @@ def main():
     T = float(t_elapsed.item())
     scenes_per_s = total_scenes / T
 
-    if rank != 0:
+    # -------- extra at N > 1: the data-parallel training step of BASELINE c5 (every rank takes part) ----------
+    dp_train = None
+    if dist is not None and not args.no_extra:
+        try:
+            net.enable_data_parallel()
+            dp_train = bench_train(net, dev, synth, B, M, rank=rank, world=world)
+        except Exception as e:  # noqa: BLE001
+            dp_train = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            net.enable_data_parallel(enabled=False)
+            net.eval().set_precision("fp32")
+
+    def finish():                          # every rank leaves together: no rank tears the communicator down early
         if dist is not None:
+            dist.barrier()
             dist.destroy_process_group()
+
+    if rank != 0:
+        finish()
         return
 
     # HBM bytes per launch of the dominant kernel: PMC counters cannot be collected from inside this process,
@@ -206,8 +222,11 @@ def main():
         "decoder_occ_ms": round(dec_ms_once, 4),
     }
 
-    # -------- extra: c4 (64 000 grasp queries per scene, f16 MFMA fused decoder) ------------------------
-    if not args.no_extra:
+    if dp_train is not None:
+        out["extra"] = {"c5_train_step_fp32_data_parallel": dp_train}
+    # -------- extra: c4 (64 000 grasp queries per scene, f16 MFMA fused decoder); single-GPU runs only ----
+    single = dist is None
+    if single and not args.no_extra:
         try:
             out["extra"] = {"c4": bench_c4(net, sd, dev, L, _capi, synth, decode_heads)}
             # BASELINE c4 is a sweep over the scenes per GPU; the decoder's MFMA fraction per batch size
@@ -222,18 +241,17 @@ def main():
             out["extra"] = {"c4_error": f"{type(e).__name__}: {e}"}
 
     # -------- extra: c5-shaped training step (fp32 here; BASELINE c5 names bf16 -- see DESIGN.md) -----------
-    if not args.no_extra:
+    if single and not args.no_extra:
         try:
             out["extra"]["c5_train_step_fp32"] = bench_train(net, dev, synth, B, M)
         except Exception as e:  # noqa: BLE001
             out["extra"]["c5_error"] = f"{type(e).__name__}: {e}"
 
     # -------- CPU baseline: the oracle (port of the reference path) on the host cores -------------------
-    if not args.no_cpu_baseline:
+    if single and not args.no_cpu_baseline:               # rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(sd, synth, M)
-    print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    print(json.dumps(out), flush=True)
+    finish()
 
 
 def bench_c4(net, sd, dev, L, _capi, synth, decode_heads, Bc=32, steps=10):
@@ -280,14 +298,19 @@ def bench_c4(net, sd, dev, L, _capi, synth, decode_heads, Bc=32, steps=10):
     }
 
 
-def bench_train(net, dev, synth, B, M, steps=10):
+def bench_train(net, dev, synth, B, M, steps=10, rank=0, world=1):
+    """One optimisation step of scripts/train_giga.py:198-211 on this rank's scenes.  world > 1: the backward
+    all-reduces (means) the flat gradient bucket over RCCL (net.enable_data_parallel), BASELINE config c5."""
     from giga_amd.training import loss_fn, select
     net.set_precision("fp32").train()
-    x = torch.from_numpy(synth.tsdf_batch(2000, B)).to(dev)
-    pos = torch.from_numpy(synth.query_points(2000, B, 1, stream=2)).to(dev)
-    pos_occ = torch.from_numpy(synth.query_points(2000, B, M, stream=3)).to(dev)
-    y = tuple(torch.from_numpy(a).to(dev) for a in synth.train_labels(2000, B, M))
-    opt = torch.optim.Adam(net.parameters(), lr=2e-4)
+    first = 2000 + rank * B
+    x = torch.from_numpy(synth.tsdf_batch(first, B)).to(dev)
+    pos = torch.from_numpy(synth.query_points(first, B, 1, stream=2)).to(dev)
+    pos_occ = torch.from_numpy(synth.query_points(first, B, M, stream=3)).to(dev)
+    y = tuple(torch.from_numpy(a).to(dev) for a in synth.train_labels(first, B, M))
+    # the reference's optimiser (train_giga.py:49: Adam, lr 2e-4) in torch's single-launch form; the default
+    # per-tensor foreach path costs 6 ms of host time per step for the 98 parameter tensors
+    opt = torch.optim.Adam(net.parameters(), lr=2e-4, fused=True)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -305,9 +328,10 @@ def bench_train(net, dev, synth, B, M, steps=10):
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / steps
     net.eval()
-    return {"workload": f"joint GIGA training step (train_giga.py:198-211): B={B} scenes, 1 grasp query + {M} "
-                        "occupancy queries, forward + HIP backward + torch Adam, fp32, 1 GPU",
-            "ms_per_step": el * 1e3, "scenes_per_sec": B / el, "final_loss": float(loss)}
+    return {"workload": f"joint GIGA training step (train_giga.py:198-211): B={B} scenes/GPU, 1 grasp query + {M} "
+                        f"occupancy queries, forward + HIP backward + fused Adam, fp32, {world} GPU"
+                        + (", one RCCL all-reduce of the flat gradient bucket per step" if world > 1 else ""),
+            "ms_per_step": el * 1e3, "scenes_per_sec": world * B / el, "final_loss": float(loss.detach())}
 
 
 def cpu_baseline(sd, synth, M, budget_s=20.0):

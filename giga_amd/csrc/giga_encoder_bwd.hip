@@ -77,7 +77,8 @@ struct WgradArgs {
 
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     __shared__ float red[3][64][17];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, hi = lane >> 5;
     int b = blockIdx.x;
     const int nb = b % a.Nb; b /= a.Nb;
@@ -93,6 +94,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int HW = a.H * a.W;
     const int ky = a.kind == CONV3 ? tap / 3 - 1 : 0, kx = a.kind == CONV3 ? tap % 3 - 1 : 0;
 
+    // fp32 MFMA shares the VALU, so the loop keeps per-load vector work at zero: W is even, hence a pixel pair
+    // (p even, p+1) never straddles a row and the pair's (image, row, column) are wave-uniform SALU values; the
+    // per-lane part of every address (odd pixel of the pair for the upper lane half, channel) is loop-invariant.
+    const int laneR = hi * a.csR + a.coR + mb * 32 + i;
+    const int laneC = (a.kind == UPCONV ? 2 * hi : hi) * csC + cn;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -101,19 +107,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         float av[4], bv[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const long long p = base + 2 * s + hi;
+            const long long pe = base + 2 * s;                    // even pixel of the pair (uniform)
             float x = 0.f, y = 0.f;
-            if (p < p1) {
-                x = a.R[(size_t)p * a.csR + a.coR + mb * 32 + i];
-                const int img = div_magic((int)p, a.mHW), rem = (int)p - img * HW;
+            if (pe < p1) {                                        // npix and the block ranges are even
+                x = a.R[(size_t)pe * a.csR + laneR];
+                const int img = div_magic((int)pe, a.mHW), rem = (int)pe - img * HW;
                 const int py = div_magic(rem, a.mW), px = rem - py * a.W;
                 if (a.kind == UPCONV) {
                     const size_t q = ((size_t)img * 2 * a.H + 2 * py + (tap >> 1)) * (2 * a.W) + 2 * px + (tap & 1);
-                    y = Cc[q * csC + cn];
+                    y = Cc[q * csC + laneC];
                 } else {
-                    const int qy = py + ky, qx = px + kx;
-                    if (qy >= 0 && qy < a.H && qx >= 0 && qx < a.W)
-                        y = Cc[((size_t)img * HW + qy * a.W + qx) * csC + cn];
+                    const int qy = py + ky, qx = px + kx;         // column of the even pixel's tap
+                    const bool row_in = qy >= 0 && qy < a.H;
+                    const bool lo_ok = qx >= 0, hi_ok = qx + 1 < a.W;       // uniform; qx+1 >= 0 and qx < W always
+                    if (row_in && (hi ? hi_ok : lo_ok))
+                        y = Cc[((long long)img * HW + qy * a.W + qx) * csC + laneC];
                 }
             }
             av[s] = x; bv[s] = y;

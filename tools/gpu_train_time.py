@@ -1,0 +1,30 @@
+"""Wall-clock breakdown of one training step (B=32, 1 grasp + 2048 occupancy queries): host-side time of each
+phase (launch/Python cost) and the synchronized time."""
+import time
+import torch
+from giga_amd import networks, synth, weights
+from giga_amd.training import loss_fn, select
+
+dev = torch.device("cuda:0")
+net = networks.get_network("giga"); net.load_state_dict(weights.make_state_dict(7)); net = net.to(dev).train()
+B, M = 32, 2048
+x = torch.from_numpy(synth.tsdf_batch(0, B)).to(dev); pos = torch.from_numpy(synth.query_points(0, B, 1, stream=2)).to(dev)
+pos_occ = torch.from_numpy(synth.query_points(0, B, M, stream=3)).to(dev)
+y = tuple(torch.from_numpy(a).to(dev) for a in synth.train_labels(0, B, M))
+for fused in (False, True):
+    opt = torch.optim.Adam(net.parameters(), lr=2e-4, fused=fused)
+    acc = {}
+    def tick(name, t0, sync):
+        if sync: torch.cuda.synchronize()
+        acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
+    for sync in (False, True):
+        acc.clear()
+        for it in range(13):
+            if it == 3: acc.clear(); torch.cuda.synchronize(); T0 = time.perf_counter()
+            t = time.perf_counter(); opt.zero_grad(set_to_none=True); tick("zero_grad", t, sync)
+            t = time.perf_counter(); out = net(x, pos, p_tsdf=pos_occ); tick("forward", t, sync)
+            t = time.perf_counter(); loss, _ = loss_fn(select(out), y); tick("loss", t, sync)
+            t = time.perf_counter(); loss.backward(); tick("backward", t, sync)
+            t = time.perf_counter(); opt.step(); tick("adam", t, sync)
+        torch.cuda.synchronize(); total = (time.perf_counter() - T0) / 10
+        print(f"fused_adam={fused} sync_each_phase={sync}: step {total*1e3:.3f} ms | " + " ".join(f"{k} {v/10*1e3:.3f}" for k, v in acc.items()))
