@@ -32,9 +32,19 @@ struct ConvArgs {
     float* out_nchw;                     // optional fp32 NCHW copy (CONV1 only)
     int nimg;
     int cs0, co0, cs1, co1;              // channel stride / first channel of in0, in1 (0 stride = dense C0 / C1)
+    int trace_id;                        // layer index (diagnostic builds)
 };
 
 constexpr int CONV_NW = 12;       // waves per workgroup (3 per SIMD; VGPR use is < 80)
+
+#ifdef GIGA_TRACE   // diagnostic build: issue timeline (s_memtime) of workgroup 0 of the layer selected at run time
+static __device__ long long g_conv_trace[CONV_NW * 64];
+static __device__ int g_conv_trace_layer = -1;
+#define CONV_T(idx) do { if (blockIdx.x == 0 && lane == 0 && a.trace_id == g_conv_trace_layer && (idx) < 64) \
+        g_conv_trace[wave * 64 + (idx)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CONV_T(idx) do {} while (0)
+#endif
 
 // H, W are the OUTPUT-grid dimensions for DOWN (its input is 2H x 2W) and the input dimensions otherwise.
 template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL, bool RELU = (KIND == CONV3)>
@@ -65,6 +75,7 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv16_kernel(ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
     uint8_t* region = smem + (size_t)WFRAGS * FRAG + wave * REGION;
+    CONV_T(0);
 
     // ---- this workgroup's weight group -> LDS, once (LDS-DMA, 1 KiB per wave-instruction) ----------
     const int grp = blockIdx.x % NGRP, wg_in_grp = blockIdx.x / NGRP, wgs_per_grp = gridDim.x / NGRP;
@@ -76,10 +87,9 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv16_kernel(ConvArgs a) {
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(wsrc + (size_t)c * FRAG + lane * 16),
                 (__attribute__((address_space(3))) void*)(smem + c * FRAG), 16, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
     const uint4* wl = reinterpret_cast<const uint4*>(smem);
+    int tcount = 2;
 
     const int nwaves = wgs_per_grp * CONV_NW;
     const int units = a.nimg * TY * TX;
@@ -124,9 +134,16 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv16_kernel(ConvArgs a) {
 
     // global wave index = wave * (#workgroups) + workgroup: remainder units spread over all CUs/SIMDs
     int u = wave * wgs_per_grp + wg_in_grp;
+    // the first patch and the biases are requested while the weight fill is still in flight
+    if (u < units) issue_loads(u, 0);
+    float bias_r[NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) bias_r[n] = a.bias ? a.bias[(nb0 + n) * 16 + j] : 0.f;
+    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): weights (LDS-DMA), patch and biases landed
+    __syncthreads();
+    CONV_T(1);
     if (u >= units) return;
     int cc = 0;
-    issue_loads(u, 0);
     constexpr int NACC = NB == 1 ? 2 : 1;          // independent accumulator chains per channel block
     f32x4v acc[NB][NACC];
 #pragma unroll
@@ -139,37 +156,52 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv16_kernel(ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < NLD; ++q)
             if (st_lds[q] >= 0) *reinterpret_cast<uint4*>(region + st_lds[q]) = stg[q];
+        CONV_T(tcount); ++tcount;          // patch chunk in LDS (includes the wait for its global loads)
         // ---- prefetch the next chunk / next unit ---------------------------------------------------
         int un = u, ccn = cc + 1;
         if (ccn == NCHUNK) { un = u + nwaves; ccn = 0; }
         const bool more = un < units;
         if (more) issue_loads(un, ccn);
-        // ---- MFMA over taps x k-groups of this chunk: A from the patch, B from the resident weights --
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
+        // ---- MFMA over taps x k-groups of this chunk: A from the patch, B from the resident weights.  The
+        // operands of step i+3 are read from LDS right after the MFMAs of step i are issued (software pipeline), so a
+        // wave keeps the MFMA pipe fed on its own instead of relying on its two SIMD siblings to cover the
+        // LDS round trip (they are gone in the ragged last round).
+        constexpr int NIT = TAPS * KGC;
+        auto read_ops = [&](int it, uint4& av, uint4 (&bw)[NB]) {
+            const int tap = it / KGC, kg = it % KGC;
             const int toff = (KIND == DOWN ? ((tap >> 1) * LW + (tap & 1)) : ((tap / 3) * LW + (tap % 3))) * PS;
+            av = *reinterpret_cast<const uint4*>(region + a_off + toff + kg * 64);
 #pragma unroll
-            for (int kg = 0; kg < KGC; ++kg) {
-                const uint4 av = *reinterpret_cast<const uint4*>(region + a_off + toff + kg * 64);
-                uint4 bw[NB];
+            for (int n = 0; n < NB; ++n) bw[n] = wl[((n * TAPS + tap) * KGT + cc * KGC + kg) * 64 + lane];
+        };
+        // ring of PD operand sets: the LDS round trip of a 1 KiB ds_read_b128 is ~300 cycles, i.e. more than two
+        // groups of four 32-cycle MFMAs
+        constexpr int PD = NIT < 3 ? NIT : 3;
+        uint4 av_q[PD], bw_q[PD][NB];
 #pragma unroll
-                for (int n = 0; n < NB; ++n) bw[n] = wl[((n * TAPS + tap) * KGT + cc * KGC + kg) * 64 + lane];
-                if constexpr (ES == 2) {
+        for (int it = 0; it < PD; ++it) read_ops(it, av_q[it], bw_q[it]);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int kg = it % KGC, sl = it % PD;
+            if constexpr (ES == 2) {
+#pragma unroll
+                for (int n = 0; n < NB; ++n)
+                    acc[n][kg & (NACC - 1)] = mfma16_16(__builtin_bit_cast(half8, av_q[sl]),
+                                                        __builtin_bit_cast(half8, bw_q[sl][n]), acc[n][kg & (NACC - 1)]);
+            } else {
+                // 16x16x4 f32: 32-cycle issue, 40-cycle dependent latency -> alternate accumulators
+                const f32x4v A = __builtin_bit_cast(f32x4v, av_q[sl]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int n = 0; n < NB; ++n)
-                        acc[n][kg & (NACC - 1)] = mfma16_16(__builtin_bit_cast(half8, av), __builtin_bit_cast(half8, bw[n]),
-                                                            acc[n][kg & (NACC - 1)]);
-                } else {
-                    // 16x16x4 f32: 32-cycle issue, 40-cycle dependent latency -> alternate accumulators
-                    const f32x4v A = __builtin_bit_cast(f32x4v, av);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int n = 0; n < NB; ++n)
-                            acc[n][e & (NACC - 1)] = mfma32_16(A[e], __builtin_bit_cast(f32x4v, bw[n])[e], acc[n][e & (NACC - 1)]);
-                }
+                        acc[n][e & (NACC - 1)] = mfma32_16(A[e], __builtin_bit_cast(f32x4v, bw_q[sl][n])[e], acc[n][e & (NACC - 1)]);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (it + PD < NIT) read_ops(it + PD, av_q[sl], bw_q[sl]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        CONV_T(tcount); ++tcount;          // MFMAs of this chunk issued
         // ---- epilogue after the last chunk: lane holds cout j of quad g (4 pixels) ------------------
         if (cc == NCHUNK - 1) {
             int tx, ty, img;
@@ -180,7 +212,7 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv16_kernel(ConvArgs a) {
 #pragma unroll
             for (int n = 0; n < NB; ++n) {
                 const int co = (nb0 + n) * 16 + j;
-                const float bv = a.bias ? a.bias[co] : 0.f;
+                const float bv = bias_r[n];
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -215,6 +247,7 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv16_kernel(ConvArgs a) {
         if (!more) break;
         u = un; cc = ccn;
     }
+    CONV_T(63);
 }
 
 template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL, bool RELU = (KIND == CONV3)>

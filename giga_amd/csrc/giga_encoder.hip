@@ -323,6 +323,7 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
         ConvArgs a{};
         a.in0 = i0; a.in1 = i1; a.w = W_(l); a.bias = Bi(l); a.out = o; a.out_pool = op; a.out_nchw = nullptr;
         a.nimg = nimg;
+        a.trace_id = l;
         return a;
     };
     uint8_t* b = ws;
@@ -357,3 +358,11 @@ int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, fl
 }
 
 }  // namespace giga
+
+#ifdef GIGA_TRACE
+// diagnostic build only: select the traced U-Net layer (host_out == nullptr) or read the timeline back
+extern "C" int giga_debug_conv_trace(int layer, long long* host_out) {
+    if (!host_out) return hipMemcpyToSymbol(HIP_SYMBOL(giga::g_conv_trace_layer), &layer, sizeof(int)) == hipSuccess ? 0 : -10;
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(giga::g_conv_trace), sizeof(long long) * giga::CONV_NW * 64) == hipSuccess ? 0 : -10;
+}
+#endif
