@@ -14,7 +14,7 @@ size_t bwd_packed_bytes();
 int pack_bwd_host(const float* P, size_t n_params, int head_present, uint8_t* blob, size_t blob_bytes);
 int pack_bwd_map_host(int head_present, int32_t* map, size_t nwords);
 // giga_encoder_bwd.hip / giga_decoder_bwd.hip
-struct BwdWs { size_t gA6, gA5, gC1, gA4, gA3, gC0, gS2, gA2, gQ1, gS1, gA1, gQ0, gS0, gA0, gP0, total; };
+struct BwdWs { size_t gA6, gA5, gC1, gA4, gA3, gC0, gS2, gA2, gQ1, gS1, gA1, gQ0, gS0, gA0, gP0, WG, total; };
 BwdWs enc_bwd_workspace(int B);
 int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws,
                             float* gplanes, uint8_t* gws, float* grads, int head_present, int B, hipStream_t s);

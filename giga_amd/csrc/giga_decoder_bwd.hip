@@ -9,7 +9,8 @@
 //         G = DN[i+1];  DH[i] = (W1_i^T G) * (h_i > 0);  DN[i] = G + (W0_i^T DH[i]) * (net_i' > 0);  dc += Wc_i^T DN[i]
 //      in the same transposed layout (lane = point, registers = features), so again no cross-lane traffic;
 //   3. write the (dY, X) pairs of every linear layer to HBM as [point][32] rows and scatter dc into the
-//      plane gradients with the bilinear weights (fp32 atomics, like aten's grid_sampler backward).
+//      plane gradients with the bilinear weights (fp32 atomics, like aten's grid_sampler backward; transposed
+//      through LDS so that an atomic instruction touches 128-byte runs of channels).
 // linear_wgrad_kernel then reduces dW = dY^T X and db = colsum(dY) for all layers of a head in ONE launch
 // (MFMA 32x32x2 over pairs of points, operands straight from HBM, one atomic per gradient element per block).
 #include "giga_args.h"
@@ -277,20 +278,45 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdArgs a) {
             }
         }
         // ---------------- scatter dc into the plane gradients (sample_plane_feature backward) ------------------
-        if (valid && a.gplanes) {                 // gplanes == nullptr: this head is detached from the planes
+        // Every atomic instruction covers two (point, tap) pairs x 32 CONTIGUOUS channels (two 128-B runs) instead of
+        // 64 scattered words: float atomics are resolved outside the XCD-local L2, one fabric operation per touched
+        // line, so the transposition through LDS (the weight image is dead by now) cuts that traffic 16-fold.
+        if (a.gplanes) {                          // nullptr: this head is detached from the planes
+            __syncthreads();                      // every wave is done with the weight image
+            float* T = reinterpret_cast<float*>(smem) + wave * (32 * 96 + 32 * 12 * 2);    // [point][96] values
+            int* Q = reinterpret_cast<int*>(T + 32 * 96);                                   // [point][plane][tap] offsets
+            float* Wt = reinterpret_cast<float*>(Q + 32 * 12);                              // [point][plane][tap] weights
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
-                float* gb = a.gplanes + pl * plane_stride + (size_t)b * RES * RES * CD;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int c = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const float v = dc[pl][r];
-                    atomicAdd(gb + (size_t)bl[pl].o00 * CD + c, v * bl[pl].w00);
-                    atomicAdd(gb + (size_t)bl[pl].o01 * CD + c, v * bl[pl].w01);
-                    atomicAdd(gb + (size_t)bl[pl].o10 * CD + c, v * bl[pl].w10);
-                    atomicAdd(gb + (size_t)bl[pl].o11 * CD + c, v * bl[pl].w11);
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(T + n * 96 + pl * 32 + 8 * q + 4 * hi) =
+                        make_float4(dc[pl][4 * q], dc[pl][4 * q + 1], dc[pl][4 * q + 2], dc[pl][4 * q + 3]);
+                if (hi == 0) {
+                    const int base = valid ? (int)(pl * plane_stride + (size_t)b * RES * RES * CD) : -1;
+                    const int o4[4] = {bl[pl].o00, bl[pl].o01, bl[pl].o10, bl[pl].o11};
+                    const float w4[4] = {bl[pl].w00, bl[pl].w01, bl[pl].w10, bl[pl].w11};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        Q[(n * 3 + pl) * 4 + t] = valid ? base + o4[t] * CD : -1;
+                        Wt[(n * 3 + pl) * 4 + t] = w4[t];
+                    }
                 }
             }
+            // wave-private staging: DS operations of one wave execute in order, no barrier needed
+            const int c = lane & 31;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                for (int pr = 0; pr < 16; ++pr) {
+                    const int pt = 2 * pr + hi;
+                    const float v = T[pt * 96 + pl * 32 + c];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int off = Q[(pt * 3 + pl) * 4 + t];
+                        const float w = Wt[(pt * 3 + pl) * 4 + t];
+                        if (off >= 0) atomicAdd(a.gplanes + off + c, v * w);
+                    }
+                }
         }
     }
 }

@@ -161,6 +161,226 @@ static int launch_wgrad(WgradArgs a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
+// ------------------------------- 3x3 weight gradient, LDS-staged -------------------------------------------------
+// dW[co][ci][tap] += sum_p dY[p][co] * X[p + tap][ci] for one 3x3 layer.  Unit = (image, strip of RS rows): the
+// workgroup stages the haloed input strip (all input channels, zero outside the image) and the dY strip (all
+// output channels) in LDS ONCE; its 8 waves then take their operands from LDS (one ds_read_b32 per 64-cycle MFMA,
+// immediate tap offsets, two VALU per pixel pair -- fp32 MFMA shares the VALU).  A wave owns one 32x32 (co, ci)
+// block for ALL nine taps (nine 32x32 accumulators, the dY operand is read once per nine MFMAs) and one of KS
+// interleaved shares of the strip's pixel pairs; blocks beyond 8 per workgroup go to blockIdx.y.  Accumulators
+// live across the whole persistent strip loop; the next strip is prefetched into registers under the MFMAs.
+// Epilogue: the waves of a block add their tiles into an LDS image laid out like the parameter ([co][ci][tap],
+// ds_add_f32), which is then added to the gradient with fully coalesced atomics.
+struct Wgrad3Args {
+    const float* dY;                 // [img][H][W][COUT]   gradient of the layer's pre-activation
+    const float* in0; const float* in1;   // layer input (concat order), dense NHWC with C0 / C1 channels
+    float* dW;                       // [COUT][CIN][3][3], accumulated by wgrad3_reduce_kernel
+    float* partial;                  // [blockIdx.y][blockIdx.x][block][32][288] per-workgroup partial sums (workspace)
+    int nimg;
+};
+constexpr int WG3_MAX_PARTS = 256 * 8;       // (workgroup, block) partial images of 32x288 floats
+
+#ifdef GIGA_TRACE
+static __device__ long long g_wg3_trace[8 * 32];
+#define WG3_T(idx) do { if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (idx) < 32) \
+        g_wg3_trace[wave * 32 + (idx)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WG3_T(idx) do {} while (0)
+#endif
+
+template <int C0, int C1, int COUT, int H, int RS>
+__global__ __launch_bounds__(512) void conv3_wgrad_kernel(Wgrad3Args a) {
+    constexpr int W = H, CIN = C0 + C1;
+    constexpr int NBK = CIN / 32, NBLK = (COUT / 32) * NBK;
+    constexpr int BPG = NBLK < 8 ? NBLK : 8;          // blocks per workgroup
+    constexpr int KS = 8 / BPG;                       // waves sharing a block (K split)
+    constexpr int XS = CIN + (CIN % 64 == 0 ? 32 : 0);      // LDS pixel strides (floats): odd multiple of 32 so that
+    constexpr int YS = COUT + (COUT % 64 == 0 ? 32 : 0);    // the two pixels of a pair fall into different bank halves
+    constexpr int XW = W + 2, XR = RS + 2;
+    constexpr int NVX = XR * XW * (CIN / 4), NVY = RS * W * (COUT / 4), NV = NVX + NVY;
+    constexpr int NLD = (NV + 511) / 512;
+    constexpr int XBYTES = XR * XW * XS * 4;
+    constexpr int NPAIR = RS * W / 2;
+    static_assert(H % RS == 0 && W % 2 == 0, "strip geometry");
+    extern __shared__ __attribute__((aligned(16))) float wg_lds[];
+    float* Xs = wg_lds;
+    float* Ys = wg_lds + XR * XW * XS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, k = lane >> 5;
+    const int blk = blockIdx.y * BPG + wave / KS, ks = wave % KS;
+    const int mb = blk / NBK, nb = blk % NBK;
+
+    // staging geometry of this thread's vectors (fixed for the whole kernel): LDS float offset and source coordinates
+    int st_lds[NLD], st_src[NLD];                     // src: X: row<<20 | col<<10 | channel ; dY: 1<<30 | pixel<<10 | channel
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int v = tid + 512 * q;
+        if (v < NVX) {
+            const int pix = v / (CIN / 4), c = (v % (CIN / 4)) * 4;
+            st_lds[q] = pix * XS + c;
+            st_src[q] = ((pix / XW) << 20) | ((pix % XW) << 10) | c;
+        } else if (v < NV) {
+            const int u = v - NVX, pix = u / (COUT / 4), c = (u % (COUT / 4)) * 4;
+            st_lds[q] = XR * XW * XS + pix * YS + c;
+            st_src[q] = (1 << 30) | (pix << 10) | c;
+        } else {
+            st_lds[q] = -1; st_src[q] = 0;
+        }
+    }
+    constexpr int SPI = H / RS;                       // strips per image
+    const int nstrips = a.nimg * SPI;
+    float4 stg[NLD];
+    auto issue = [&](int st) {
+        const int img = st / SPI, y0 = (st % SPI) * RS;
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int sd = st_src[q], c = sd & 1023;
+            if (st_lds[q] >= 0) {
+                if (sd >> 30) {
+                    const int pix = (sd >> 10) & 0xFFFFF;
+                    val = *reinterpret_cast<const float4*>(a.dY + ((size_t)(img * H + y0) * W + pix) * COUT + c);
+                } else {
+                    const int gy = y0 - 1 + (sd >> 20), gx = ((sd >> 10) & 1023) - 1;
+                    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                        const size_t px = (size_t)(img * H + gy) * W + gx;
+                        val = c < C0 ? *reinterpret_cast<const float4*>(a.in0 + px * C0 + c)
+                                     : *reinterpret_cast<const float4*>(a.in1 + px * C1 + (c - C0));
+                    }
+                }
+            }
+            stg[q] = val;
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int lane_a = k * YS + mb * 32 + i;          // dY operand: row = co, k = pixel of the pair
+    const int lane_b = k * XS + nb * 32 + i;          // X operand: column = ci
+
+    WG3_T(0);
+    int tc = 1;
+    int st = blockIdx.x;
+    if (st < nstrips) issue(st);
+    for (; st < nstrips; st += gridDim.x) {
+        __syncthreads();                              // everyone is done reading the previous strip
+#pragma unroll
+        for (int q = 0; q < NLD; ++q)
+            if (st_lds[q] >= 0) *reinterpret_cast<float4*>(wg_lds + st_lds[q]) = stg[q];
+        __syncthreads();
+        WG3_T(tc); ++tc;
+        if (st + (int)gridDim.x < nstrips) issue(st + gridDim.x);      // flies under this strip's MFMAs
+        WG3_T(tc); ++tc;
+        // this wave's pixel pairs ks, ks+KS, ...: the ten operands of pair j+1 are read from LDS before the nine
+        // MFMAs of pair j are issued (ping-pong registers), so the LDS round trip never stalls the MFMA pipe
+        constexpr int CNT = NPAIR / KS;
+        static_assert(NPAIR % KS == 0 && CNT % 2 == 0, "pair split");
+        auto ld = [&](int j, float& av, float (&bv)[9]) {
+            const int pi = ks + j * KS;
+            const int r = pi / (W / 2), x = 2 * (pi % (W / 2));
+            av = Ys[(r * W + x) * YS + lane_a];
+            const float* xb = Xs + (r * XW + x) * XS + lane_b;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) bv[t] = xb[((t / 3) * XW + (t % 3)) * XS];
+        };
+        float a0, b0[9], a1, b1[9];
+        ld(0, a0, b0);
+        for (int j = 0; j < CNT; j += 2) {
+            ld(j + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = mfma32(a0, b0[t], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + 2 < CNT) ld(j + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = mfma32(a1, b1[t], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        WG3_T(tc); ++tc;
+    }
+    WG3_T(30);
+    // ---- epilogue: three rounds of three taps.  Every wave parks its three 32x32 tiles in its own LDS slot (register
+    // layout, 16-B vectors, conflict-free), then all 512 threads sum the KS slots of every block and store the result
+    // tap-major ([block][tap][co][ci], coalesced) into this workgroup's partial image; wgrad3_reduce_kernel sums the
+    // workgroups and transposes to the parameter layout.  (Device-scope float atomics from 256 workgroups onto one
+    // 36 KiB image, and LDS float atomics, each cost several times the MFMA loop.)
+    float4* slot = reinterpret_cast<float4*>(wg_lds);                 // [wave][tap of the round][r4][lane]
+    constexpr int RN = 9 * 1024;
+    float* part = a.partial + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * BPG) * RN;
+#pragma unroll
+    for (int g3 = 0; g3 < 3; ++g3) {
+        __syncthreads();
+#pragma unroll
+        for (int tl = 0; tl < 3; ++tl)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                slot[((wave * 3 + tl) * 4 + r4) * 64 + lane] =
+                    make_float4(acc[3 * g3 + tl][4 * r4], acc[3 * g3 + tl][4 * r4 + 1], acc[3 * g3 + tl][4 * r4 + 2],
+                                acc[3 * g3 + tl][4 * r4 + 3]);
+        __syncthreads();
+        for (int v = tid; v < BPG * 3 * 4 * 64; v += 512) {
+            const int ln = v & 63, r4 = (v >> 6) & 3, tl = (v >> 8) % 3, b = v / 768;
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < KS; ++q) {
+                const float4 x = slot[(((b * KS + q) * 3 + tl) * 4 + r4) * 64 + ln];
+                sum.x += x.x; sum.y += x.y; sum.z += x.z; sum.w += x.w;
+            }
+            const int n = ln & 31, m0 = 8 * r4 + 4 * (ln >> 5);       // D rows of registers 4*r4 .. 4*r4+3: m0 .. m0+3
+            float* dst = part + ((size_t)(b * 9 + 3 * g3 + tl) * 32 + m0) * 32 + n;
+            dst[0] = sum.x; dst[32] = sum.y; dst[64] = sum.z; dst[96] = sum.w;
+        }
+    }
+    WG3_T(31);
+}
+
+// dW[co][ci][tap] of block gb = sum over the nx workgroups of partial[by][bx][b][tap][co][ci]   (gb = by*BPG + b);
+// the sum over workgroups is split in NZ groups (blockIdx.z) whose results meet in dW with one atomic each
+template <int CIN, int BPG, int NZ>
+__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restrict__ partial, int nx, float* __restrict__ dW) {
+    constexpr int RN = 9 * 1024, NBK = CIN / 32;
+    const int e = blockIdx.x * 256 + threadIdx.x;               // RN is a multiple of 256
+    const int gb = blockIdx.y, by = gb / BPG, b = gb % BPG;
+    const int x0 = (int)((long long)nx * blockIdx.z / NZ), x1 = (int)((long long)nx * (blockIdx.z + 1) / NZ);
+    const float* src = partial + ((size_t)by * nx * BPG + b) * RN + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int x = x0;
+    for (; x + 4 <= x1; x += 4) {
+        s0 += src[(size_t)(x + 0) * BPG * RN]; s1 += src[(size_t)(x + 1) * BPG * RN];
+        s2 += src[(size_t)(x + 2) * BPG * RN]; s3 += src[(size_t)(x + 3) * BPG * RN];
+    }
+    for (; x < x1; ++x) s0 += src[(size_t)x * BPG * RN];
+    const int t = e >> 10, m = (e >> 5) & 31, n = e & 31;
+    const int gmb = gb / NBK, gnb = gb % NBK;
+    atomicAdd(dW + ((size_t)(gmb * 32 + m) * CIN + gnb * 32 + n) * 9 + t, (s0 + s1) + (s2 + s3));
+}
+
+template <int C0, int C1, int COUT, int H, int RS>
+static int launch_wgrad3(const Wgrad3Args& a, hipStream_t s) {
+    constexpr int CIN = C0 + C1, W = H;
+    constexpr int NBLK = (COUT / 32) * (CIN / 32), BPG = NBLK < 8 ? NBLK : 8, NY = NBLK / BPG;
+    constexpr int XS = CIN + (CIN % 64 == 0 ? 32 : 0), YS = COUT + (COUT % 64 == 0 ? 32 : 0);
+    constexpr size_t strip = ((size_t)(RS + 2) * (W + 2) * XS + (size_t)RS * W * YS) * 4;
+    constexpr size_t lds = strip > 8 * 3 * 4 * 64 * 16 ? strip : 8 * 3 * 4 * 64 * 16;      // strip or the epilogue slots (96 KiB)
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    const int nstrips = a.nimg * (H / RS);
+    int gx = 256 / NY;
+    if (gx > nstrips) gx = nstrips;
+    auto kern = conv3_wgrad_kernel<C0, C1, COUT, H, RS>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(gx, NY), dim3(512), lds, s, a);
+    constexpr int NZ = NBLK >= 8 ? 1 : 8 / NBLK;                 // >= 288 reducing workgroups for every layer
+    hipLaunchKernelGGL((wgrad3_reduce_kernel<CIN, BPG, NZ>), dim3(9 * 1024 / 256, NBLK, NZ), dim3(256), 0, s, a.partial, gx,
+                       a.dW);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
 // ------------------------------- conv_in backward ----------------------------------------------------------
 // Same decomposition as convin_project_kernel (8 waves = 4 iy-groups x 2 channel halves, 16-voxel x 16-channel
 // units).  Per unit: recompute pre = conv_in(x) + b (7 MFMAs), dF = (pre > 0) * (gxz + gxy + gyz) / 40, then
@@ -272,7 +492,7 @@ __global__ __launch_bounds__(512) void convin_bwd_kernel(const float* __restrict
 
 // ------------------------------- driver -----------------------------------------------------------------------
 // forward activations: the encoder workspace (giga_encoder.hip::EncWs, fp32).  Gradient workspace carve:
-struct BwdWs { size_t gA6, gA5, gC1, gA4, gA3, gC0, gS2, gA2, gQ1, gS1, gA1, gQ0, gS0, gA0, gP0, total; };
+struct BwdWs { size_t gA6, gA5, gC1, gA4, gA3, gC0, gS2, gA2, gQ1, gS1, gA1, gQ0, gS0, gA0, gP0, WG, total; };
 BwdWs enc_bwd_workspace(int B) {
     const size_t n = 3 * (size_t)B;
     BwdWs w{};
@@ -283,6 +503,7 @@ BwdWs enc_bwd_workspace(int B) {
     w.gS2 = take(n * 100 * 128); w.gA2 = take(n * 100 * 128); w.gQ1 = take(n * 100 * 64);
     w.gS1 = take(n * 400 * 64);  w.gA1 = take(n * 400 * 64);  w.gQ0 = take(n * 400 * 32);
     w.gS0 = take(n * 1600 * 32); w.gA0 = take(n * 1600 * 32); w.gP0 = take(n * 1600 * 32);
+    w.WG = take((size_t)WG3_MAX_PARTS * 32 * 288);      // per-workgroup weight-gradient partials (conv3_wgrad_kernel)
     w.total = at;
     return w;
 }
@@ -321,7 +542,21 @@ int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_
         a.dW = grads + po.conv_w[l]; a.sM = cin * taps; a.sN = taps; a.sT = 1;
         a.kind = d.kind; a.taps = taps; a.Mb = d.cout / 32; a.Nb = cin / 32;
         a.nimg = nimg; a.H = H; a.W = H;
-        rc |= launch_wgrad(a, s);
+        if (d.kind == CONV3) {
+            Wgrad3Args w3{dpre, in0, in1, grads + po.conv_w[l], G(g.WG), nimg};
+            switch (l) {   // <C0, C1, COUT, H, rows per strip>
+                case 0: case 1: case 11: rc |= launch_wgrad3<32, 0, 32, 40, 4>(w3, s); break;
+                case 10: rc |= launch_wgrad3<32, 32, 32, 40, 2>(w3, s); break;
+                case 2: rc |= launch_wgrad3<32, 0, 64, 20, 4>(w3, s); break;
+                case 3: case 8: rc |= launch_wgrad3<64, 0, 64, 20, 4>(w3, s); break;
+                case 7: rc |= launch_wgrad3<64, 64, 64, 20, 2>(w3, s); break;
+                case 4: rc |= launch_wgrad3<64, 0, 128, 10, 2>(w3, s); break;
+                case 5: rc |= launch_wgrad3<128, 0, 128, 10, 2>(w3, s); break;
+                default: rc |= launch_wgrad(a, s);
+            }
+        } else {
+            rc |= launch_wgrad(a, s);
+        }
         colsum(dpre, d.cout, 0, d.cout, (size_t)nimg * H * H, l);
     };
     // ConvTranspose2d(cin, cout, 2, 2): dW[ci][co][d] = sum In[p][ci] * dU[up(p,d)][co]; dU = channels [0,cout) of dcat
@@ -420,3 +655,9 @@ int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_
 }
 
 }  // namespace giga
+
+#ifdef GIGA_TRACE
+extern "C" int giga_debug_wgrad3_trace(long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(giga::g_wg3_trace), sizeof(long long) * 8 * 32) == hipSuccess ? 0 : -10;
+}
+#endif
