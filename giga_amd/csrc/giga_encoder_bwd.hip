@@ -175,10 +175,12 @@ struct Wgrad3Args {
     const float* dY;                 // [img][H][W][COUT]   gradient of the layer's pre-activation
     const float* in0; const float* in1;   // layer input (concat order), dense NHWC with C0 / C1 channels
     float* dW;                       // [COUT][CIN][3][3], accumulated by wgrad3_reduce_kernel
-    float* partial;                  // [blockIdx.y][blockIdx.x][block][32][288] per-workgroup partial sums (workspace)
+    float* db;                       // [COUT] bias gradient = column sums of dY, accumulated by wgrad3_reduce_kernel
+    float* partial;                  // per-workgroup partial sums (workspace): [by][bx][block][9][32][32], then [bx][COUT]
     int nimg;
 };
-constexpr int WG3_MAX_PARTS = 256 * 8;       // (workgroup, block) partial images of 32x288 floats
+constexpr int WG3_MAX_PARTS = 256 * 8;       // (workgroup, block) partial images of 9x32x32 floats
+constexpr int WG3_BIAS_FLOATS = 256 * 128;   // per-workgroup bias partials behind them
 
 #ifdef GIGA_TRACE
 static __device__ long long g_wg3_trace[8 * 32];
@@ -265,6 +267,7 @@ __global__ __launch_bounds__(512) void conv3_wgrad_kernel(Wgrad3Args a) {
 
     WG3_T(0);
     int tc = 1;
+    float bsum = 0.f;
     int st = blockIdx.x;
     if (st < nstrips) issue(st);
     for (; st < nstrips; st += gridDim.x) {
@@ -276,6 +279,11 @@ __global__ __launch_bounds__(512) void conv3_wgrad_kernel(Wgrad3Args a) {
         WG3_T(tc); ++tc;
         if (st + (int)gridDim.x < nstrips) issue(st + gridDim.x);      // flies under this strip's MFMAs
         WG3_T(tc); ++tc;
+        // bias gradient: column sums of the staged dY strip (ten adds per thread per strip)
+        if (blockIdx.y == 0) {
+            const int bc = tid % COUT;
+            for (int px = tid / COUT; px < RS * W; px += 512 / COUT) bsum += Ys[px * YS + bc];
+        }
         // this wave's pixel pairs ks, ks+KS, ...: the ten operands of pair j+1 are read from LDS before the nine
         // MFMAs of pair j are issued (ping-pong registers), so the LDS round trip never stalls the MFMA pipe
         constexpr int CNT = NPAIR / KS;
@@ -310,6 +318,16 @@ __global__ __launch_bounds__(512) void conv3_wgrad_kernel(Wgrad3Args a) {
     // tap-major ([block][tap][co][ci], coalesced) into this workgroup's partial image; wgrad3_reduce_kernel sums the
     // workgroups and transposes to the parameter layout.  (Device-scope float atomics from 256 workgroups onto one
     // 36 KiB image, and LDS float atomics, each cost several times the MFMA loop.)
+    if (blockIdx.y == 0) {                                            // fold the 512/COUT pixel shares of every channel
+        __syncthreads();
+        wg_lds[tid] = bsum;
+        __syncthreads();
+        if (tid < COUT) {
+            float sb = 0.f;
+            for (int q = 0; q < 512 / COUT; ++q) sb += wg_lds[q * COUT + tid];
+            a.partial[(size_t)gridDim.y * gridDim.x * BPG * 9 * 1024 + (size_t)blockIdx.x * COUT + tid] = sb;
+        }
+    }
     float4* slot = reinterpret_cast<float4*>(wg_lds);                 // [wave][tap of the round][r4][lane]
     constexpr int RN = 9 * 1024;
     float* part = a.partial + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * BPG) * RN;
@@ -343,8 +361,30 @@ __global__ __launch_bounds__(512) void conv3_wgrad_kernel(Wgrad3Args a) {
 // dW[co][ci][tap] of block gb = sum over the nx workgroups of partial[by][bx][b][tap][co][ci]   (gb = by*BPG + b);
 // the sum over workgroups is split in NZ groups (blockIdx.z) whose results meet in dW with one atomic each
 template <int CIN, int BPG, int NZ>
-__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restrict__ partial, int nx, float* __restrict__ dW) {
+__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restrict__ partial, int nx, float* __restrict__ dW,
+                                                            float* __restrict__ db, int cout, int ny) {
     constexpr int RN = 9 * 1024, NBK = CIN / 32;
+    if (blockIdx.x == RN / 256) {                               // one extra block: the bias gradient
+        if (blockIdx.y != 0 || blockIdx.z != 0) return;
+        __shared__ float sb[256];
+        const int c = threadIdx.x % cout, part = threadIdx.x / cout, np = 256 / cout;     // cout divides 256
+        const float* bsrc = partial + (size_t)ny * nx * BPG * RN + c;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int x = part;
+        for (; x + 3 * np < nx; x += 4 * np) {
+            v0 += bsrc[(size_t)x * cout]; v1 += bsrc[(size_t)(x + np) * cout];
+            v2 += bsrc[(size_t)(x + 2 * np) * cout]; v3 += bsrc[(size_t)(x + 3 * np) * cout];
+        }
+        for (; x < nx; x += np) v0 += bsrc[(size_t)x * cout];
+        sb[threadIdx.x] = (v0 + v1) + (v2 + v3);
+        __syncthreads();
+        if ((int)threadIdx.x < cout) {
+            float t = 0.f;
+            for (int q = 0; q < np; ++q) t += sb[q * cout + threadIdx.x];
+            db[threadIdx.x] += t;
+        }
+        return;
+    }
     const int e = blockIdx.x * 256 + threadIdx.x;               // RN is a multiple of 256
     const int gb = blockIdx.y, by = gb / BPG, b = gb % BPG;
     const int x0 = (int)((long long)nx * blockIdx.z / NZ), x1 = (int)((long long)nx * (blockIdx.z + 1) / NZ);
@@ -376,8 +416,8 @@ static int launch_wgrad3(const Wgrad3Args& a, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(gx, NY), dim3(512), lds, s, a);
     constexpr int NZ = NBLK >= 8 ? 1 : 8 / NBLK;                 // >= 288 reducing workgroups for every layer
-    hipLaunchKernelGGL((wgrad3_reduce_kernel<CIN, BPG, NZ>), dim3(9 * 1024 / 256, NBLK, NZ), dim3(256), 0, s, a.partial, gx,
-                       a.dW);
+    hipLaunchKernelGGL((wgrad3_reduce_kernel<CIN, BPG, NZ>), dim3(9 * 1024 / 256 + 1, NBLK, NZ), dim3(256), 0, s, a.partial, gx,
+                       a.dW, a.db, COUT, NY);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
@@ -503,7 +543,7 @@ BwdWs enc_bwd_workspace(int B) {
     w.gS2 = take(n * 100 * 128); w.gA2 = take(n * 100 * 128); w.gQ1 = take(n * 100 * 64);
     w.gS1 = take(n * 400 * 64);  w.gA1 = take(n * 400 * 64);  w.gQ0 = take(n * 400 * 32);
     w.gS0 = take(n * 1600 * 32); w.gA0 = take(n * 1600 * 32); w.gP0 = take(n * 1600 * 32);
-    w.WG = take((size_t)WG3_MAX_PARTS * 32 * 288);      // per-workgroup weight-gradient partials (conv3_wgrad_kernel)
+    w.WG = take((size_t)WG3_MAX_PARTS * 32 * 288 + WG3_BIAS_FLOATS);      // per-workgroup weight-gradient partials (conv3_wgrad_kernel)
     w.total = at;
     return w;
 }
@@ -543,7 +583,7 @@ int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_
         a.kind = d.kind; a.taps = taps; a.Mb = d.cout / 32; a.Nb = cin / 32;
         a.nimg = nimg; a.H = H; a.W = H;
         if (d.kind == CONV3) {
-            Wgrad3Args w3{dpre, in0, in1, grads + po.conv_w[l], G(g.WG), nimg};
+            Wgrad3Args w3{dpre, in0, in1, grads + po.conv_w[l], grads + po.conv_b[l], G(g.WG), nimg};
             switch (l) {   // <C0, C1, COUT, H, rows per strip>
                 case 0: case 1: case 11: rc |= launch_wgrad3<32, 0, 32, 40, 4>(w3, s); break;
                 case 10: rc |= launch_wgrad3<32, 32, 32, 40, 2>(w3, s); break;
@@ -552,12 +592,12 @@ int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_
                 case 7: rc |= launch_wgrad3<64, 64, 64, 20, 2>(w3, s); break;
                 case 4: rc |= launch_wgrad3<64, 0, 128, 10, 2>(w3, s); break;
                 case 5: rc |= launch_wgrad3<128, 0, 128, 10, 2>(w3, s); break;
-                default: rc |= launch_wgrad(a, s);
+                default: rc |= launch_wgrad(a, s); colsum(dpre, d.cout, 0, d.cout, (size_t)nimg * H * H, l);
             }
         } else {
             rc |= launch_wgrad(a, s);
+            colsum(dpre, d.cout, 0, d.cout, (size_t)nimg * H * H, l);
         }
-        colsum(dpre, d.cout, 0, d.cout, (size_t)nimg * H * H, l);
     };
     // ConvTranspose2d(cin, cout, 2, 2): dW[ci][co][d] = sum In[p][ci] * dU[up(p,d)][co]; dU = channels [0,cout) of dcat
     auto wgrad_up = [&](int l, const float* in, const float* dcat, int cs_cat, int H) {
