@@ -428,7 +428,8 @@ static int launch_wgrad3(const Wgrad3Args& a, hipStream_t s) {
 // of the forward unit ARE the B operand of these).  dW / db are reduced with atomics at the end.
 constexpr int CB_ROWSTRIDE = 56;
 constexpr int CB_SLICE = 42 * CB_ROWSTRIDE;
-constexpr size_t CB_LDS_BYTES = 4 * CB_SLICE * sizeof(float);
+constexpr int CB_GROW = 2 * RES * CD;                   // per slice: one row of the xz-plane gradient and one of the xy-plane
+constexpr size_t CB_LDS_BYTES = (4 * CB_SLICE + CB_GROW) * sizeof(float);
 
 __global__ __launch_bounds__(512) void convin_bwd_kernel(const float* __restrict__ tsdf, const float* __restrict__ wpk,
                                                          const float* __restrict__ bias,
@@ -450,22 +451,40 @@ __global__ __launch_bounds__(512) void convin_bwd_kernel(const float* __restrict
     const int ch = 16 * chh + j;
     const float bn = bias[ch];
     __syncthreads();
+    float* grow = slices + 4 * CB_SLICE;          // [2][40][32]: gxz[iz][ix][c] and gxy[iy][ix][c] of the current slice
+    const size_t img_stride = (size_t)RES * RES * CD;
+    const float* gxz = gplanes + ((size_t)0 * B + b) * img_stride;
+    const float* gxy = gplanes + ((size_t)1 * B + b) * img_stride;
+    const float* gyz = gplanes + ((size_t)2 * B + b) * img_stride;
     auto load_slice = [&](int ix) {
         float* dst = slices + ((ix + 1) & 3) * CB_SLICE;
         const bool in = ix >= 0 && ix < RES;
         for (int i = tid; i < RES * RES; i += blockDim.x)
             dst[(i / RES + 1) * CB_ROWSTRIDE + (i % RES + 1)] = in ? vol[(size_t)ix * RES * RES + i] : 0.f;
     };
+    // the upstream gradients of slice ix that do not depend on the unit position: staged once per slice instead of
+    // nine scattered global loads (full round trip each) inside every one of the 25 units
+    auto load_grow = [&](int ix) {
+        for (int i = tid; i < CB_GROW; i += blockDim.x) {
+            const int pl = i / (RES * CD), rest = i % (RES * CD);       // rest = row * 32 + c
+            grow[i] = (pl ? gxy : gxz)[((size_t)(rest / CD) * RES + ix) * CD + rest % CD];
+        }
+    };
     load_slice(ix0 - 1); load_slice(ix0);
-    const size_t img_stride = (size_t)RES * RES * CD;
-    const float* gxz = gplanes + ((size_t)0 * B + b) * img_stride;
-    const float* gxy = gplanes + ((size_t)1 * B + b) * img_stride;
-    const float* gyz = gplanes + ((size_t)2 * B + b) * img_stride;
     const float inv = 1.0f / RES;
     // forward A operand: row i = lane&15 is voxel (iy_l = i>>3, iz_l = 4*((i>>2)&1) + (i&3)); k-slot g -> tap 4s+g
     const int a_base = (grp * 10 + (j >> 3)) * CB_ROWSTRIDE + 4 * ((j >> 2) & 1) + (j & 3);
     // backward A operand: row = tap (lane&15 + 16*th), k-slot g -> voxel row 4g + r of the unit
     const int v_base = (grp * 10 + (g >> 1)) * CB_ROWSTRIDE + 4 * (g & 1);
+    // the yz-plane gradient of this lane's 100 voxels does not depend on the slice: registers, loaded once
+    f32x4v gz[5][5];
+#pragma unroll
+    for (int ip = 0; ip < 5; ++ip)
+#pragma unroll
+        for (int zg = 0; zg < 5; ++zg)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                gz[ip][zg][r] = gyz[((size_t)(8 * zg + 4 * (g & 1) + r) * RES + grp * 10 + 2 * ip + (g >> 1)) * CD + ch];
 
     f32x4v accw[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
     float accb = 0.f;
@@ -473,6 +492,7 @@ __global__ __launch_bounds__(512) void convin_bwd_kernel(const float* __restrict
         const int ix = ix0 + sx;
         __syncthreads();
         load_slice(ix + 1);
+        load_grow(ix);
         __syncthreads();
         const int o[3] = {((ix + 0) & 3) * CB_SLICE, ((ix + 1) & 3) * CB_SLICE, ((ix + 2) & 3) * CB_SLICE};
         int aoff[7], toff[2];
@@ -490,24 +510,22 @@ __global__ __launch_bounds__(512) void convin_bwd_kernel(const float* __restrict
             const int dx = t / 9;
             toff[th] = v_base + ((t / 3) % 3) * CB_ROWSTRIDE + t % 3 + (dx == 0 ? o[0] : dx == 1 ? o[1] : o[2]);
         }
-#pragma unroll 1
+#pragma unroll
         for (int ip = 0; ip < 5; ++ip) {
-#pragma unroll 1
+            const float gy_ = grow[RES * CD + (grp * 10 + 2 * ip + (g >> 1)) * CD + ch];
+#pragma unroll
             for (int zg = 0; zg < 5; ++zg) {
                 const int uo = 2 * ip * CB_ROWSTRIDE + 8 * zg;
-                f32x4v d = {0.f, 0.f, 0.f, 0.f};
+                f32x4v d = {bn, bn, bn, bn};                  // bias in the C operand, as the forward does
 #pragma unroll
                 for (int s = 0; s < 7; ++s) d = mfma32_16(slices[aoff[s] + uo], wreg[s], d);
                 // upstream gradient of the three axis means for this lane's 4 voxels (iz = 8zg + 4(g&1) + r)
-                const int iy = grp * 10 + 2 * ip + (g >> 1), izb = 8 * zg + 4 * (g & 1);
-                const float gy_ = gxy[((size_t)iy * RES + ix) * CD + ch];
                 f32x4v dF;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int iz = izb + r;
-                    const float gsum = gxz[((size_t)iz * RES + ix) * CD + ch] + gy_ +
-                                       gyz[((size_t)iz * RES + iy) * CD + ch];
-                    dF[r] = (d[r] + bn) > 0.f ? gsum * inv : 0.f;
+                    const float gxz_r = grow[(8 * zg + 4 * (g & 1) + r) * CD + ch];
+                    const float gsum = gxz_r + gy_ + gz[ip][zg][r];
+                    dF[r] = d[r] > 0.f ? gsum * inv : 0.f;
                     accb += dF[r];
                 }
 #pragma unroll
