@@ -1,0 +1,14 @@
+#!/bin/bash
+# End-of-round evidence in ONE GPU call: GPU tests, smoke, the default bench line, rocprofv3 kernel stats of the bench
+# command and of a training step, HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE separately).  Outputs: gpurun_out/final/.
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; R=$PWD
+O=$R/gpurun_out/final; mkdir -p $O; export TMPDIR=/tmp PYTHONPATH=$R
+timeout 900 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -n 2 $O/pytest.log
+timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 2 $O/smoke.log
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o b -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/prof_bench.log 2>&1 ); echo "rocprof bench rc=$?"
+python tools/prof_summary.py /tmp/prof_bench $O/bench_kernel_stats.txt
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_train -o t -- python $R/tools/gpu_prof.py train 10 > $O/prof_train.log 2>&1 ); echo "rocprof train rc=$?"
+python tools/prof_summary.py /tmp/prof_train $O/train_kernel_stats.txt
+bash tools/gpu_traffic.sh > $O/traffic.txt 2>&1; echo "traffic rc=$?"
+tail -n 30 $O/traffic.txt
