@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="scenes per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--dp-train", action="store_true",
+                    help="with --gpus N > 1: also time the data-parallel training step of BASELINE c5 (one RCCL "
+                         "all-reduce of the flat gradient bucket per step) and report it under extra")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -157,9 +160,10 @@ def main():
     T = float(t_elapsed.item())
     scenes_per_s = total_scenes / T
 
-    # -------- extra at N > 1: the data-parallel training step of BASELINE c5 (every rank takes part) ----------
+    # -------- opt-in extra at N > 1 (--dp-train): the data-parallel training step of BASELINE c5 (every rank takes part;
+    # off by default so that the scaling run consists of the data-path-free forward only) ----------
     dp_train = None
-    if dist is not None and not args.no_extra:
+    if dist is not None and args.dp_train:
         try:
             net.enable_data_parallel()
             dp_train = bench_train(net, dev, synth, B, M, rank=rank, world=world)
