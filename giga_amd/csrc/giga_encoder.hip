@@ -11,145 +11,115 @@
 
 namespace giga {
 
-#ifdef CI_TRACE   // diagnostic build: per-wave issue timeline of workgroup (0,0) into the yz partial buffer
-#define CI_T(idx) do { if (slab == 0 && b == 0 && lane == 0) reinterpret_cast<long long*>(yz_partial)[wave * 128 + (idx)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define CI_T(idx) do {} while (0)
-#endif
 
 // ====================================================================================================
 // conv_in + ReLU + axis means.
-//   grid (NSLAB, B), block 512 = 8 waves = 4 iy-groups (10 rows each) x 2 channel halves.  The
-//   workgroup walks SX = 40/NSLAB consecutive ix slices of one scene.  Work unit = 16 voxels
-//   (2 iy x 8 iz) x 16 channels: D[voxel][channel] = A[voxel][tap] * Wt[tap][channel], K = 27 taps
-//   (+1 zero) = 7 x v_mfma_f32_16x16x4_f32 (exact fp32).  25 units per wave per slice on every one of
-//   the 8 waves: the 4 SIMDs of the CU carry exactly the same MFMA load (2 waves each).
+//   grid (NXP, 8, B), block 512 = 8 waves.  A workgroup owns one iy-group (10 rows) x one channel half (16 channels) of
+//   one scene for XW = 8*SXW consecutive ix slices; it stages that haloed sub-volume ((XW+2) x 12 x 42 voxels, <= 87 KiB)
+//   in LDS ONCE and every wave then walks its own SXW slices with no workgroup barrier at all.
+//   Work unit = 16 voxels (2 iy x 8 iz) x 16 channels: D[voxel][channel] = A[voxel][tap] * Wt[tap][channel], K = 27 taps
+//   (+1 zero) = 7 x v_mfma_f32_16x16x4_f32 (exact fp32), 25 units per slice.
 //   D-row -> voxel map: row v = 4g + r (g = lane>>4):  iz_local = 4*(g&1) + r ,  iy_local = g>>1, so
-//   * mean over iz (plane 'xy') : in-lane adds + one lane^16 exchange               -> written directly
-//   * mean over iy (plane 'xz') : in-lane adds + one lane^32 exchange, then a fixed-order sum of the
-//                                 4 iy-groups through LDS                            -> written directly
-//   * mean over ix (plane 'yz') : register accumulation over the slab, one fp32 partial per slab to
-//                                 HBM, summed in fixed order by plane_finalize_kernel (no atomics).
+//   * mean over iz (plane 'xy') : in-lane adds + one lane^16 exchange                          -> written directly
+//   * mean over iy (plane 'xz') : in-lane adds + one lane^32 exchange = the sum over the group's 10 rows; one fp32
+//                                 partial per iy-group, the 4 groups are summed by plane_finalize_kernel
+//   * mean over ix (plane 'yz') : register accumulation over the wave's slices, then a fixed-order sum of the 8 waves
+//                                 through LDS (and over the NXP x-parts in plane_finalize_kernel); no atomics anywhere.
+//   SXW = 5 (NXP = 1, batch >= 32: 8*B workgroups) or 1 (NXP = 5: 40*B workgroups for small batches).
 // Plane pixel (H,W) conventions (common.py:246-251,303-318): xz -> [iz][ix], xy -> [iy][ix], yz -> [iz][iy].
 // ====================================================================================================
 
-constexpr int CI_ROWSTRIDE = 56;                  // floats per LDS row (>= 42; 56 mod 32 = 24 spreads the rows over banks)
-constexpr int CI_SLICE = 42 * CI_ROWSTRIDE;       // one haloed slice
-constexpr int CI_LDS_SLICES = 4 * CI_SLICE;       // ring of 4 slices (floats): 3 in use + 1 being filled
-constexpr int CI_LDS_RED = 4 * 40 * 32;           // cross-group reduction buffer (floats), double-buffered
-constexpr size_t CI_LDS_BYTES = (CI_LDS_SLICES + 2 * CI_LDS_RED) * sizeof(float);
+constexpr int CV_RS = 44;                         // floats per (ix, iy) row of the staged sub-volume: iz + 1 in [0, 41]
+constexpr int CV_ROWS = 12;                       // the group's 10 iy rows + halo
+constexpr size_t ci_lds_bytes(int sxw) {
+    const size_t stage = (size_t)(8 * sxw + 2) * CV_ROWS * CV_RS * sizeof(float);
+    const size_t red = (size_t)8 * 10 * 64 * 16;  // yz reduction: 8 waves x 10 units x 64 lanes x 16 B
+    return stage > red ? stage : red;
+}
 
-template <typename TOut>
+template <typename TOut, int SXW>
 __global__ __launch_bounds__(512) void convin_project_kernel(
     const float* __restrict__ tsdf,        // [B][40][40][40]
     const float* __restrict__ wpk,         // [2][7][64] packed B operands
     const float* __restrict__ bias,        // [32]
-    TOut* __restrict__ planes,             // [3][B][40][40][32] NHWC (xz, xy written here)
-    float* __restrict__ yz_partial,        // [NSLAB][B][40(iz)][40(iy)][32] sums over SX ix
-    int B, int SX) {
+    TOut* __restrict__ planes,             // [3][B][40][40][32] NHWC (xy written here)
+    float* __restrict__ xz_partial,        // [4 iy-groups][B][40(iz)][40(ix)][32] sums over the group's 10 iy
+    float* __restrict__ yz_partial,        // [NXP][B][40(iz)][40(iy)][32] sums over the part's ix
+    int B) {
+    constexpr int XW = 8 * SXW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* slices = lds;
-    float* red = lds + CI_LDS_SLICES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
-    const int chh = wave & 1, grp = wave >> 1;
-    const int slab = blockIdx.x, b = blockIdx.y;
-    const int ix0 = slab * SX;
+    const int xp = blockIdx.x, grp = blockIdx.y >> 1, chh = blockIdx.y & 1, b = blockIdx.z;
+    const int x0 = xp * XW;
     const float* vol = tsdf + (size_t)b * RES * RES * RES;
 
-    for (int i = tid; i < CI_LDS_SLICES; i += blockDim.x) slices[i] = 0.f;   // halos stay zero
+    // ---- stage the haloed sub-volume: rows (xl, yl) of 40 iz values + the two iz halo cells; outside = 0 ----
+    for (int v = tid; v < (XW + 2) * CV_ROWS * 10; v += 512) {
+        const int q = v % 10, row = v / 10, yl = row % CV_ROWS, xl = row / CV_ROWS;
+        const int ix = x0 - 1 + xl, iy = 10 * grp - 1 + yl;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ix >= 0 && ix < RES && iy >= 0 && iy < RES)
+            val = *reinterpret_cast<const float4*>(vol + ((size_t)ix * RES + iy) * RES + 4 * q);
+        float* dst = lds + row * CV_RS + 1 + 4 * q;
+        dst[0] = val.x; dst[1] = val.y; dst[2] = val.z; dst[3] = val.w;
+        if (q == 0) dst[-1] = 0.f;
+        if (q == 9) dst[4] = 0.f;
+    }
     float wreg[7];
 #pragma unroll
     for (int s = 0; s < 7; ++s) wreg[s] = wpk[(chh * 7 + s) * 64 + lane];
-    const float bn = bias[16 * chh + j];
-    __syncthreads();
-
-    // slice ix lives in ring slot (ix+1) & 3; out-of-range slices are zero.  Each thread moves up to 4
-    // voxels of a slice (1600 = 3*512 + 64): global -> registers early, registers -> LDS late.
-    auto fetch_slice = [&](int ix, float (&pre)[4]) {
-        const bool in = ix >= 0 && ix < RES;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = tid + 512 * q;
-            pre[q] = (in && i < RES * RES) ? vol[(size_t)ix * RES * RES + i] : 0.f;
-        }
-    };
-    auto commit_slice = [&](int ix, const float (&pre)[4]) {
-        float* dst = slices + ((ix + 1) & 3) * CI_SLICE;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = tid + 512 * q;         // recomputed (not kept live): the kernel sits at the VGPR limit
-            if (i < RES * RES) dst[(i / RES + 1) * CI_ROWSTRIDE + (i % RES + 1)] = pre[q];
-        }
-    };
-    {   // the three slices of the first step: one round trip, not three
-        float p0[4], p1[4], p2[4];
-        fetch_slice(ix0 - 1, p0); fetch_slice(ix0, p1); fetch_slice(ix0 + 1, p2);
-        commit_slice(ix0 - 1, p0); commit_slice(ix0, p1); commit_slice(ix0 + 1, p2);
-    }
-    __syncthreads();
-
+    const int ch = 16 * chh + j;
+    const float bn = bias[ch];
     // A operand: row i = lane&15 is voxel (iy_l = i>>3, iz_l = 4*((i>>2)&1) + (i&3)); k-slot g supplies tap 4s+g
-    // (tap = dx*9 + dy*3 + dz; tap 27 has zero weight and reads tap 26's voxel).  abase[s] is loop-invariant;
-    // only the ring slot of the tap's dx changes per slice.
-    const int a_base = (grp * 10 + (j >> 3)) * CI_ROWSTRIDE + 4 * ((j >> 2) & 1) + (j & 3);
+    // (tap = dx*9 + dy*3 + dz; tap 27 has zero weight and reads tap 26's voxel)
     int abase[7];
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
         int t = 4 * s + g;
         t = t > 26 ? 26 : t;
-        abase[s] = a_base + ((t / 3) % 3) * CI_ROWSTRIDE + t % 3;
+        abase[s] = ((t / 9) * CV_ROWS + (j >> 3) + (t / 3) % 3) * CV_RS + 4 * ((j >> 2) & 1) + (j & 3) + t % 3;
     }
     f32x4v acc_yz[5][5];
 #pragma unroll
     for (int ip = 0; ip < 5; ++ip)
 #pragma unroll
         for (int zg = 0; zg < 5; ++zg) acc_yz[ip][zg] = f32x4v{0.f, 0.f, 0.f, 0.f};
-
     const float inv = 1.0f / RES;
     const size_t img_stride = (size_t)RES * RES * CD;
-    TOut* plane_xz = planes + ((size_t)0 * B + b) * img_stride;
     TOut* plane_xy = planes + ((size_t)1 * B + b) * img_stride;
-    const int ch = 16 * chh + j;
+    float* xzp = xz_partial + ((size_t)grp * B + b) * img_stride;
     const f32x4v bias4 = {bn, bn, bn, bn};            // the bias rides in the C operand of the first MFMA
     const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int xz_lane = 4 * (g & 1) * RES * CD + ch;  // lane part of the xz-partial index (uniform base + 32-bit offset)
+    __syncthreads();
 
-    for (int sx = 0; sx < SX; ++sx) {
-        const int ix = ix0 + sx;
-        // Hazards are covered by the single barrier below: the slot filled this iteration (slice ix+2)
-        // was last read as slice ix-2 in the previous iteration; `red` alternates between two buffers.
-        float* redw = red + (sx & 1) * CI_LDS_RED;
-        float pre[4];
-        if (sx + 1 < SX) fetch_slice(ix + 2, pre);   // global loads fly under this slice's MFMAs
-        const int o0 = ((ix + 0) & 3) * CI_SLICE, o1 = ((ix + 1) & 3) * CI_SLICE, o2 = ((ix + 2) & 3) * CI_SLICE;
+    for (int sx = 0; sx < SXW; ++sx) {
+        const int ixl = wave * SXW + sx, ix = x0 + ixl;
         int addr[7];
 #pragma unroll
-        for (int s = 0; s < 7; ++s) {
-            const int lo = (4 * s) / 9, hi = (4 * s + 3 > 26 ? 26 : 4 * s + 3) / 9;    // dx of k-slots 0 and 3
-            const int olo = lo == 0 ? o0 : lo == 1 ? o1 : o2, ohi = hi == 0 ? o0 : hi == 1 ? o1 : o2;
-            addr[s] = abase[s] + (lo == hi ? olo : (4 * s + g >= 9 * hi ? ohi : olo));
-        }
+        for (int s = 0; s < 7; ++s) addr[s] = abase[s] + ixl * CV_ROWS * CV_RS;
         f32x2v sum_z[5];                  // per iy-pair: sum over the 5 iz-groups and the 4 in-lane iz (two partials)
 #pragma unroll
         for (int ip = 0; ip < 5; ++ip) sum_z[ip] = f32x2v{0.f, 0.f};
         // Software pipeline over the 5 iz-groups.  Per group: five independent 7-MFMA chains (the iy-pairs).
         // A operands of MFMA steps 0..2 are loaded one group ahead (P), those of steps 3..6 at the top of the
         // group (Q) under the first 15 MFMAs, so no LDS round trip is exposed.  The 35 MFMAs stay one
-        // uninterrupted burst: an extra issue slot between MFMAs costs far more than the slot itself, and the
-        // ReLU / axis-sum epilogue (packed adds) runs as its own burst under the sibling wave's MFMAs.
+        // uninterrupted burst (an extra issue slot between MFMAs costs far more than the slot itself); the ReLU /
+        // axis-sum epilogue is paid in full: fp32 MFMA shares the VALU with it.
         float P[3][5], Q[4][5];
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
-            for (int ip = 0; ip < 5; ++ip) P[s][ip] = slices[addr[s] + 2 * ip * CI_ROWSTRIDE];
-        CI_T(sx * 16 + 0);
+            for (int ip = 0; ip < 5; ++ip) P[s][ip] = lds[addr[s] + 2 * ip * CV_RS];
 #pragma unroll
         for (int zg = 0; zg < 5; ++zg) {
             f32x4v d[5];
 #pragma unroll
             for (int s = 3; s < 7; ++s)
 #pragma unroll
-                for (int ip = 0; ip < 5; ++ip) Q[s - 3][ip] = slices[addr[s] + 2 * ip * CI_ROWSTRIDE + 8 * zg];
+                for (int ip = 0; ip < 5; ++ip) Q[s - 3][ip] = lds[addr[s] + 2 * ip * CV_RS + 8 * zg];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 3; ++s)
@@ -160,8 +130,7 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
 #pragma unroll
-                    for (int ip = 0; ip < 5; ++ip)
-                        P[s][ip] = slices[addr[s] + 2 * ip * CI_ROWSTRIDE + 8 * (zg + 1)];
+                    for (int ip = 0; ip < 5; ++ip) P[s][ip] = lds[addr[s] + 2 * ip * CV_RS + 8 * (zg + 1)];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -169,7 +138,6 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
 #pragma unroll
                 for (int ip = 0; ip < 5; ++ip) d[ip] = mfma32_16(Q[s - 3][ip], wreg[s], d[ip]);
             __builtin_amdgcn_sched_barrier(0);
-            CI_T(sx * 16 + 1 + 2 * zg);
             f32x4v part_y = zero4;            // per r: sum over the 5 iy-pairs of this group
 #pragma unroll
             for (int ip = 0; ip < 5; ++ip) {
@@ -178,17 +146,16 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
                 sum_z[ip] += f32x2v{v[0], v[1]} + f32x2v{v[2], v[3]};
                 part_y += v;
             }
-            // plane xz [iz][ix][c]: the other iy row of each tile lives in lane^32; 4 groups go through LDS
+            // plane xz [iz][ix][c], this iy-group's share: the other iy row of each tile lives in lane^32
             float other[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) other[r] = __shfl_xor(part_y[r], 32);       // four exchanges, one wait
             if ((g >> 1) == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    redw[(grp * 40 + 8 * zg + 4 * (g & 1) + r) * 32 + ch] = part_y[r] + other[r];
+                    xzp[xz_lane + ((8 * zg + r) * RES + ix) * CD] = part_y[r] + other[r];      // 32-bit offsets
             }
             __builtin_amdgcn_sched_barrier(0);
-            CI_T(sx * 16 + 2 + 2 * zg);
         }
         // plane xy [iy][ix][c]: other half of the 8 iz of each tile lives in lane^16
 #pragma unroll
@@ -197,58 +164,51 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
             const float sm = sl + __shfl_xor(sl, 16);
             if ((g & 1) == 0) {
                 const int iy = grp * 10 + 2 * ip + (g >> 1);
-                plane_xy[((size_t)iy * RES + ix) * CD + ch] = (TOut)(sm * inv);
+                plane_xy[(iy * RES + ix) * CD + ch] = (TOut)(sm * inv);
             }
         }
-        if (sx + 1 < SX) commit_slice(ix + 2, pre);
-        CI_T(sx * 16 + 11);
-        __syncthreads();
-        CI_T(sx * 16 + 12);
-        // the fixed-order sum of the 4 iy-groups is done by ONE half of the waves (alternating per slice):
-        // the sibling wave of every SIMD goes straight on to the next slice's MFMAs
-        if ((wave >> 2) == (sx & 1)) {
-            for (int i = tid & 255; i < 40 * 32; i += 256) {
-                const float sr = (redw[i] + redw[1280 + i]) + (redw[2560 + i] + redw[3840 + i]);
-                const int iz = i >> 5, c = i & 31;
-                plane_xz[((size_t)iz * RES + ix) * CD + c] = (TOut)(sr * inv);
-            }
-        }
-        CI_T(sx * 16 + 13);
     }
-#ifdef CI_TRACE
-    return;
-#endif
-    // plane yz partial of this slab, in the kernel's own register order so that every store is one fully
-    // coalesced 16 B per lane: [slab][b][wave][unit = ip*5+zg][lane][r]; plane_finalize_kernel undoes the map.
-    f32x4v* part = reinterpret_cast<f32x4v*>(yz_partial + ((size_t)slab * B + b) * img_stride) + (size_t)wave * 25 * 64 + lane;
+    // ---- plane yz: fixed-order sum of the 8 waves (each holds the sum over its own slices), 10 units per round ----
+    f32x4v* slot = reinterpret_cast<f32x4v*>(lds);                     // [wave][unit of the round][lane]
+    float* yzp = yz_partial + ((size_t)xp * B + b) * img_stride;
 #pragma unroll
-    for (int ip = 0; ip < 5; ++ip)
+    for (int rd = 0; rd < 3; ++rd) {
+        constexpr int U0[3] = {0, 10, 20}, UN[3] = {10, 10, 5};
+        __syncthreads();                                               // (round 0: every wave is done with the sub-volume)
 #pragma unroll
-        for (int zg = 0; zg < 5; ++zg) part[(ip * 5 + zg) * 64] = acc_yz[ip][zg];
+        for (int ul = 0; ul < UN[rd]; ++ul)
+            slot[(wave * 10 + ul) * 64 + lane] = acc_yz[(U0[rd] + ul) / 5][(U0[rd] + ul) % 5];
+        __syncthreads();
+        for (int e = tid; e < UN[rd] * 64; e += 512) {
+            const int ul = e >> 6, ln = e & 63;
+            f32x4v sum = slot[ul * 64 + ln];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) sum += slot[(w * 10 + ul) * 64 + ln];
+            const int u = U0[rd] + ul, ip = u / 5, zg = u % 5, lg = ln >> 4, lj = ln & 15;
+            const int iy = grp * 10 + 2 * ip + (lg >> 1), iz0 = 8 * zg + 4 * (lg & 1);
+            const int di = (iz0 * RES + iy) * CD + 16 * chh + lj;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yzp[di + r * RES * CD] = sum[r];
+        }
+    }
 }
 
+// planes xz = (sum of the 4 iy-group partials) / 40, yz = (sum of the NXP x-part partials) / 40
 template <typename TOut>
-__global__ void plane_finalize_kernel(const float* __restrict__ yz_partial, TOut* __restrict__ planes, int B,
-                                      int nslab) {
-    // one thread per (scene, iy, group of 4 iz, channel): a 16-B read per slab in convin_project's register
-    // order (see the store at its end), fixed-order sum over the slabs, four channel-contiguous row writes
-    const size_t per = (size_t)B * RES * RES * CD;          // elements of one plane over the batch
+__global__ void plane_finalize_kernel(const float* __restrict__ xz_partial, const float* __restrict__ yz_partial,
+                                      TOut* __restrict__ planes, int B, int nxp) {
+    const size_t per4 = (size_t)B * RES * RES * CD / 4;     // float4 elements of one plane over the batch
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= per / 4) return;
-    const int c = (int)(t % CD);
-    const int izq = (int)((t / CD) % 10);
-    const int iy = (int)((t / (CD * 10)) % RES);
-    const size_t b = t / ((size_t)CD * 10 * RES);
-    const int iyl = iy % 10;
-    const int wave = (iy / 10) * 2 + c / 16;
-    const int unit = (iyl / 2) * 5 + izq / 2;
-    const int lane = ((iyl & 1) * 2 + (izq & 1)) * 16 + (c & 15);
-    const f32x4v* src = reinterpret_cast<const f32x4v*>(yz_partial) + (b * 8 + wave) * 25 * 64 + unit * 64 + lane;
-    f32x4v sum = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < nslab; ++k) sum += src[(size_t)k * (per / 4)];
-    TOut* dst = planes + 2 * per + ((b * RES + 4 * izq) * RES + iy) * CD + c;      // [iz][iy][c]
+    if (t >= per4) return;
+    const f32x4v* xs = reinterpret_cast<const f32x4v*>(xz_partial) + t;
+    const f32x4v* ys = reinterpret_cast<const f32x4v*>(yz_partial) + t;
+    f32x4v sx = (xs[0] + xs[per4]) + (xs[2 * per4] + xs[3 * per4]);
+    f32x4v sy = ys[0];
+    for (int k = 1; k < nxp; ++k) sy += ys[(size_t)k * per4];
+    TOut* dx = planes + 4 * t;
+    TOut* dy = planes + 2 * 4 * per4 + 4 * t;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dst[(size_t)r * RES * CD] = (TOut)(sum[r] * (1.0f / RES));
+    for (int r = 0; r < 4; ++r) { dx[r] = (TOut)(sx[r] * (1.0f / RES)); dy[r] = (TOut)(sy[r] * (1.0f / RES)); }
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -259,6 +219,9 @@ __global__ void plane_finalize_kernel(const float* __restrict__ yz_partial, TOut
 struct EncWs {
     size_t P0, A0, S0, Q0, A1, S1, Q1, A2, S2, U0, A3, A4, U1, A5, A6, YZ, XZ, total;   // XZ unused (kept for the ABI)
 };
+// x-parts of conv_in+project: 1 (8*B workgroups, five slices per wave) from 32 scenes up, else 5 (40*B workgroups)
+int enc_nxp(int B) { return B >= 32 ? 1 : 5; }
+
 EncWs enc_workspace(int B, int precision, int nslab) {
     const size_t es = precision == 1 ? 2 : 4;
     const size_t n = 3 * (size_t)B;
@@ -270,7 +233,8 @@ EncWs enc_workspace(int B, int precision, int nslab) {
     w.Q1 = take(n * 100 * 64, es);  w.A2 = take(n * 100 * 128, es); w.S2 = take(n * 100 * 128, es);
     w.U0 = take(n * 400 * 64, es);  w.A3 = take(n * 400 * 64, es);  w.A4 = take(n * 400 * 64, es);
     w.U1 = take(n * 1600 * 32, es); w.A5 = take(n * 1600 * 32, es); w.A6 = take(n * 1600 * 32, es);
-    w.YZ = take((size_t)nslab * B * 1600 * 32, 4);
+    (void)nslab;                                            // (slab count of the backward's conv_in kernel)
+    w.YZ = take((size_t)(4 + enc_nxp(B)) * B * 1600 * 32, 4);   // 4 xz partials (iy-groups) + NXP yz partials (x-parts)
     w.XZ = w.YZ;
     w.total = at;
     return w;
@@ -299,19 +263,29 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     const int nslab = enc_nslab(B);
     const EncWs w = enc_workspace(B, precision, nslab);
     T* P0 = reinterpret_cast<T*>(ws + w.P0);
-    float* YZ = reinterpret_cast<float*>(ws + w.YZ);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convin_project_kernel<T>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)CI_LDS_BYTES);
+    const size_t per = (size_t)B * RES * RES * CD;
+    float* XZP = reinterpret_cast<float*>(ws + w.YZ);
+    float* YZP = XZP + 4 * per;
+    const int nxp = enc_nxp(B);
+    const float* cw = reinterpret_cast<const float*>(blob + ko.convin_w);
+    const float* cb = reinterpret_cast<const float*>(blob + ko.convin_b);
     pre();
-    hipLaunchKernelGGL(convin_project_kernel<T>, dim3(nslab, B), dim3(512), CI_LDS_BYTES, s, tsdf,
-                       reinterpret_cast<const float*>(blob + ko.convin_w),
-                       reinterpret_cast<const float*>(blob + ko.convin_b), P0, YZ, B, RES / nslab);
+    if (nxp == 1) {
+        auto kern = convin_project_kernel<T, 5>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)ci_lds_bytes(5));
+        hipLaunchKernelGGL(kern, dim3(1, 8, B), dim3(512), ci_lds_bytes(5), s, tsdf, cw, cb, P0, XZP, YZP, B);
+    } else {
+        auto kern = convin_project_kernel<T, 1>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)ci_lds_bytes(1));
+        hipLaunchKernelGGL(kern, dim3(5, 8, B), dim3(512), ci_lds_bytes(1), s, tsdf, cw, cb, P0, XZP, YZP, B);
+    }
     post();
     {
         pre();
-        const size_t per = (size_t)B * RES * RES * CD;
-        hipLaunchKernelGGL(plane_finalize_kernel<T>, dim3((unsigned)((per / 4 + 255) / 256)), dim3(256), 0, s, YZ, P0, B,
-                           nslab);
+        hipLaunchKernelGGL(plane_finalize_kernel<T>, dim3((unsigned)((per / 4 + 255) / 256)), dim3(256), 0, s, XZP, YZP, P0, B,
+                           nxp);
         post();
     }
     if (hipGetLastError() != hipSuccess) return -10;
