@@ -314,7 +314,8 @@ __global__ __launch_bounds__(256, 1) void decoder_f32_kernel(DecArgs a) {
     }
     bool fresh = true;                                        // the resident image has not been waited for yet
 
-    for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
+    for (int bseq = blockIdx.x; bseq < a.nbatch; bseq += gridDim.x) {
+        const int batch = xcd_swizzle(bseq, a.nbatch);        // an XCD works on a contiguous range of points (L2 locality)
         float cf[T][48], ax0[T], ax1[T];
         long long gidx[T];
         bool valid[T];
@@ -346,29 +347,51 @@ __global__ __launch_bounds__(256, 1) void decoder_f32_kernel(DecArgs a) {
                     }
                 }
             } else {
-            const float px = a.p[3 * g + 0], py = a.p[3 * g + 1], pz = a.p[3 * g + 2];
-            const float nx = norm_coord(px), ny = norm_coord(py), nz = norm_coord(pz);
-            ax0[t] = hi ? py : px;       // aux MFMA 0: slots (px, py)
-            ax1[t] = hi ? 1.0f : pz;     // aux MFMA 1: slots (pz, 1)
+            // ---------------- generic gather, line-friendly.  A load instruction in which every lane fetches 16 B of
+            // its OWN point touches 64 different cache lines; the gather of a 256-point batch then took a third of the
+            // kernel (the CU's texture path handles a few lines per clock).  Here four adjacent lanes fetch the four
+            // 16-B quads of one (point, channel half), i.e. one whole 64-B line per four lanes, interpolate them, and
+            // the tile is transposed to the operand layout (lane = point) through a wave-private LDS stage.
+            const float pxo = a.p[3 * g + 0], pyo = a.p[3 * g + 1], pzo = a.p[3 * g + 2];
+            ax0[t] = hi ? pyo : pxo;     // aux MFMA 0: slots (px, py)
+            ax1[t] = hi ? 1.0f : pzo;    // aux MFMA 1: slots (pz, 1)
+            float* S = reinterpret_cast<float*>(smem + DEC32_BYTES) + wave * (32 * 96);      // [point][96]
+            const long long tile0 = ((long long)batch * 4 * T + wave * T + t) * 32;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                const float u = pl == 2 ? ny : nx;
-                const float v = pl == 1 ? ny : nz;
-                const Bilin bl = bilin_setup(u, v);
-                const float* base = planes + pl * plane_stride + (size_t)b * RES * RES * CD + 16 * hi;
+            for (int part = 0; part < 4; ++part) {
+                const int pair = part * 16 + (lane >> 2), pt = pair >> 1, hf = pair & 1, qd = lane & 3;
+                long long gp = tile0 + pt;
+                if (gp >= a.P) gp = a.P - 1;
+                int bp, rp;
+                split_scene(gp, a.N, a.invN, bp, rp);
+                const float nx = norm_coord(a.p[3 * gp + 0]), ny = norm_coord(a.p[3 * gp + 1]), nz = norm_coord(a.p[3 * gp + 2]);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 v00 = *reinterpret_cast<const float4*>(base + (size_t)bl.o00 * CD + 4 * q);
-                    const float4 v01 = *reinterpret_cast<const float4*>(base + (size_t)bl.o01 * CD + 4 * q);
-                    const float4 v10 = *reinterpret_cast<const float4*>(base + (size_t)bl.o10 * CD + 4 * q);
-                    const float4 v11 = *reinterpret_cast<const float4*>(base + (size_t)bl.o11 * CD + 4 * q);
+                for (int pl = 0; pl < 3; ++pl) {
+                    // xz: (u,v)=(x,z)  xy: (x,y)  yz: (y,z)      common.py:246-251
+                    const Bilin bl = bilin_setup(pl == 2 ? ny : nx, pl == 1 ? ny : nz);
+                    const float* base = planes + pl * plane_stride + (size_t)bp * RES * RES * CD + 16 * hf + 4 * qd;
+                    const float4 v00 = *reinterpret_cast<const float4*>(base + (size_t)bl.o00 * CD);
+                    const float4 v01 = *reinterpret_cast<const float4*>(base + (size_t)bl.o01 * CD);
+                    const float4 v10 = *reinterpret_cast<const float4*>(base + (size_t)bl.o10 * CD);
+                    const float4 v11 = *reinterpret_cast<const float4*>(base + (size_t)bl.o11 * CD);
                     // same order as aten's grid_sampler: nw, ne, sw, se
-                    cf[t][16 * pl + 4 * q + 0] = fmaf(v11.x, bl.w11, fmaf(v10.x, bl.w10, fmaf(v01.x, bl.w01, v00.x * bl.w00)));
-                    cf[t][16 * pl + 4 * q + 1] = fmaf(v11.y, bl.w11, fmaf(v10.y, bl.w10, fmaf(v01.y, bl.w01, v00.y * bl.w00)));
-                    cf[t][16 * pl + 4 * q + 2] = fmaf(v11.z, bl.w11, fmaf(v10.z, bl.w10, fmaf(v01.z, bl.w01, v00.z * bl.w00)));
-                    cf[t][16 * pl + 4 * q + 3] = fmaf(v11.w, bl.w11, fmaf(v10.w, bl.w10, fmaf(v01.w, bl.w01, v00.w * bl.w00)));
+                    float4 o;
+                    o.x = fmaf(v11.x, bl.w11, fmaf(v10.x, bl.w10, fmaf(v01.x, bl.w01, v00.x * bl.w00)));
+                    o.y = fmaf(v11.y, bl.w11, fmaf(v10.y, bl.w10, fmaf(v01.y, bl.w01, v00.y * bl.w00)));
+                    o.z = fmaf(v11.z, bl.w11, fmaf(v10.z, bl.w10, fmaf(v01.z, bl.w01, v00.z * bl.w00)));
+                    o.w = fmaf(v11.w, bl.w11, fmaf(v10.w, bl.w10, fmaf(v01.w, bl.w01, v00.w * bl.w00)));
+                    *reinterpret_cast<float4*>(S + pt * 96 + pl * 32 + 16 * hf + 4 * qd) = o;
                 }
             }
+            // wave-private stage: DS operations of one wave execute in order, no barrier needed
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(S + n * 96 + pl * 32 + 16 * hi + 4 * q);
+                    cf[t][16 * pl + 4 * q + 0] = v.x; cf[t][16 * pl + 4 * q + 1] = v.y;
+                    cf[t][16 * pl + 4 * q + 2] = v.z; cf[t][16 * pl + 4 * q + 3] = v.w;
+                }
             }
         }
         for (int h = h_begin; h < h_end; ++h) {
@@ -544,6 +567,8 @@ __global__ void lattice_resample_kernel(const TP* __restrict__ planes, const flo
 }
 
 // ------------------------------- launchers ----------------------------------------------------------
+constexpr size_t DEC32_LDS = DEC32_BYTES + 4 * 32 * 96 * sizeof(float);     // weight image + the gather's per-wave stage
+static_assert(DEC32_LDS <= 160 * 1024, "LDS budget of the fp32 decoder");
 int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, void* ev1) {
     DecArgs a = a0;
     if (a.P <= 0 || a.nheads <= 0) return 0;
@@ -580,8 +605,8 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
         auto kern = lat ? decoder_f32_kernel<T, true> : decoder_f32_kernel<T, false>;
         a.heads_per_wg = a.nheads;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)DEC32_BYTES);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), DEC32_BYTES, s, a);
+                                  (int)DEC32_LDS);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), DEC32_LDS, s, a);
     } else {
         constexpr int T = 1;
         a.nbatch = (int)((tiles + 4 * T - 1) / (4 * T));
@@ -591,8 +616,8 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
         const bool split = grid * a.nheads <= 256;
         a.heads_per_wg = split ? 1 : a.nheads;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)DEC32_BYTES);
-        hipLaunchKernelGGL(kern, dim3(grid, split ? a.nheads : 1), dim3(256), DEC32_BYTES, s, a);
+                                  (int)DEC32_LDS);
+        hipLaunchKernelGGL(kern, dim3(grid, split ? a.nheads : 1), dim3(256), DEC32_LDS, s, a);
     }
     if (ev0 && ev1) (void)hipEventRecord(static_cast<hipEvent_t>(ev1), s);
     return hipGetLastError() == hipSuccess ? 0 : -10;

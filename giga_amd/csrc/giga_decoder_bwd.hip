@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdArgs a) {
     const float4* W = reinterpret_cast<const float4*>(smem);
     const size_t plane_stride = (size_t)a.B * RES * RES * CD;
 
-    for (int batch = blockIdx.x; batch < a.nbatch; batch += gridDim.x) {
+    for (int bseq = blockIdx.x; bseq < a.nbatch; bseq += gridDim.x) {
+        const int batch = xcd_swizzle(bseq, a.nbatch);        // an XCD works on a contiguous range of points (L2 locality)
         // ---------------- gather (as decoder_f32_kernel), keep the bilinear footprints for the scatter --------
         long long g = ((long long)batch * 4 + wave) * 32 + n;
         const bool valid = g < a.P;

@@ -93,4 +93,14 @@ __device__ __forceinline__ Bilin bilin_setup(float u, float v) {
     return b;
 }
 
+
+// XCD-aware work mapping (speed only, never correctness): workgroup i runs on XCD i % 8 (observed dispatch order), and
+// each XCD has its own 4 MiB L2.  Consecutive work items share data (the points of one scene sample the same planes),
+// so item indices are permuted such that XCD x gets the x-th contiguous eighth of the items instead of every eighth
+// item: an XCD then touches 1/8 of the scenes and its L2 keeps their planes resident.
+__device__ __forceinline__ int xcd_swizzle(int i, int n) {
+    const int m = n & ~7;                    // the largest multiple of 8; the remainder keeps its place
+    return i < m ? (i & 7) * (m >> 3) + (i >> 3) : i;
+}
+
 }  // namespace giga
