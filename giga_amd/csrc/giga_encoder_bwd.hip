@@ -422,60 +422,69 @@ static int launch_wgrad3(const Wgrad3Args& a, hipStream_t s) {
 }
 
 // ------------------------------- conv_in backward ----------------------------------------------------------
-// Same decomposition as convin_project_kernel (8 waves = 4 iy-groups x 2 channel halves, 16-voxel x 16-channel
-// units).  Per unit: recompute pre = conv_in(x) + b (7 MFMAs), dF = (pre > 0) * (gxz + gxy + gyz) / 40, then
-// dW^T[tap][ch] += X^T[tap][voxel] * dF[voxel][ch] as 2 tap halves x 4 k-steps = 8 more MFMAs (the D registers
-// of the forward unit ARE the B operand of these).  dW / db are reduced with atomics at the end.
-constexpr int CB_ROWSTRIDE = 56;
-constexpr int CB_SLICE = 42 * CB_ROWSTRIDE;
-constexpr int CB_GROW = 2 * RES * CD;                   // per slice: one row of the xz-plane gradient and one of the xy-plane
-constexpr size_t CB_LDS_BYTES = (4 * CB_SLICE + CB_GROW) * sizeof(float);
+// Same decomposition as convin_project_kernel: workgroup = (x-part, iy-group x channel half, scene), the haloed TSDF
+// sub-volume is staged in LDS once, every wave owns SXW slices and runs without workgroup barriers; units of 16 voxels x
+// 16 channels.  Per unit: recompute pre = conv_in(x) + b (7 MFMAs), dF = (pre > 0) * (gxz + gxy + gyz) / 40, then
+// dW^T[tap][ch] += X^T[tap][voxel] * dF[voxel][ch] as 2 tap halves x 4 k-steps = 8 more MFMAs (the D registers of the
+// forward unit ARE the B operand of these).  The yz-plane gradient of a lane's 100 voxels does not depend on the slice and
+// lives in registers; the xz / xy rows of a slice are loaded into registers at the top of the slice.  Every workgroup
+// leaves one partial (27x16 weights + 16 biases, fixed-order sum of its 8 waves through LDS); convin_bwd_reduce_kernel adds
+// the workgroups up (no same-address atomics: those are resolved outside the XCD-local L2, one fabric operation each).
+constexpr int CB_RS = 44, CB_ROWS = 12;           // staged sub-volume: (XW+2) x 12 rows x 44 floats (iz + 1 in [0, 41])
+constexpr int CB_PART = 27 * 16 + 16;             // floats per workgroup partial: dW^T[tap][ch16], db[ch16]
+constexpr size_t cb_lds_bytes(int sxw) { return (size_t)(8 * sxw + 2) * CB_ROWS * CB_RS * sizeof(float); }
 
+template <int SXW>
 __global__ __launch_bounds__(512) void convin_bwd_kernel(const float* __restrict__ tsdf, const float* __restrict__ wpk,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ gplanes,   // [3][B][40][40][32]
-                                                         float* __restrict__ dW,              // [32][27]
-                                                         float* __restrict__ db,              // [32]
-                                                         int B, int SX) {
-    extern __shared__ __attribute__((aligned(16))) float slices[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                                         float* __restrict__ partial,         // [workgroup][CB_PART]
+                                                         int B) {
+    constexpr int XW = 8 * SXW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
-    const int chh = wave & 1, grp = wave >> 1;
-    const int slab = blockIdx.x, b = blockIdx.y;
-    const int ix0 = slab * SX;
+    const int xp = blockIdx.x, grp = blockIdx.y >> 1, chh = blockIdx.y & 1, b = blockIdx.z;
+    const int x0 = xp * XW;
     const float* vol = tsdf + (size_t)b * RES * RES * RES;
-    for (int i = tid; i < 4 * CB_SLICE; i += blockDim.x) slices[i] = 0.f;
+    for (int v = tid; v < (XW + 2) * CB_ROWS * 10; v += 512) {
+        const int q = v % 10, row = v / 10, yl = row % CB_ROWS, xl = row / CB_ROWS;
+        const int ix = x0 - 1 + xl, iy = 10 * grp - 1 + yl;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ix >= 0 && ix < RES && iy >= 0 && iy < RES)
+            val = *reinterpret_cast<const float4*>(vol + ((size_t)ix * RES + iy) * RES + 4 * q);
+        float* dst = lds + row * CB_RS + 1 + 4 * q;
+        dst[0] = val.x; dst[1] = val.y; dst[2] = val.z; dst[3] = val.w;
+        if (q == 0) dst[-1] = 0.f;
+        if (q == 9) dst[4] = 0.f;
+    }
     float wreg[7];
 #pragma unroll
     for (int s = 0; s < 7; ++s) wreg[s] = wpk[(chh * 7 + s) * 64 + lane];
     const int ch = 16 * chh + j;
     const float bn = bias[ch];
-    __syncthreads();
-    float* grow = slices + 4 * CB_SLICE;          // [2][40][32]: gxz[iz][ix][c] and gxy[iy][ix][c] of the current slice
     const size_t img_stride = (size_t)RES * RES * CD;
     const float* gxz = gplanes + ((size_t)0 * B + b) * img_stride;
     const float* gxy = gplanes + ((size_t)1 * B + b) * img_stride;
     const float* gyz = gplanes + ((size_t)2 * B + b) * img_stride;
-    auto load_slice = [&](int ix) {
-        float* dst = slices + ((ix + 1) & 3) * CB_SLICE;
-        const bool in = ix >= 0 && ix < RES;
-        for (int i = tid; i < RES * RES; i += blockDim.x)
-            dst[(i / RES + 1) * CB_ROWSTRIDE + (i % RES + 1)] = in ? vol[(size_t)ix * RES * RES + i] : 0.f;
-    };
-    // the upstream gradients of slice ix that do not depend on the unit position: staged once per slice instead of
-    // nine scattered global loads (full round trip each) inside every one of the 25 units
-    auto load_grow = [&](int ix) {
-        for (int i = tid; i < CB_GROW; i += blockDim.x) {
-            const int pl = i / (RES * CD), rest = i % (RES * CD);       // rest = row * 32 + c
-            grow[i] = (pl ? gxy : gxz)[((size_t)(rest / CD) * RES + ix) * CD + rest % CD];
-        }
-    };
-    load_slice(ix0 - 1); load_slice(ix0);
     const float inv = 1.0f / RES;
     // forward A operand: row i = lane&15 is voxel (iy_l = i>>3, iz_l = 4*((i>>2)&1) + (i&3)); k-slot g -> tap 4s+g
-    const int a_base = (grp * 10 + (j >> 3)) * CB_ROWSTRIDE + 4 * ((j >> 2) & 1) + (j & 3);
-    // backward A operand: row = tap (lane&15 + 16*th), k-slot g -> voxel row 4g + r of the unit
-    const int v_base = (grp * 10 + (g >> 1)) * CB_ROWSTRIDE + 4 * (g & 1);
+    int abase[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        int t = 4 * s + g;
+        t = t > 26 ? 26 : t;
+        abase[s] = ((t / 9) * CB_ROWS + (j >> 3) + (t / 3) % 3) * CB_RS + 4 * ((j >> 2) & 1) + (j & 3) + t % 3;
+    }
+    // backward A operand: row = tap (lane&15 + 16*th), k-slot g -> voxel row 4g + r of the unit (iy_l = g>>1, iz_l = 4(g&1)+r)
+    int tbase[2];
+#pragma unroll
+    for (int th = 0; th < 2; ++th) {
+        int t = j + 16 * th;
+        t = t > 26 ? 26 : t;                      // rows >= 27 of dW^T are never written back
+        tbase[th] = ((t / 9) * CB_ROWS + (g >> 1) + (t / 3) % 3) * CB_RS + 4 * (g & 1) + t % 3;
+    }
     // the yz-plane gradient of this lane's 100 voxels does not depend on the slice: registers, loaded once
     f32x4v gz[5][5];
 #pragma unroll
@@ -484,68 +493,97 @@ __global__ __launch_bounds__(512) void convin_bwd_kernel(const float* __restrict
         for (int zg = 0; zg < 5; ++zg)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                gz[ip][zg][r] = gyz[((size_t)(8 * zg + 4 * (g & 1) + r) * RES + grp * 10 + 2 * ip + (g >> 1)) * CD + ch];
-
+                gz[ip][zg][r] = gyz[((8 * zg + 4 * (g & 1) + r) * RES + grp * 10 + 2 * ip + (g >> 1)) * CD + ch];
     f32x4v accw[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
     float accb = 0.f;
-    for (int sx = 0; sx < SX; ++sx) {
-        const int ix = ix0 + sx;
-        __syncthreads();
-        load_slice(ix + 1);
-        load_grow(ix);
-        __syncthreads();
-        const int o[3] = {((ix + 0) & 3) * CB_SLICE, ((ix + 1) & 3) * CB_SLICE, ((ix + 2) & 3) * CB_SLICE};
-        int aoff[7], toff[2];
+    const f32x4v bias4 = {bn, bn, bn, bn};
+    __syncthreads();
+
+    for (int sx = 0; sx < SXW; ++sx) {
+        const int ixl = wave * SXW + sx, ix = x0 + ixl;
+        const int so = ixl * CB_ROWS * CB_RS;
+        // upstream gradients of this slice that do not depend on the unit: xy row per iy-pair, xz rows per (zg, r)
+        float gy[5];
+        f32x4v gx[5];
 #pragma unroll
-        for (int s = 0; s < 7; ++s) {
-            int t = 4 * s + g;
-            t = t > 26 ? 26 : t;
-            const int dx = t / 9;
-            aoff[s] = a_base + ((t / 3) % 3) * CB_ROWSTRIDE + t % 3 + (dx == 0 ? o[0] : dx == 1 ? o[1] : o[2]);
-        }
+        for (int ip = 0; ip < 5; ++ip) gy[ip] = gxy[((grp * 10 + 2 * ip + (g >> 1)) * RES + ix) * CD + ch];
 #pragma unroll
-        for (int th = 0; th < 2; ++th) {
-            int t = j + 16 * th;
-            t = t > 26 ? 26 : t;                  // rows >= 27 of dW^T are never written back
-            const int dx = t / 9;
-            toff[th] = v_base + ((t / 3) % 3) * CB_ROWSTRIDE + t % 3 + (dx == 0 ? o[0] : dx == 1 ? o[1] : o[2]);
-        }
+        for (int zg = 0; zg < 5; ++zg)
 #pragma unroll
-        for (int ip = 0; ip < 5; ++ip) {
-            const float gy_ = grow[RES * CD + (grp * 10 + 2 * ip + (g >> 1)) * CD + ch];
+            for (int r = 0; r < 4; ++r) gx[zg][r] = gxz[((8 * zg + 4 * (g & 1) + r) * RES + ix) * CD + ch];
 #pragma unroll
-            for (int zg = 0; zg < 5; ++zg) {
-                const int uo = 2 * ip * CB_ROWSTRIDE + 8 * zg;
-                f32x4v d = {bn, bn, bn, bn};                  // bias in the C operand, as the forward does
+        for (int zg = 0; zg < 5; ++zg) {
+            // forward recompute: five independent 7-MFMA chains (bias in the C operand, as the forward does)
+            f32x4v d[5];
 #pragma unroll
-                for (int s = 0; s < 7; ++s) d = mfma32_16(slices[aoff[s] + uo], wreg[s], d);
-                // upstream gradient of the three axis means for this lane's 4 voxels (iz = 8zg + 4(g&1) + r)
+            for (int ip = 0; ip < 5; ++ip) d[ip] = bias4;
+#pragma unroll
+            for (int s = 0; s < 7; ++s)
+#pragma unroll
+                for (int ip = 0; ip < 5; ++ip)
+                    d[ip] = mfma32_16(lds[abase[s] + so + 2 * ip * CB_RS + 8 * zg], wreg[s], d[ip]);
+#pragma unroll
+            for (int ip = 0; ip < 5; ++ip) {
+                const int uo = so + 2 * ip * CB_RS + 8 * zg;
                 f32x4v dF;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float gxz_r = grow[(8 * zg + 4 * (g & 1) + r) * CD + ch];
-                    const float gsum = gxz_r + gy_ + gz[ip][zg][r];
-                    dF[r] = d[r] > 0.f ? gsum * inv : 0.f;
+                    const float gsum = gx[zg][r] + gy[ip] + gz[ip][zg][r];
+                    dF[r] = d[ip][r] > 0.f ? gsum * inv : 0.f;
                     accb += dF[r];
                 }
 #pragma unroll
                 for (int th = 0; th < 2; ++th)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) accw[th] = mfma32_16(slices[toff[th] + uo + r], dF[r], accw[th]);
+                    for (int r = 0; r < 4; ++r) accw[th] = mfma32_16(lds[tbase[th] + uo + r], dF[r], accw[th]);
             }
         }
     }
-    // accw[th][r]: dW^T[tap = 16th + 4g + r][ch]
+    // ---- workgroup partial: fixed-order sum of the 8 waves.  accw[th][r]: dW^T[tap = 16th + 4g + r][ch] ----------------
+    accb += __shfl_xor(accb, 16);
+    accb += __shfl_xor(accb, 32);
+    __syncthreads();                                  // every wave is done with the sub-volume
+    float* red = lds;                                 // [wave][CB_PART]
 #pragma unroll
     for (int th = 0; th < 2; ++th)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int tap = 16 * th + 4 * g + r;
-            if (tap < 27) atomicAdd(dW + ch * 27 + tap, accw[th][r]);
+            if (tap < 27) red[wave * CB_PART + tap * 16 + j] = accw[th][r];
         }
-    accb += __shfl_xor(accb, 16);
-    accb += __shfl_xor(accb, 32);
-    if (g == 0) atomicAdd(db + ch, accb);
+    if (g == 0) red[wave * CB_PART + 27 * 16 + j] = accb;
+    __syncthreads();
+    if (tid < CB_PART) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) sum += red[w * CB_PART + tid];
+        const int wgi = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partial[(size_t)wgi * CB_PART + tid] = sum;
+    }
+}
+
+// dW[ch][tap] / db[ch] = sum over the scene's workgroups of one (channel half): partial[scene][grp*2+chh][xp][CB_PART]
+__global__ __launch_bounds__(256) void convin_bwd_reduce_kernel(const float* __restrict__ partial, int B, int nxp,
+                                                                float* __restrict__ dW, float* __restrict__ db) {
+    __shared__ float sm[256];
+    const int e = blockIdx.x, chh = blockIdx.y;       // e: element of the partial (tap*16 + j, or 432 + j)
+    float s = 0.f;
+    const int per_scene = 8 * nxp;                    // workgroups per scene, (grp*2+chh) major, x-part minor
+    for (int i = threadIdx.x; i < B * 4 * nxp; i += 256) {
+        const int bq = i / (4 * nxp), rest = i % (4 * nxp), grp = rest / nxp, xp = rest % nxp;
+        s += partial[((size_t)bq * per_scene + (grp * 2 + chh) * nxp + xp) * CB_PART + e];
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) sm[threadIdx.x] += sm[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int jj = e & 15, ch = 16 * chh + jj;
+        if (e < 27 * 16) dW[ch * 27 + (e >> 4)] += sm[0];
+        else db[ch] += sm[0];
+    }
 }
 
 // ------------------------------- driver -----------------------------------------------------------------------
@@ -569,6 +607,7 @@ BwdWs enc_bwd_workspace(int B) {
 struct EncWs { size_t P0, A0, S0, Q0, A1, S1, Q1, A2, S2, U0, A3, A4, U1, A5, A6, YZ, XZ, total; };
 EncWs enc_workspace(int B, int precision, int nslab);
 int enc_nslab(int B);
+int enc_nxp(int B);
 
 int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws,
                             float* gplanes /* [3B][40][40][32], in: dLoss/dPlanes, clobbered */, uint8_t* gws,
@@ -700,13 +739,23 @@ int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_
     rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false>(dgrad_args(0, G(g.gA0), 0, G(g.gP0)), s);
     // conv_in + projection
     {
-        const int nslab = enc_nslab(B);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convin_bwd_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)CB_LDS_BYTES);
-        hipLaunchKernelGGL(convin_bwd_kernel, dim3(nslab, B), dim3(512), CB_LDS_BYTES, s, tsdf,
-                           reinterpret_cast<const float*>(blob + ko.convin_w),
-                           reinterpret_cast<const float*>(blob + ko.convin_b), G(g.gP0), grads + po.conv_in_w,
-                           grads + po.conv_in_b, B, RES / nslab);
+        const int nxp = enc_nxp(B);
+        const float* cw = reinterpret_cast<const float*>(blob + ko.convin_w);
+        const float* cb = reinterpret_cast<const float*>(blob + ko.convin_b);
+        float* part = G(g.WG);                        // free again: the 3x3 weight gradients are done
+        if (nxp == 1) {
+            auto kern = convin_bwd_kernel<5>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)cb_lds_bytes(5));
+            hipLaunchKernelGGL(kern, dim3(1, 8, B), dim3(512), cb_lds_bytes(5), s, tsdf, cw, cb, G(g.gP0), part, B);
+        } else {
+            auto kern = convin_bwd_kernel<1>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)cb_lds_bytes(1));
+            hipLaunchKernelGGL(kern, dim3(5, 8, B), dim3(512), cb_lds_bytes(1), s, tsdf, cw, cb, G(g.gP0), part, B);
+        }
+        hipLaunchKernelGGL(convin_bwd_reduce_kernel, dim3(CB_PART, 2), dim3(256), 0, s, part, B, nxp, grads + po.conv_in_w,
+                           grads + po.conv_in_b);
     }
     if (hipGetLastError() != hipSuccess) rc |= -10;
     return rc;
