@@ -24,8 +24,7 @@ int launch_decoder_backward(const float* planes, const float* p, const uint8_t* 
                             float* grads, int head_present, float* scratch, int B, int N, hipStream_t s);
 // giga_encoder.hip
 struct EncWs { size_t P0, A0, S0, Q0, A1, S1, Q1, A2, S2, U0, A3, A4, U1, A5, A6, YZ, XZ, total; };
-EncWs enc_workspace(int B, int precision, int nslab);
-int enc_nslab(int B);
+EncWs enc_workspace(int B, int precision);
 int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, float* planes_nchw, int B,
                    int precision, uint8_t* ws, hipStream_t s, int probe_stage, void* ev0, void* ev1);
 // giga_decoder.hip
@@ -92,12 +91,12 @@ int giga_repack_device(const float* params_dev, const int32_t* map_dev, void* pa
 
 size_t giga_encoder_workspace_bytes(int B, int precision) {
     if (B <= 0) return 0;
-    return enc_workspace(B, precision, enc_nslab(B)).total;
+    return enc_workspace(B, precision).total;
 }
 
 int giga_encoder_workspace_layout(int B, int precision, size_t* offsets) {
     if (B <= 0 || !offsets) return -1;
-    const EncWs w = enc_workspace(B, precision, enc_nslab(B));
+    const EncWs w = enc_workspace(B, precision);
     const size_t v[17] = {w.P0, w.A0, w.S0, w.Q0, w.A1, w.S1, w.Q1, w.A2, w.S2, w.U0, w.A3, w.A4, w.U1, w.A5, w.A6,
                           w.YZ, w.XZ};
     for (int i = 0; i < 17; ++i) offsets[i] = v[i];

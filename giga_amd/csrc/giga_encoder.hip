@@ -89,6 +89,7 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
     const float inv = 1.0f / RES;
     const size_t img_stride = (size_t)RES * RES * CD;
     TOut* plane_xy = planes + ((size_t)1 * B + b) * img_stride;
+    TOut* plane_yz = planes + ((size_t)2 * B + b) * img_stride;
     float* xzp = xz_partial + ((size_t)grp * B + b) * img_stride;
     const f32x4v bias4 = {bn, bn, bn, bn};            // the bias rides in the C operand of the first MFMA
     const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -187,8 +188,13 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
             const int u = U0[rd] + ul, ip = u / 5, zg = u % 5, lg = ln >> 4, lj = ln & 15;
             const int iy = grp * 10 + 2 * ip + (lg >> 1), iz0 = 8 * zg + 4 * (lg & 1);
             const int di = (iz0 * RES + iy) * CD + 16 * chh + lj;
+            if constexpr (SXW == 5) {                          // one x-part: this IS the plane (mean over all 40 ix)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) yzp[di + r * RES * CD] = sum[r];
+                for (int r = 0; r < 4; ++r) plane_yz[di + r * RES * CD] = (TOut)(sum[r] * inv);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yzp[di + r * RES * CD] = sum[r];
+            }
         }
     }
 }
@@ -203,12 +209,16 @@ __global__ void plane_finalize_kernel(const float* __restrict__ xz_partial, cons
     const f32x4v* xs = reinterpret_cast<const f32x4v*>(xz_partial) + t;
     const f32x4v* ys = reinterpret_cast<const f32x4v*>(yz_partial) + t;
     f32x4v sx = (xs[0] + xs[per4]) + (xs[2 * per4] + xs[3 * per4]);
-    f32x4v sy = ys[0];
-    for (int k = 1; k < nxp; ++k) sy += ys[(size_t)k * per4];
     TOut* dx = planes + 4 * t;
-    TOut* dy = planes + 2 * 4 * per4 + 4 * t;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { dx[r] = (TOut)(sx[r] * (1.0f / RES)); dy[r] = (TOut)(sy[r] * (1.0f / RES)); }
+    for (int r = 0; r < 4; ++r) dx[r] = (TOut)(sx[r] * (1.0f / RES));
+    if (nxp > 1) {                                          // (one x-part: conv_in wrote the yz plane itself)
+        f32x4v sy = ys[0];
+        for (int k = 1; k < nxp; ++k) sy += ys[(size_t)k * per4];
+        TOut* dy = planes + 2 * 4 * per4 + 4 * t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dy[r] = (TOut)(sy[r] * (1.0f / RES));
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -222,7 +232,7 @@ struct EncWs {
 // x-parts of conv_in+project: 1 (8*B workgroups, five slices per wave) from 32 scenes up, else 5 (40*B workgroups)
 int enc_nxp(int B) { return B >= 32 ? 1 : 5; }
 
-EncWs enc_workspace(int B, int precision, int nslab) {
+EncWs enc_workspace(int B, int precision) {
     const size_t es = precision == 1 ? 2 : 4;
     const size_t n = 3 * (size_t)B;
     EncWs w{};
@@ -233,19 +243,10 @@ EncWs enc_workspace(int B, int precision, int nslab) {
     w.Q1 = take(n * 100 * 64, es);  w.A2 = take(n * 100 * 128, es); w.S2 = take(n * 100 * 128, es);
     w.U0 = take(n * 400 * 64, es);  w.A3 = take(n * 400 * 64, es);  w.A4 = take(n * 400 * 64, es);
     w.U1 = take(n * 1600 * 32, es); w.A5 = take(n * 1600 * 32, es); w.A6 = take(n * 1600 * 32, es);
-    (void)nslab;                                            // (slab count of the backward's conv_in kernel)
     w.YZ = take((size_t)(4 + enc_nxp(B)) * B * 1600 * 32, 4);   // 4 xz partials (iy-groups) + NXP yz partials (x-parts)
     w.XZ = w.YZ;
     w.total = at;
     return w;
-}
-
-// slabs per scene: the smallest divisor of 40 that gives >= 256 workgroups (one per CU), at most 40
-int enc_nslab(int B) {
-    const int divs[8] = {1, 2, 4, 5, 8, 10, 20, 40};
-    for (int d : divs)
-        if ((long long)B * d >= 256) return d;
-    return 40;
 }
 
 // probe: if probe_stage == k, ev0/ev1 (hipEvent_t) are recorded right before / after launch k
@@ -260,8 +261,7 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     auto post = [&]() { if (pr.stage == stage_no) (void)hipEventRecord(pr.ev1, s); ++stage_no; };
     constexpr int precision = sizeof(T) == 2 ? 1 : 0;
     const PackOff ko = pack_offsets();
-    const int nslab = enc_nslab(B);
-    const EncWs w = enc_workspace(B, precision, nslab);
+    const EncWs w = enc_workspace(B, precision);
     T* P0 = reinterpret_cast<T*>(ws + w.P0);
     const size_t per = (size_t)B * RES * RES * CD;
     float* XZP = reinterpret_cast<float*>(ws + w.YZ);

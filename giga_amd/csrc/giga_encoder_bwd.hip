@@ -605,8 +605,7 @@ BwdWs enc_bwd_workspace(int B) {
 }
 
 struct EncWs { size_t P0, A0, S0, Q0, A1, S1, Q1, A2, S2, U0, A3, A4, U1, A5, A6, YZ, XZ, total; };
-EncWs enc_workspace(int B, int precision, int nslab);
-int enc_nslab(int B);
+EncWs enc_workspace(int B, int precision);
 int enc_nxp(int B);
 
 int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws,
@@ -616,7 +615,7 @@ int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_
     const PackOff ko = pack_offsets();
     const BwdPackOff bo = bwd_pack_offsets();
     const ParamOff po = param_offsets(head_present);
-    const EncWs f = enc_workspace(B, 0, enc_nslab(B));
+    const EncWs f = enc_workspace(B, 0);
     const BwdWs g = enc_bwd_workspace(B);
     const int nimg = 3 * B;
     auto F = [&](size_t off) { return reinterpret_cast<const float*>(fws + off); };
