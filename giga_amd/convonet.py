@@ -199,9 +199,11 @@ class LocalVoxelEncoder(nn.Module):
         params = _encoder_param_list(self)
         return self._packed.get(params, 0, device)     # encoder-only blob (no heads)
 
-    def encode_nhwc(self, x, blob=None, want_nchw=False, precision=None, probe=None):
+    def encode_nhwc(self, x, blob=None, want_nchw=False, precision=None, probe=None, fold_final=False):
         """Run the HIP encoder.  Returns (nhwc planes [3,B,40,40,32], nchw [3,B,32,40,40] or None).
-        probe = (stage, ev_start, ev_stop) brackets one kernel launch with HIP events (bench.py)."""
+        probe = (stage, ev_start, ev_stop) brackets one kernel launch with HIP events (bench.py).
+        fold_final: stop before conv_final (unet.py:238); the planes are then only valid for `decode_heads(...,
+        folded=True)`, whose head images carry that 1x1 convolution inside fc_c (GIGA_FOLD_FINAL, include/giga_hip.h)."""
         _capi.require_device(x)
         prec = _capi.PRECISION[precision or self.precision]
         if x.dim() != 4 or tuple(x.shape[1:]) != (RES, RES, RES):
@@ -220,8 +222,11 @@ class LocalVoxelEncoder(nn.Module):
             ws = torch.empty(max(L.giga_encoder_workspace_bytes(B, prec), 16), dtype=torch.uint8, device=x.device)
             self._ws[key] = ws
         stage, ev0, ev1 = probe if probe is not None else (-1, None, None)
+        if fold_final and want_nchw:
+            raise ValueError("fold_final planes are an internal representation; the reference layout needs the final planes")
         _capi.check(L.giga_encoder_forward_probe(_capi.ptr(x), _capi.ptr(blob), _capi.ptr(nhwc), _capi.ptr(nchw),
-                                                 B, prec, _capi.ptr(ws), ws.numel(), _capi.stream_ptr(),
+                                                 B, prec | (_capi.FOLD_FINAL if fold_final else 0),
+                                                 _capi.ptr(ws), ws.numel(), _capi.stream_ptr(),
                                                  stage, ev0, ev1),
                     "giga_encoder_forward")
         return nhwc, nchw
@@ -280,9 +285,10 @@ def _lattice_of(p):
     return ent[1], ent[2]
 
 
-def decode_heads(nhwc, p, blob, head_mask, precision, post, probe=None):
+def decode_heads(nhwc, p, blob, head_mask, precision, post, probe=None, folded=False):
     """One fused launch for every head in `head_mask` over p (B,N,3).  Returns dict name->tensor.
     probe = (ev_start, ev_stop) brackets the launch with HIP events (bench.py).
+    folded: `nhwc` came from `encode_nhwc(..., fold_final=True)` (planes before conv_final).
     A registered lattice tensor (shape (1, R^3, 3)) is shared by all scenes and takes the lattice path."""
     _capi.require_device(nhwc, p, blob)
     if p.dim() != 3 or p.shape[-1] != 3:
@@ -307,6 +313,7 @@ def decode_heads(nhwc, p, blob, head_mask, precision, post, probe=None):
     if lat is not None:
         lin, R = lat
         prec = _capi.PRECISION[precision]
+        fold = _capi.FOLD_FINAL if folded else 0
         L = _capi.lib()
         key = (B, R, prec, str(dev))
         ws = _LATTICE_WS.get(key)
@@ -318,14 +325,15 @@ def decode_heads(nhwc, p, blob, head_mask, precision, post, probe=None):
             _capi.ptr(nhwc), _capi.ptr(lin), _capi.ptr(blob), head_mask,
             _capi.ptr(out.get("decoder_qual")), _capi.ptr(out.get("decoder_rot")),
             _capi.ptr(out.get("decoder_width")), _capi.ptr(out.get("decoder_tsdf")),
-            B, R, prec, 1 if post else 0, _capi.ptr(ws), ws.numel(), _capi.stream_ptr(), ev0, ev1),
+            B, R, prec | fold, 1 if post else 0, _capi.ptr(ws), ws.numel(), _capi.stream_ptr(), ev0, ev1),
             "giga_decoder_forward_lattice")
         return out
     _capi.check(_capi.lib().giga_decoder_forward_probe(
         _capi.ptr(nhwc), _capi.ptr(p), _capi.ptr(blob), head_mask,
         _capi.ptr(out.get("decoder_qual")), _capi.ptr(out.get("decoder_rot")),
         _capi.ptr(out.get("decoder_width")), _capi.ptr(out.get("decoder_tsdf")),
-        B, N, _capi.PRECISION[precision], 1 if post else 0, _capi.stream_ptr(), ev0, ev1),
+        B, N, _capi.PRECISION[precision] | (_capi.FOLD_FINAL if folded else 0), 1 if post else 0, _capi.stream_ptr(),
+        ev0, ev1),
         "giga_decoder_forward")
     return out
 
@@ -423,11 +431,13 @@ class ConvolutionalOccupancyNetwork(nn.Module):
         if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
             return self._forward_train(inputs, p, p_tsdf)
         blob = self.packed_blob(inputs.device)
-        nhwc, _ = self.encoder.encode_nhwc(inputs, blob=blob, precision=self.precision, probe=_probe)
-        g = decode_heads(nhwc, p, blob, 7, self.precision, post=True)
+        # encoder and decoders are called back to back here, so conv_final is folded into the heads' fc_c weights and
+        # never launched (GIGA_FOLD_FINAL); encode_inputs / decode keep exchanging the final planes, as the reference does
+        nhwc, _ = self.encoder.encode_nhwc(inputs, blob=blob, precision=self.precision, probe=_probe, fold_final=True)
+        g = decode_heads(nhwc, p, blob, 7, self.precision, post=True, folded=True)
         out = (g["decoder_qual"], g["decoder_rot"], g["decoder_width"])
         if p_tsdf is not None:
-            t = decode_heads(nhwc, p_tsdf, blob, 8, self.precision, post=False)
+            t = decode_heads(nhwc, p_tsdf, blob, 8, self.precision, post=False, folded=True)
             out = out + (t["decoder_tsdf"],)
         return out
 

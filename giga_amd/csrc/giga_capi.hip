@@ -90,6 +90,7 @@ int giga_repack_device(const float* params_dev, const int32_t* map_dev, void* pa
 }
 
 size_t giga_encoder_workspace_bytes(int B, int precision) {
+    precision &= ~GIGA_FOLD_FINAL;
     if (B <= 0) return 0;
     return enc_workspace(B, precision).total;
 }
@@ -107,9 +108,13 @@ int giga_encoder_forward_probe(const float* tsdf, const void* packed, void* plan
                                int B, int precision, void* workspace, size_t workspace_bytes, void* stream,
                                int probe_stage, void* ev_start, void* ev_stop) {
     if (B < 0 || (B > 0 && (!tsdf || !packed || !planes_nhwc || !workspace))) return -1;
+    const bool fold = (precision & GIGA_FOLD_FINAL) != 0;     // stop before conv_final (folded decoder images)
+    precision &= ~GIGA_FOLD_FINAL;
     if (precision != 0 && precision != 1) return -5;
+    if (fold && planes_nchw) return -1;                       // the reference-layout copy is the FINAL planes only
     if (workspace_bytes < giga_encoder_workspace_bytes(B, precision)) return -4;
-    return launch_encoder(tsdf, static_cast<const uint8_t*>(packed), planes_nhwc, planes_nchw, B, precision,
+    return launch_encoder(tsdf, static_cast<const uint8_t*>(packed), planes_nhwc, planes_nchw, B,
+                          precision | (fold ? GIGA_FOLD_FINAL : 0),
                           static_cast<uint8_t*>(workspace), static_cast<hipStream_t>(stream), probe_stage,
                           ev_start, ev_stop);
 }
@@ -160,6 +165,8 @@ int giga_decoder_forward_probe(const void* planes_nhwc, const float* p, const vo
                                float* qual, float* rot, float* width, float* occ, int B, int N, int precision,
                                int post, void* stream, void* ev_start, void* ev_stop) {
     if (B < 0 || N < 0) return -1;
+    const bool fold = (precision & GIGA_FOLD_FINAL) != 0;     // planes are the encoder output BEFORE conv_final
+    precision &= ~GIGA_FOLD_FINAL;
     if (precision != 0 && precision != 1) return -5;
     if ((long long)B * N == 0 || (head_mask & 15) == 0) return 0;
     if (!planes_nhwc || !p || !packed) return -1;
@@ -171,7 +178,7 @@ int giga_decoder_forward_probe(const void* planes_nhwc, const float* p, const vo
         if (!(head_mask >> h & 1)) continue;
         if (!outs[h]) return -6;
         a.head_id[a.nheads] = h;
-        a.head_off[a.nheads] = precision == 1 ? ko.dec16[h] : ko.dec32[h];
+        a.head_off[a.nheads] = precision == 1 ? (fold ? ko.dec16f[h] : ko.dec16[h]) : (fold ? ko.dec32f[h] : ko.dec32[h]);
         a.out[a.nheads] = outs[h];
         ++a.nheads;
     }
@@ -180,6 +187,7 @@ int giga_decoder_forward_probe(const void* planes_nhwc, const float* p, const vo
 }
 
 size_t giga_lattice_workspace_bytes(int B, int R, int precision) {
+    precision &= ~GIGA_FOLD_FINAL;
     if (B <= 0 || R <= 0) return 0;
     return (size_t)3 * B * R * R * CD * (precision == 1 ? 2 : 4);
 }
@@ -189,6 +197,8 @@ int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, cons
                                  int post, void* workspace, size_t workspace_bytes, void* stream, void* ev_start,
                                  void* ev_stop) {
     if (B < 0 || R < 0 || R > 64) return -1;
+    const bool fold = (precision & GIGA_FOLD_FINAL) != 0;
+    precision &= ~GIGA_FOLD_FINAL;
     if (precision != 0 && precision != 1) return -5;
     if (B == 0 || R == 0 || (head_mask & 15) == 0) return 0;
     if (!planes_nhwc || !lin || !packed || !workspace) return -1;
@@ -204,7 +214,7 @@ int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, cons
         if (!(head_mask >> h & 1)) continue;
         if (!outs[h]) return -6;
         a.head_id[a.nheads] = h;
-        a.head_off[a.nheads] = precision == 1 ? ko.dec16[h] : ko.dec32[h];
+        a.head_off[a.nheads] = precision == 1 ? (fold ? ko.dec16f[h] : ko.dec16[h]) : (fold ? ko.dec32f[h] : ko.dec32[h]);
         a.out[a.nheads] = outs[h];
         ++a.nheads;
     }

@@ -6,6 +6,7 @@
 // Kernel 1 (convin_project_kernel) fuses the 3-D conv, the ReLU and the three axis means, so the
 // 32x40^3 feature volume (8.2 MB/scene in the reference) is never written to memory.  Kernel 2
 // (conv16_kernel) is one LDS-staged implicit-GEMM convolution used for every U-Net layer.
+#include "../../include/giga_hip.h"
 #include "giga_dev.h"
 #include "giga_conv16.h"
 
@@ -255,7 +256,7 @@ struct Probe { int stage; hipEvent_t ev0, ev1; };
 
 template <typename T>
 static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc, float* planes_nchw, int B,
-                       uint8_t* ws, hipStream_t s, const Probe& pr) {
+                       uint8_t* ws, hipStream_t s, const Probe& pr, bool fold_final) {
     int stage_no = 0;
     auto pre = [&]() { if (pr.stage == stage_no) (void)hipEventRecord(pr.ev0, s); };
     auto post = [&]() { if (pr.stage == stage_no) (void)hipEventRecord(pr.ev1, s); ++stage_no; };
@@ -314,8 +315,13 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     pre(); rc |= launch_conv<T, CONV3, 64, 0, 64, 20, 20, 1, false>(args(8, b + w.A3, nullptr, b + w.A4, nullptr), s); post();
     pre(); rc |= launch_conv<T, UPCONV, 64, 0, 32, 20, 20, 2, false>(args(9, b + w.A4, nullptr, b + w.U1, nullptr), s); post();
     pre(); rc |= launch_conv<T, CONV3, 32, 32, 32, 40, 40, 2, false>(args(10, b + w.U1, b + w.S0, b + w.A5, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 32, 0, 32, 40, 40, 2, false>(args(11, b + w.A5, nullptr, b + w.A6, nullptr), s); post();
-    {
+    // GIGA_FOLD_FINAL: the caller's decoder carries conv_final inside its fc_c weights, so up1.conv2 writes straight
+    // into the output planes and the last layer is not launched (its probe stage then brackets nothing)
+    void* a6 = fold_final ? planes_nhwc : static_cast<void*>(b + w.A6);
+    pre(); rc |= launch_conv<T, CONV3, 32, 0, 32, 40, 40, 2, false>(args(11, b + w.A5, nullptr, a6, nullptr), s); post();
+    if (fold_final) {
+        pre(); post();
+    } else {
         ConvArgs a = args(12, b + w.A6, nullptr, planes_nhwc, nullptr);
         a.out_nchw = planes_nchw;
         pre(); rc |= launch_conv<T, CONV1, 32, 0, 32, 40, 40, 2, false>(a, s); post();
@@ -327,8 +333,9 @@ int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, fl
                    int precision, uint8_t* ws, hipStream_t s, int probe_stage, void* ev0, void* ev1) {
     if (B <= 0) return 0;
     Probe pr{ev0 && ev1 ? probe_stage : -1, static_cast<hipEvent_t>(ev0), static_cast<hipEvent_t>(ev1)};
-    return precision == 1 ? encoder_run<half_t>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr)
-                          : encoder_run<float>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr);
+    const bool fold = (precision & GIGA_FOLD_FINAL) != 0;
+    return (precision & 1) ? encoder_run<half_t>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold)
+                           : encoder_run<float>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold);
 }
 
 }  // namespace giga

@@ -116,6 +116,7 @@ struct PackOff {
     size_t convin_b;        // fp32 [32]
     ConvPackOff conv[NCONV];
     size_t dec16[NHEADS], dec32[NHEADS];
+    size_t dec16f[NHEADS], dec32f[NHEADS];   // the same heads with the encoder's final 1x1 conv folded into fc_c (see giga_pack.cpp)
     size_t total;
 };
 
@@ -139,6 +140,10 @@ inline PackOff pack_offsets() {
     for (int h = 0; h < NHEADS; ++h) {
         o.dec16[h] = at; at += align_up(DEC16_BYTES, 256);
         o.dec32[h] = at; at += align_up(DEC32_BYTES, 256);
+    }
+    for (int h = 0; h < NHEADS; ++h) {
+        o.dec16f[h] = at; at += align_up(DEC16_BYTES, 256);
+        o.dec32f[h] = at; at += align_up(DEC32_BYTES, 256);
     }
     o.total = at;
     return o;

@@ -192,6 +192,37 @@ int pack_weights_host(const float* P, size_t n_params, int head_present, uint8_t
         pack_head16(P, po.head[h], HEAD_OUT[h], blob + ko.dec16[h]);
         pack_head32(P, po.head[h], HEAD_OUT[h], blob + ko.dec32[h]);
     }
+    // Folded variants.  The encoder ends with conv_final, a 1x1 convolution WITHOUT activation (unet.py:238), and the
+    // decoder's first use of the planes is linear too: bilinear sampling (decoder.py:117-122) followed by fc_c (:169).
+    // Sampling commutes with a per-pixel linear map, so  fc_c(sample(Wf x + bf)) = (Wc blockdiag(Wf,Wf,Wf)) sample(x) +
+    // (bc + Wc [bf;bf;bf]):  with these fc_c weights the decoder reads the planes BEFORE conv_final and the encoder can
+    // skip that layer (GIGA_FOLD_FINAL).  Products are accumulated in double, then rounded to fp32 once.
+    {
+        std::vector<float> Pf(P, P + n_params);
+        const float* Wf = P + po.conv_w[NCONV - 1];          // [co][ci] (32 x 32 x 1 x 1)
+        const float* bf = P + po.conv_b[NCONV - 1];
+        for (int h = 0; h < NHEADS; ++h) {
+            if (!(head_present >> h & 1)) continue;
+            const HeadParamOff& ho = po.head[h];
+            for (int b = 0; b < NBLK; ++b) {
+                const float* Wc = P + ho.fc_c_w[b];           // [32][96]
+                for (int n = 0; n < 32; ++n) {
+                    double bacc = P[ho.fc_c_b[b] + n];
+                    for (int pl = 0; pl < 3; ++pl) {
+                        for (int ci = 0; ci < CD; ++ci) {
+                            double acc = 0.0;
+                            for (int co = 0; co < CD; ++co) acc += (double)Wc[n * 96 + pl * 32 + co] * Wf[co * CD + ci];
+                            Pf[ho.fc_c_w[b] + n * 96 + pl * 32 + ci] = (float)acc;
+                        }
+                        for (int co = 0; co < CD; ++co) bacc += (double)Wc[n * 96 + pl * 32 + co] * bf[co];
+                    }
+                    Pf[ho.fc_c_b[b] + n] = (float)bacc;
+                }
+            }
+            pack_head16(Pf.data(), ho, HEAD_OUT[h], blob + ko.dec16f[h]);
+            pack_head32(Pf.data(), ho, HEAD_OUT[h], blob + ko.dec32f[h]);
+        }
+    }
     return 0;
 }
 

@@ -96,6 +96,14 @@ int giga_decoder_forward(const void* planes_nhwc, const float* p, const void* pa
                          float* qual, float* rot, float* width, float* occ, int B, int N,
                          int precision, int post, void* stream);
 
+/* GIGA_FOLD_FINAL, OR-ed into `precision` of giga_encoder_forward* AND of the giga_decoder_forward* call that consumes its
+ * planes: the encoder stops before its last layer, conv_final (a 1x1 convolution without activation, encoder/unet.py:238),
+ * and the decoder uses head images in which that layer is folded into fc_c -- bilinear sampling (decoder.py:117-122)
+ * commutes with a per-pixel linear map, so fc_c(sample(Wf x + bf)) = (Wc blockdiag(Wf)) sample(x) + (bc + Wc bf).  Same
+ * outputs (fp32 rounding-level differences), one layer less.  planes_nchw must be NULL with this flag: the planes it
+ * produces are NOT LocalVoxelEncoder's return value and are only meaningful to a decoder call carrying the flag. */
+#define GIGA_FOLD_FINAL 16
+
 /* Inference fast path for the FIXED QUERY LATTICE of VGNImplicit (detection_implicit.py:28-31,107):
  * the R^3 points meshgrid(lin, lin, lin, 'ij') with z fastest, shared by all B scenes.  Each plane is
  * sampled at only R*R distinct positions, so the planes are first resampled at the lattice coordinates

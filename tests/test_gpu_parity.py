@@ -248,3 +248,24 @@ def test_tsdf_feed_pinned_double_buffer(sd7):
         assert torch.equal(xb.cpu(), torch.from_numpy(host[i][0])) and torch.equal(pb.cpu(), host[i][1])
         seen += 1
     assert seen == 5
+
+
+@pytest.mark.gpu
+def test_folded_final_conv_matches_piecewise_path(sd7):
+    """net(x, p, p_tsdf) folds conv_final into the decoders' fc_c (GIGA_FOLD_FINAL); the piecewise reference-style calls
+    (encode_inputs -> decode / decode_occ) exchange the FINAL planes.  Both must agree with each other and the oracle."""
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(synth.tsdf_batch(90, 3))
+    p = torch.from_numpy(synth.query_points(90, 3, 333, stream=4, half_width=0.55))
+    ref = O.model_forward(sd7, x, p, p_tsdf=p)
+    for prec, tol_pair, tol_ref in (("fp32", 2e-5, 1e-4), ("fp16", 1e-2, 1e-2)):
+        net = networks.get_network("giga")
+        net.load_state_dict(sd7)
+        net = net.to(dev).eval().set_precision(prec)
+        with torch.no_grad():
+            fused = net(x.to(dev), p.to(dev), p_tsdf=p.to(dev))
+            c = net.encode_inputs(x.to(dev))
+            piece = net.decode(p.to(dev), c) + (net.decode_occ(p.to(dev), c).logits,)
+        for a, b, r in zip(fused, piece, ref):
+            assert (a - b).abs().max().item() < tol_pair
+            assert (a.cpu() - r).abs().max().item() < tol_ref

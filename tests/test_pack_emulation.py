@@ -31,6 +31,10 @@ def _blob_and_offsets(sd):
     for _ in range(4):
         dec16.append(at); at += up(59 * 1024)          # 58 fragments + C table in a 59th 1 KiB chunk
         dec32.append(at); at += up(111 * 1024)
+    dec16f, dec32f = [], []                            # the same heads with conv_final folded into fc_c (GIGA_FOLD_FINAL)
+    for _ in range(4):
+        dec16f.append(at); at += up(59 * 1024)
+        dec32f.append(at); at += up(111 * 1024)
     assert at == blob.size
     return blob, dec16, dec32
 
