@@ -150,7 +150,7 @@ static int launch_wgrad(WgradArgs a, hipStream_t s) {
     a.mHW = (unsigned)((0x100000000ULL + (unsigned)(a.H * a.W) - 1) / (unsigned)(a.H * a.W));
     a.mW = (unsigned)((0x100000000ULL + (unsigned)a.W - 1) / (unsigned)a.W);
     const int blocks_wn = a.taps * a.Mb * a.Nb;
-    int ksplit = 2048 / blocks_wn;
+    int ksplit = 768 / blocks_wn;      // few workgroups per gradient element: every atomic is a fabric operation
     if (ksplit < 1) ksplit = 1;
     long long ppb = (a.npix + ksplit - 1) / ksplit;
     ppb = (ppb + 31) / 32 * 32;
