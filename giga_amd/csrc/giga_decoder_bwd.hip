@@ -434,7 +434,7 @@ int launch_decoder_backward(const float* planes, const float* p, const uint8_t* 
         add(S + 0 * AS, a.Pbuf, 32, grads + o.fc_p_w, grads + o.fc_p_b, 3, 32, 3);                             // fc_p: DN[0], p
         L.nb_start[L.nprob] = L.nb_total;
         L.P = P;
-        int ksplit = 1024 / L.nb_total;
+        int ksplit = 2048 / L.nb_total;
         if (ksplit < 1) ksplit = 1;
         long long ppb = (P + ksplit - 1) / ksplit;
         ppb = (ppb + 31) / 32 * 32;
