@@ -4,7 +4,7 @@ import re
 import sys
 
 STAGE_OF = {   # kernel-name fragment -> stage names of bench.py that run this instantiation
-    "convin_project_kernel<float>": ["convin_project"],
+    "convin_project_kernel<float,": ["convin_project"],
     "plane_finalize_kernel<float>": ["plane_finalize"],
     "conv16_kernel<float, 0, 32, 0, 32, 40, 40, 2, false, true>": ["unet.down0.conv1", "unet.up1.conv2"],
     "conv16_kernel<float, 0, 32, 0, 32, 40, 40, 2, true, true>": ["unet.down0.conv2+pool"],
