@@ -123,9 +123,12 @@ def main():
     stage_ms = []
     ms = __import__("ctypes").c_float()
     for st in range(15):
-        step(probe=(st, ev_a, ev_b))
-        _capi.check(L.giga_event_elapsed_ms(ev_a, ev_b, __import__("ctypes").byref(ms)), "event")
-        stage_ms.append(ms.value)
+        reps = []
+        for _ in range(5):                 # median of five: two layers are within a few percent of each other
+            step(probe=(st, ev_a, ev_b))
+            _capi.check(L.giga_event_elapsed_ms(ev_a, ev_b, __import__("ctypes").byref(ms)), "event")
+            reps.append(ms.value)
+        stage_ms.append(float(np.median(reps)))
     step(dec_probe=dec_ev)
     _capi.check(L.giga_event_elapsed_ms(dec_ev[0], dec_ev[1], __import__("ctypes").byref(ms)), "event")
     dec_ms_once = ms.value
