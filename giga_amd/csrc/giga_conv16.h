@@ -46,21 +46,42 @@ static __device__ int g_conv_trace_layer = -1;
 #define CONV_T(idx) do {} while (0)
 #endif
 
+// linear 16-pixel units for the 10x10 layers (not for DOWN, whose H x W is the coarse output grid, and not with POOL)
+template <int KIND, int H, int W>
+constexpr bool conv_lin() { return H == 10 && W == 10 && KIND != DOWN; }
+// waves per workgroup: 12 unless the resident weights + the wave-private patches would not fit the 160 KiB LDS
+template <typename T, int KIND, int C0, int C1, int H, int W, int NB>
+constexpr int conv_nw() {
+    constexpr int ES = (int)sizeof(T), PS = 32 * ES + 16, HALO = KIND == CONV3 ? 1 : 0;
+    constexpr int TAPS = KIND == CONV3 ? 9 : KIND == DOWN ? 4 : 1;
+    constexpr int NPIX = conv_lin<KIND, H, W>() ? (W + 2 * HALO) * (3 + 2 * HALO) : KIND == DOWN ? 64 : (4 + 2 * HALO) * (4 + 2 * HALO);
+    constexpr int REGION = (NPIX * PS + 15) / 16 * 16;
+    constexpr int WB = NB * TAPS * ((C0 + C1) / 32 * (ES == 4 ? 2 : 1)) * (int)FRAG;
+    constexpr int fit = (160 * 1024 - WB) / REGION;
+    return fit >= CONV_NW ? CONV_NW : (fit / 2) * 2;
+}
+
 // H, W are the OUTPUT-grid dimensions for DOWN (its input is 2H x 2W) and the input dimensions otherwise.
 template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL, bool RELU = (KIND == CONV3)>
-__global__ __launch_bounds__(CONV_NW * 64) void conv16_kernel(ConvArgs a) {
+__global__ __launch_bounds__((conv_nw<T, KIND, C0, C1, H, W, NB>() * 64)) void conv16_kernel(ConvArgs a) {
     constexpr int CIN = C0 + C1;
     constexpr int TAPS = KIND == CONV3 ? 9 : KIND == DOWN ? 4 : 1;
     constexpr int HALO = KIND == CONV3 ? 1 : 0;
     constexpr int NCHUNK = CIN / 32;
     constexpr int ES = (int)sizeof(T);
     constexpr int PS = 32 * ES + 16;                  // LDS pixel stride in bytes
-    constexpr int LW = KIND == DOWN ? 8 : 4 + 2 * HALO, NPIX = LW * LW;  // staged patch (DOWN: the 8x8 fine pixels)
+    // LIN (the 10x10 layers): a 4x4 tiling covers 144 pixel slots for 100 pixels; instead a unit is 16 CONSECUTIVE
+    // pixels of an image in row-major order (7 units per image), staged as the haloed band of rows they touch.
+    constexpr bool LIN = conv_lin<KIND, H, W>();
+    constexpr int NWV = conv_nw<T, KIND, C0, C1, H, W, NB>();
+    constexpr int LW = LIN ? W + 2 * HALO : KIND == DOWN ? 8 : 4 + 2 * HALO;                 // staged patch width
+    constexpr int LH = LIN ? 3 + 2 * HALO : LW;                                                // 16 pixels of a 10-wide image touch <= 3 rows
+    constexpr int NPIX = LW * LH;                     // (DOWN: the 8x8 fine pixels)
     constexpr int VPP = 32 * ES / 16;                 // 16-byte vectors per pixel per chunk
     constexpr int NVEC = NPIX * VPP;                  // vectors per chunk
     constexpr int NLD = (NVEC + 63) / 64;             // staging loads per lane
     constexpr int REGION = (NPIX * PS + 15) / 16 * 16;
-    constexpr int TX = (W + 3) / 4, TY = (H + 3) / 4;
+    constexpr int TX = LIN ? (H * W + 15) / 16 : (W + 3) / 4, TY = LIN ? 1 : (H + 3) / 4;   // LIN: TX = units per image
     constexpr int NSUB = KIND == UPCONV ? 4 : 1;
     constexpr int NBT = COUT / 16;                    // 16-channel blocks per sub-output
     constexpr int CG = NBT / NB;                      // channel groups per sub-output
@@ -83,7 +104,7 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv16_kernel(ConvArgs a) {
     {
         // fragments of (sub, nb0 .. nb0+NB-1) are contiguous in the packed blob: [sub][nb][tap][kg]
         const uint8_t* wsrc = a.w + (size_t)(sub * NBT + nb0) * TAPS * KGT * FRAG;
-        for (int c = wave; c < WFRAGS; c += CONV_NW)
+        for (int c = wave; c < WFRAGS; c += NWV)
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(wsrc + (size_t)c * FRAG + lane * 16),
                 (__attribute__((address_space(3))) void*)(smem + c * FRAG), 16, 0, 0);
@@ -91,12 +112,12 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv16_kernel(ConvArgs a) {
     const uint4* wl = reinterpret_cast<const uint4*>(smem);
     int tcount = 2;
 
-    const int nwaves = wgs_per_grp * CONV_NW;
+    const int nwaves = wgs_per_grp * NWV;
     const int units = a.nimg * TY * TX;
 
     // A geometry: row i = lane&15 : quad = i>>2 (qy = quad>>1, qx = quad&1), pos = i&3 (dy = pos>>1, dx = pos&1)
     const int ay = 2 * (j >> 3) + ((j >> 1) & 1), ax = 2 * ((j >> 2) & 1) + (j & 1);
-    const int a_off = (KIND == DOWN ? (2 * ay * LW + 2 * ax) : (ay * LW + ax)) * PS + g * 16;
+    int a_off = (KIND == DOWN ? (2 * ay * LW + 2 * ax) : (ay * LW + ax)) * PS + g * 16;      // LIN: set per unit below
 
     // staging geometry of this lane's NLD vectors (fixed for the whole kernel)
     int st_lds[NLD], st_ly[NLD], st_lx[NLD], st_v[NLD];
@@ -123,7 +144,8 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv16_kernel(ConvArgs a) {
         constexpr int TS = KIND == DOWN ? 8 : 4;                                        // input pixels per tile edge
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
-            const int gy = TS * ty + st_ly[q] - HALO, gx = TS * tx + st_lx[q] - HALO;
+            const int gy = LIN ? (16 * tx) / W + st_ly[q] - HALO : TS * ty + st_ly[q] - HALO;
+            const int gx = LIN ? st_lx[q] - HALO : TS * tx + st_lx[q] - HALO;
             uint4 val = make_uint4(0, 0, 0, 0);
             if (st_lds[q] >= 0 && gy >= 0 && gy < IH && gx >= 0 && gx < IW)
                 val = *reinterpret_cast<const uint4*>(src + ((size_t)(img * IH + gy) * IW + gx) * csrc + coff +
@@ -152,6 +174,12 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv16_kernel(ConvArgs a) {
         for (int c = 0; c < NACC; ++c) acc[n][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     while (true) {
+        if constexpr (LIN) {           // row i of the A operand is pixel 16*tile + i of the image (clamped past the end)
+            const int t16 = 16 * (u % TX);
+            int p = t16 + j;
+            p = p < H * W ? p : H * W - 1;
+            a_off = ((p / W - t16 / W) * LW + p % W) * PS + g * 16;
+        }
         // ---- registers -> wave-private LDS patch (DS ops of one wave execute in order) -----------
 #pragma unroll
         for (int q = 0; q < NLD; ++q)
@@ -208,7 +236,8 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv16_kernel(ConvArgs a) {
             unit_coords(u, tx, ty, img);
             T* out = reinterpret_cast<T*>(a.out);
             const int qy = 4 * ty + 2 * (g >> 1), qx = 4 * tx + 2 * (g & 1);
-            const bool qok = qy < H && qx < W;             // H, W even: a quad is in or out as a whole
+            const int lp0 = 16 * tx + 4 * g;               // LIN: this lane's registers are pixels lp0 .. lp0+3 of the image
+            const bool qok = LIN ? lp0 < H * W : (qy < H && qx < W);   // (H, W even / H*W % 4 == 0: all four in or out)
 #pragma unroll
             for (int n = 0; n < NB; ++n) {
                 const int co = (nb0 + n) * 16 + j;
@@ -226,7 +255,7 @@ __global__ __launch_bounds__(CONV_NW * 64) void conv16_kernel(ConvArgs a) {
                 if (qok) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int y = qy + (e >> 1), x = qx + (e & 1);
+                        const int y = LIN ? (lp0 + e) / W : qy + (e >> 1), x = LIN ? (lp0 + e) % W : qx + (e & 1);
                         if (KIND == UPCONV) {
                             const int oy = 2 * y + (sub >> 1), ox = 2 * x + (sub & 1);
                             out[((size_t)(img * 2 * H + oy) * (2 * W) + ox) * COUT + co] = (T)v[e];
@@ -256,21 +285,24 @@ inline int launch_conv(const ConvArgs& a, hipStream_t s) {
     constexpr int TAPS = KIND == CONV3 ? 9 : KIND == DOWN ? 4 : 1;
     constexpr int ES = (int)sizeof(T);
     constexpr int PS = 32 * ES + 16;
-    constexpr int NPIX = KIND == DOWN ? 64 : (4 + 2 * HALO) * (4 + 2 * HALO);
+    constexpr bool LIN = conv_lin<KIND, H, W>();
+    constexpr int NWV = conv_nw<T, KIND, C0, C1, H, W, NB>();
+    constexpr int NPIX = LIN ? (W + 2 * HALO) * (3 + 2 * HALO) : KIND == DOWN ? 64 : (4 + 2 * HALO) * (4 + 2 * HALO);
     constexpr int REGION = (NPIX * PS + 15) / 16 * 16;
     constexpr int NSUB = KIND == UPCONV ? 4 : 1;
     constexpr int NGRP = NSUB * (COUT / 16 / NB);
     constexpr int KGT = (C0 + C1) / 32 * (ES == 4 ? 2 : 1);
-    constexpr size_t lds = (size_t)NB * TAPS * KGT * FRAG + CONV_NW * REGION;
+    constexpr size_t lds = (size_t)NB * TAPS * KGT * FRAG + NWV * REGION;
     static_assert(lds <= 160 * 1024, "LDS budget");
+    static_assert(!(LIN && POOL), "the in-lane 2x2 max-pool needs the quad tiling");
     static_assert(256 % NGRP == 0, "weight groups must divide the CU count");
-    const int units = a.nimg * ((H + 3) / 4) * ((W + 3) / 4);        // per weight group
-    int wgs = (units + CONV_NW - 1) / CONV_NW;                        // workgroups per weight group
+    const int units = a.nimg * (LIN ? (H * W + 15) / 16 : ((H + 3) / 4) * ((W + 3) / 4));   // per weight group
+    int wgs = (units + NWV - 1) / NWV;                                // workgroups per weight group
     if (wgs > 256 / NGRP) wgs = 256 / NGRP;                           // one persistent workgroup per CU
     auto kern = conv16_kernel<T, KIND, C0, C1, COUT, H, W, NB, POOL, RELU>;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(wgs * NGRP), dim3(CONV_NW * 64), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(wgs * NGRP), dim3(NWV * 64), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
