@@ -249,6 +249,13 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["extra"] = {"c4_error": f"{type(e).__name__}: {e}"}
 
+    # -------- extra: c2 (ii), N = M = 2048 queries per scene on all four heads -------------------
+    if single and not args.no_extra:
+        try:
+            out["extra"]["c2_ii"] = bench_c2_ii(net, dev, synth, B)
+        except Exception as e:  # noqa: BLE001
+            out["extra"]["c2_ii_error"] = f"{type(e).__name__}: {e}"
+
     # -------- extra: c5-shaped training step (fp32 here; BASELINE c5 names bf16 -- see DESIGN.md) -----------
     if single and not args.no_extra:
         try:
@@ -305,6 +312,28 @@ def bench_c4(net, sd, dev, L, _capi, synth, decode_heads, Bc=32, steps=10):
                      "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": None,
                      "avg_launch_ms": dec_ms, "flops_per_launch": flops},
     }
+
+
+def bench_c2_ii(net, dev, synth, B, steps=20):
+    """BASELINE c2 (ii): every scene gets 2048 grasp queries (3 heads) and 2048 occupancy queries, fp32."""
+    N = 2048
+    net.set_precision("fp32").eval()
+    x = torch.from_numpy(synth.tsdf_batch(3000, B)).to(dev)
+    p = torch.from_numpy(synth.query_points(3000, B, N, stream=2)).to(dev)
+    po = torch.from_numpy(synth.query_points(3000, B, N, stream=3)).to(dev)
+    with torch.no_grad():
+        for _ in range(5):
+            net(x, p, p_tsdf=po)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net(x, p, p_tsdf=po)
+        torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    flop_scene = FLOP_ENCODER + N * (FLOP_GRASP3 + FLOP_HEAD["tsdf"])
+    return {"workload": f"c2 (ii): batch={B}, 2048 grasp queries x 3 heads + 2048 occupancy queries per scene, fp32",
+            "ms_per_step": el * 1e3, "scenes_per_sec": B / el, "query_points_per_sec": B * 2 * N / el,
+            "algorithmic_tflops": B * flop_scene / el / 1e12}
 
 
 def bench_train(net, dev, synth, B, M, steps=10, rank=0, world=1):
@@ -380,12 +409,25 @@ def cpu_baseline(sd, synth, M, budget_s=20.0):
         t_start = time.perf_counter()
         while len(times) < 10 and (not times or time.perf_counter() - t_start < budget_s):
             times.append(one(Bs))
+        # SURVEY 8d also asks for the reference-shaped single-scene cases: c1 (1 scene, 2048 grasp + 2048 occupancy
+        # queries) and the c4 shape (1 scene, the 64 000-point lattice, three grasp heads); median of three passes each
+        also = {}
+        x1 = x[:1]
+        p1 = torch.from_numpy(synth.query_points(0, 1, 2048, stream=2))
+        lat = torch.from_numpy(synth.inference_lattice())
+        for name, fn in (("c1_scene_2048pts_ms", lambda: O.model_forward(sd, x1, p1, p_tsdf=p1)),
+                         ("c4_scene_64000pts_ms", lambda: O.model_forward(sd, x1, lat))):
+            fn()
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+            also[name] = float(np.median(ts)) * 1e3
     med = float(np.median(times))
     return {"value": Bs / med, "unit": "scenes/s", "cores": best, "kind": "port",
             "sample": f"{len(times)} passes of {Bs} scenes (1 grasp query + {M} occupancy queries each), "
                       f"torch {torch.__version__} CPU fp32, median; {best} intra-op threads chosen from "
                       f"{cands} on a host with {avail} usable cores",
-            "ms_per_pass": med * 1e3}
+            "ms_per_pass": med * 1e3, "also": also}
 
 
 if __name__ == "__main__":
