@@ -77,7 +77,7 @@ if what == "train":
     x = torch.from_numpy(synth.tsdf_batch(0, B)).to(dev); pos = torch.from_numpy(synth.query_points(0, B, 1, stream=2)).to(dev)
     pos_occ = torch.from_numpy(synth.query_points(0, B, 2048, stream=3)).to(dev)
     y = tuple(torch.from_numpy(a).to(dev) for a in synth.train_labels(0, B, 2048))
-    opt = torch.optim.Adam(net.parameters(), lr=2e-4)
+    opt = torch.optim.Adam(net.parameters(), lr=2e-4, fused=True)
     def step():
         opt.zero_grad(set_to_none=True)
         loss, _ = loss_fn(select(net(x, pos, p_tsdf=pos_occ)), y)
