@@ -189,6 +189,17 @@ def test_full_size_properties_c2_c4(net, dev):
     assert q.min().item() > 0 and q.max().item() < 1
     assert maxerr(q16, q.cpu()) < 1e-2 and maxerr(r16, r.cpu()) < 2e-2 and maxerr(w16, w.cpu()) < 2e-2
     net.set_precision("fp32")
+    # two scenes of the 32-scene batch against the oracle (the batch takes the one-x-part conv_in kernels, the
+    # small-batch tests the five-x-part ones), and one of them against the same scene run alone
+    sd = weights.make_state_dict(7)
+    for k in (5, 31):
+        ref = O.model_forward(sd, x[k:k + 1].cpu(), p[k:k + 1].cpu(), p_tsdf=p[k:k + 1].cpu())
+        for got, want in zip((q, r, w, t), ref):
+            assert maxerr(got[k:k + 1], want) < 1e-4
+    with torch.no_grad():
+        alone = net(x[5:6].contiguous(), p[5:6].contiguous(), p_tsdf=p[5:6].contiguous())
+    for got, one in zip((q, r, w, t), alone):
+        assert maxerr(got[5:6], one.cpu()) < 1e-5
 
 
 def test_variants_aff_geo(dev):
