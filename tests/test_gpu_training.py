@@ -59,6 +59,24 @@ def test_train_step_gradients_match_oracle_and_g4(golden, sd7):
         assert abs(got_norms[n] - ref) <= 2e-3 * max(ref, 1e-6) + 1e-8, (n, got_norms[n], ref)
 
 
+def test_gradients_at_batch_32(sd7):
+    """From 32 scenes up the conv_in kernels (forward and backward) switch to the one-x-part decomposition; hold that
+    variant's gradients to the oracle too (M kept small: the oracle's CPU autograd runs the whole 32-scene encoder)."""
+    dev = torch.device("cuda:0")
+    x, pos, pos_occ, y = _batch(300, 32, 96)
+    ref_loss, ref_grads, _ = _oracle_grads(sd7, x, pos, pos_occ, y)
+    net = networks.get_network("giga")
+    net.load_state_dict(sd7)
+    net = net.to(dev).train()
+    loss, _ = loss_fn(select(net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev))), tuple(t.to(dev) for t in y))
+    assert abs(loss.item() - ref_loss) < 1e-5
+    loss.backward()
+    for name, prm in net.named_parameters():
+        ref, got = ref_grads[name], prm.grad.detach().cpu()
+        scale = ref.abs().max().item()
+        assert (got - ref).abs().max().item() <= 2e-3 * scale + 1e-6, name
+
+
 def test_giga_detach_gradients(sd7):
     """giga_detach (networks.py:143-169): the occupancy loss must not reach the encoder; the heads are unchanged."""
     dev = torch.device("cuda:0")
