@@ -123,7 +123,10 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdArgs a) {
             __builtin_amdgcn_s_waitcnt(0x0F70);
             __syncthreads();
             const float* ctab = reinterpret_cast<const float*>(smem + (size_t)DEC32_FRAGS * FRAG);
-            f32x16 netp[NBLK], hh[NBLK], net;
+            // the backward chain needs only the SIGNS of the pre-activations: 16 bits per lane and tensor instead of 16
+            // registers; the activations themselves (X of the weight-gradient GEMMs) leave as soon as they exist
+            unsigned mnet[NBLK + 1], mhid[NBLK];
+            f32x16 net;
 #pragma unroll
             for (int r = 0; r < 16; ++r) net[r] = 0.f;
             int k = 0;
@@ -139,7 +142,14 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdArgs a) {
                     const float4 A = W[(k++) * 64 + lane];
                     net = mfma32(A.x, ax0, net); net = mfma32(A.y, ax1, net); net = mfma32(A.z, ax2, net);
                 }
-                netp[blk] = net;
+                {
+                    f32x16 t;
+                    unsigned m = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { t[r] = relu(net[r]); m |= (net[r] > 0.f ? 1u : 0u) << r; }
+                    mnet[blk] = m;
+                    store_rows(S + (11 + blk) * AS, g, hi, t, valid);          // XN[blk]
+                }
                 f32x16 hcur;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -152,7 +162,14 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdArgs a) {
                     hcur = mfma32(A.x, relu(net[4 * q + 0]), hcur); hcur = mfma32(A.y, relu(net[4 * q + 1]), hcur);
                     hcur = mfma32(A.z, relu(net[4 * q + 2]), hcur); hcur = mfma32(A.w, relu(net[4 * q + 3]), hcur);
                 }
-                hh[blk] = hcur;
+                {
+                    f32x16 t;
+                    unsigned m = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { t[r] = relu(hcur[r]); m |= (hcur[r] > 0.f ? 1u : 0u) << r; }
+                    mhid[blk] = m;
+                    store_rows(S + (16 + blk) * AS, g, hi, t, valid);          // XH[blk]
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 A = W[(k++) * 64 + lane];
@@ -164,20 +181,12 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdArgs a) {
                 const float4 A = W[(k++) * 64 + lane];
                 net = mfma32(A.y, ax1, net);
             }
-            // X arrays of the weight-gradient GEMMs
-            {
+            {   // XO = relu(net5) and its sign mask
                 f32x16 t;
+                unsigned m = 0;
 #pragma unroll
-                for (int blk = 0; blk < NBLK; ++blk) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) t[r] = relu(netp[blk][r]);
-                    store_rows(S + (11 + blk) * AS, g, hi, t, valid);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) t[r] = relu(hh[blk][r]);
-                    store_rows(S + (16 + blk) * AS, g, hi, t, valid);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t[r] = relu(net[r]);
+                for (int r = 0; r < 16; ++r) { t[r] = relu(net[r]); m |= (net[r] > 0.f ? 1u : 0u) << r; }
+                mnet[NBLK] = m;
                 store_rows(S + 21 * AS, g, hi, t, valid);
             }
             // ================= 2. epilogue backward: dO (<= 4 values, identical in both lane halves) ============
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int f = (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const float v = wout[f] * dO[0] + wout[32 + f] * dO[1] + wout[64 + f] * dO[2] + wout[96 + f] * dO[3];
-                G[r] = net[r] > 0.f ? v : 0.f;
+                G[r] = (mnet[NBLK] >> r & 1u) ? v : 0.f;
             }
             store_rows(S + 5 * AS, g, hi, G, valid);
             // ================= 4. gradient chain (fragments: block b -> Wc^T 20b..20b+11, W0^T +12..15, W1^T +16..19) ====
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdArgs a) {
                     dh = mfma32(A.z, G[4 * q + 2], dh); dh = mfma32(A.w, G[4 * q + 3], dh);
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dh[r] = hh[blk][r] > 0.f ? dh[r] : 0.f;
+                for (int r = 0; r < 16; ++r) dh[r] = (mhid[blk] >> r & 1u) ? dh[r] : 0.f;
                 store_rows(S + (6 + blk) * AS, g, hi, dh, valid);
                 f32x16 dn;
 #pragma unroll
@@ -266,7 +275,7 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdArgs a) {
                     dn = mfma32(A.z, dh[4 * q + 2], dn); dn = mfma32(A.w, dh[4 * q + 3], dn);
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) G[r] += netp[blk][r] > 0.f ? dn[r] : 0.f;     // DN[blk]
+                for (int r = 0; r < 16; ++r) G[r] += (mnet[blk] >> r & 1u) ? dn[r] : 0.f;     // DN[blk]
                 store_rows(S + blk * AS, g, hi, G, valid);
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)                      // dc += Wc^T DN[blk]
