@@ -78,7 +78,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):
+        # launched by torch.distributed.run: one rank per GPU over RCCL (also at world size 1, so that the collective
+        # code path of the multi-GPU runs can be exercised on a single-GPU box)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -166,7 +168,7 @@ def main():
     # -------- opt-in extra at N > 1 (--dp-train): the data-parallel training step of BASELINE c5 (every rank takes part;
     # off by default so that the scaling run consists of the data-path-free forward only) ----------
     dp_train = None
-    if dist is not None and args.dp_train:
+    if dist is not None and world > 1 and args.dp_train:
         try:
             net.enable_data_parallel()
             dp_train = bench_train(net, dev, synth, B, M, rank=rank, world=world)
@@ -234,7 +236,7 @@ def main():
     if dp_train is not None:
         out["extra"] = {"c5_train_step_fp32_data_parallel": dp_train}
     # -------- extra: c4 (64 000 grasp queries per scene, f16 MFMA fused decoder); single-GPU runs only ----
-    single = dist is None
+    single = world == 1
     if single and not args.no_extra:
         try:
             out["extra"] = {"c4": bench_c4(net, sd, dev, L, _capi, synth, decode_heads)}
