@@ -142,5 +142,30 @@ def main():
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
 
+def g7_generation():
+    """G7: the reference's own Generator3D.eval_points (conv_onet/generation.py:326-358, chunked decode_occ on cached
+    planes) on one scene: 2500 points in three chunks -> occupancy logits.  Run:  python -m oracle.make_goldens g7"""
+    import numpy as np
+    import torch
+    from giga_amd import synth, weights
+    from oracle import ref_bootstrap
+    ref_bootstrap.install()
+    from vgn.ConvONets.conv_onet.generation import Generator3D
+    net = ref_bootstrap.load_reference_giga(weights.make_state_dict(7))
+    gen = Generator3D(net, device=torch.device("cpu"), points_batch_size=1000, input_type="voxel")
+    x = torch.from_numpy(synth.tsdf_batch(70, 1))
+    with torch.no_grad():
+        c = net.encode_inputs(x)
+        p = torch.from_numpy(synth.query_points(70, 1, 2500, stream=12, half_width=0.55))[0]
+        occ = gen.eval_points(p, c)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g7_generation.npz")
+    np.savez_compressed(out, first_scene=70, n=2500, stream=12, half_width=0.55, logits=occ.numpy().astype(np.float32))
+    print("wrote", out, occ.shape)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "g7":
+        g7_generation()
+    else:
+        main()
+        g7_generation()

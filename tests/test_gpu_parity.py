@@ -223,7 +223,7 @@ def test_variants_aff_geo(dev):
 
 
 @pytest.mark.gpu
-def test_generation_eval_points_and_grid(sd7):
+def test_generation_eval_points_and_grid(sd7, golden):
     """encode once, query occupancy many times (generation.py:326-358) == oracle decoder_tsdf."""
     from giga_amd.generation import Generator3D
     dev = torch.device("cuda:0")
@@ -242,6 +242,10 @@ def test_generation_eval_points_and_grid(sd7):
         assert (got - ref).abs().max().item() < 1e-4
     one = gen.eval_points(p[0], {k: v[:1] for k, v in c.items()}).cpu()      # (N,3) form, reference-style dict
     assert (one - ref[0]).abs().max().item() < 1e-4
+    g7 = golden("g7_generation.npz")                        # the reference's own Generator3D.eval_points on scene 70
+    p7 = torch.from_numpy(synth.query_points(70, 1, int(g7["n"]), stream=int(g7["stream"]), half_width=float(g7["half_width"])))[0]
+    got7 = gen.eval_points(p7, {k: v[:1] for k, v in c.items()}).cpu().numpy()
+    assert np.abs(got7 - g7["logits"]).max() < 1e-4
     grid = gen.occupancy_grid(c, resolution=16).cpu()
     ref_grid = O.decoder_forward(sd7, "decoder_tsdf", gen.grid_points(16).cpu().expand(2, -1, -1), planes)
     assert (grid.reshape(2, -1) - ref_grid).abs().max().item() < 1e-4

@@ -106,3 +106,13 @@ def test_g5_edges(golden, sd7):
     x = torch.from_numpy(synth.tsdf_batch(int(g["edge_scene"]), 1))
     q, r, w, t = O.model_forward(sd7, x, pe, p_tsdf=pe)
     close(q, g["edge_qual"]); close(r, g["edge_rot"]); close(w, g["edge_width"]); close(t, g["edge_tsdf"])
+
+
+def test_g7_generation_eval_points(golden, sd7):
+    """Occupancy logits of the reference's Generator3D.eval_points (generation.py:326-358) == oracle decoder_tsdf."""
+    g = golden("g7_generation.npz")
+    x = torch.from_numpy(synth.tsdf_batch(int(g["first_scene"]), 1))
+    p = torch.from_numpy(synth.query_points(int(g["first_scene"]), 1, int(g["n"]), stream=int(g["stream"]),
+                                            half_width=float(g["half_width"])))
+    got = O.infer_geo(sd7, x, p)[0].numpy()
+    assert np.abs(got - g["logits"]).max() < 2e-5
