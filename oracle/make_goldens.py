@@ -163,9 +163,43 @@ def g7_generation():
     print("wrote", out, occ.shape)
 
 
+def g8_detach():
+    """G8: per-tensor gradient norms of the reference's `giga_detach` network (networks.py:143-169: detach_tsdf, the
+    occupancy loss does not reach the encoder) on the G4 batch.  Run:  python -m oracle.make_goldens g8"""
+    import torch.nn.functional as F
+    from giga_amd import synth, weights
+    from oracle import ref_bootstrap
+    net = ref_bootstrap.load_reference_giga(weights.make_state_dict(7), name="giga_detach").train()
+    torch.set_grad_enabled(True)
+    B, M = 4, 2048
+    x4 = torch.from_numpy(synth.tsdf_batch(10, B))
+    pos = torch.from_numpy(synth.query_points(10, B, 1, stream=2))
+    pos_occ = torch.from_numpy(synth.query_points(10, B, M, stream=3))
+    label, rots, width_t, occ = [torch.from_numpy(a) for a in synth.train_labels(10, B, M)]
+    q_o, r_o, w_o, o_o = net(x4, pos, p_tsdf=pos_occ)
+    yq, yr, yw, yo = q_o.squeeze(-1), r_o.squeeze(1), w_o.squeeze(-1), torch.sigmoid(o_o)
+    quat = lambda pr, t: 1.0 - torch.abs(torch.sum(pr * t, dim=1))        # noqa: E731
+    lq = F.binary_cross_entropy(yq, label, reduction="none")
+    lr = torch.min(quat(yr, rots[:, 0]), quat(yr, rots[:, 1]))
+    lw = F.mse_loss(40 * yw, 40 * width_t, reduction="none")
+    lo = F.binary_cross_entropy(yo, occ, reduction="none").mean(-1)
+    loss = (lq + label * (lr + 0.01 * lw) + lo).mean()
+    net.zero_grad()
+    loss.backward()
+    names = [n for n, _ in net.named_parameters()]
+    norms = [p.grad.double().norm().item() for _, p in net.named_parameters()]
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g8_detach.npz")
+    np.savez_compressed(out, first_scene=10, B=B, M=M, loss_all=loss.item(), grad_names=np.array(names),
+                        grad_norms=np.array(norms, np.float64), grad_conv_in_w=net.encoder.conv_in.weight.grad.numpy())
+    torch.set_grad_enabled(False)
+    print("wrote", out, loss.item())
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "g7":
-        g7_generation()
-    else:
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "main"):
         main()
+    if which in ("all", "g7"):
         g7_generation()
+    if which in ("all", "g8"):
+        g8_detach()

@@ -77,6 +77,23 @@ def test_gradients_at_batch_32(sd7):
         assert (got - ref).abs().max().item() <= 2e-3 * scale + 1e-6, name
 
 
+def test_giga_detach_matches_reference_golden_g8(golden, sd7):
+    """Per-tensor gradient norms of the reference's own giga_detach network on the G4 batch (golden G8)."""
+    dev = torch.device("cuda:0")
+    g = golden("g8_detach.npz")
+    B, M, s0 = int(g["B"]), int(g["M"]), int(g["first_scene"])
+    x, pos, pos_occ, y = _batch(s0, B, M)
+    net = networks.get_network("giga_detach")
+    net.load_state_dict(sd7)
+    net = net.to(dev).train()
+    loss, _ = loss_fn(select(net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev))), tuple(t.to(dev) for t in y))
+    assert abs(loss.item() - float(g["loss_all"])) < 1e-4
+    loss.backward()
+    got = {n: p.grad.double().norm().item() for n, p in net.named_parameters()}
+    for n, ref in zip([str(n) for n in g["grad_names"]], g["grad_norms"]):
+        assert abs(got[n] - ref) <= 2e-3 * max(ref, 1e-6) + 1e-8, (n, got[n], ref)
+
+
 def test_giga_detach_gradients(sd7):
     """giga_detach (networks.py:143-169): the occupancy loss must not reach the encoder; the heads are unchanged."""
     dev = torch.device("cuda:0")

@@ -116,3 +116,23 @@ def test_g7_generation_eval_points(golden, sd7):
                                             half_width=float(g["half_width"])))
     got = O.infer_geo(sd7, x, p)[0].numpy()
     assert np.abs(got - g["logits"]).max() < 2e-5
+
+
+def test_g8_detach_gradients(golden, sd7):
+    """giga_detach (networks.py:143-169): the oracle's detach_tsdf gradients == the reference network's."""
+    g = golden("g8_detach.npz")
+    B, M, s0 = int(g["B"]), int(g["M"]), int(g["first_scene"])
+    x = torch.from_numpy(synth.tsdf_batch(s0, B))
+    pos = torch.from_numpy(synth.query_points(s0, B, 1, stream=2))
+    pos_occ = torch.from_numpy(synth.query_points(s0, B, M, stream=3))
+    y = tuple(torch.from_numpy(a) for a in synth.train_labels(s0, B, M))
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd7.items()}
+    with torch.enable_grad():
+        loss, _ = O.train_loss(O.train_select(O.model_forward(sdg, x, pos, p_tsdf=pos_occ, detach_tsdf=True)), y)
+        loss.backward()
+    assert abs(loss.item() - float(g["loss_all"])) < 1e-5
+    for n, ref in zip([str(n) for n in g["grad_names"]], g["grad_norms"]):
+        got = sdg[n].grad.double().norm().item()
+        assert abs(got - ref) <= 1e-4 * max(ref, 1e-6) + 1e-9, (n, got, ref)
+    ref_w = g["grad_conv_in_w"]
+    assert np.abs(sdg["encoder.conv_in.weight"].grad.numpy() - ref_w).max() < 1e-5 * np.abs(ref_w).max()
