@@ -195,6 +195,25 @@ def g8_detach():
     print("wrote", out, loss.item())
 
 
+def g9_variants():
+    """G9: the reference's ablation networks giga_aff (networks.py:65-89, no occupancy head) and giga_geo (:117-141,
+    ConvolutionalOccupancyNetworkGeometry: occupancy only) on 2 scenes x 100 points.  python -m oracle.make_goldens g9"""
+    from giga_amd import synth, weights
+    from oracle import ref_bootstrap
+    x = torch.from_numpy(synth.tsdf_batch(9, 2))
+    p = torch.from_numpy(synth.query_points(9, 2, 100))
+    with torch.no_grad():
+        aff = ref_bootstrap.load_reference_giga(weights.make_state_dict(3, with_tsdf=False), name="giga_aff")
+        q, r, w = aff(x, p)
+        geo = ref_bootstrap.load_reference_giga(weights.make_state_dict(4, heads=("decoder_tsdf",)), name="giga_geo")
+        t = geo.infer_geo(x, p)
+        occ = geo.decode_occ(p, geo.encode_inputs(x)).logits
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g9_variants.npz")
+    np.savez_compressed(out, aff_seed=3, geo_seed=4, first_scene=9, aff_qual=q.numpy(), aff_rot=r.numpy(), aff_width=w.numpy(),
+                        geo_tsdf=t.numpy(), geo_occ_logits=occ.numpy())
+    print("wrote", out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "main"):
@@ -203,3 +222,5 @@ if __name__ == "__main__":
         g7_generation()
     if which in ("all", "g8"):
         g8_detach()
+    if which in ("all", "g9"):
+        g9_variants()

@@ -202,8 +202,10 @@ def test_full_size_properties_c2_c4(net, dev):
         assert maxerr(got[5:6], one.cpu()) < 1e-5
 
 
-def test_variants_aff_geo(dev):
-    """giga_aff (no occupancy head) and giga_geo (occupancy only) run on the same kernels."""
+def test_variants_aff_geo(dev, golden):
+    """giga_aff (no occupancy head) and giga_geo (occupancy only) run on the same kernels; held to the
+    oracle and to golden G9 (the reference's own ablation networks)."""
+    g9 = golden("g9_variants.npz")
     sd_aff = weights.make_state_dict(3, with_tsdf=False)
     aff = networks.get_network("giga_aff"); aff.load_state_dict(sd_aff); aff = aff.to(dev).eval()
     x = torch.from_numpy(synth.tsdf_batch(9, 2)); p = torch.from_numpy(synth.query_points(9, 2, 100))
@@ -212,6 +214,8 @@ def test_variants_aff_geo(dev):
         ref = O.model_forward(sd_aff, x, p)
     for a, b in zip(out, ref):
         assert maxerr(a, b) < 1e-4
+    for a, key in zip(out, ("aff_qual", "aff_rot", "aff_width")):
+        assert maxerr(a, g9[key]) < 1e-4
     sd_geo = weights.make_state_dict(4, heads=("decoder_tsdf",))
     geo = networks.get_network("giga_geo"); geo.load_state_dict(sd_geo); geo = geo.to(dev).eval()
     with torch.no_grad():
@@ -220,6 +224,7 @@ def test_variants_aff_geo(dev):
         occ = geo.decode_occ(p.to(dev), geo.encode_inputs(x.to(dev)))
     assert maxerr(t, ref_t) < 1e-4
     assert maxerr(occ.logits, ref_t) < 1e-4
+    assert maxerr(t, g9["geo_tsdf"]) < 1e-4 and maxerr(occ.logits, g9["geo_occ_logits"]) < 1e-4
 
 
 @pytest.mark.gpu

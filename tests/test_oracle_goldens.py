@@ -136,3 +136,15 @@ def test_g8_detach_gradients(golden, sd7):
         assert abs(got - ref) <= 1e-4 * max(ref, 1e-6) + 1e-9, (n, got, ref)
     ref_w = g["grad_conv_in_w"]
     assert np.abs(sdg["encoder.conv_in.weight"].grad.numpy() - ref_w).max() < 1e-5 * np.abs(ref_w).max()
+
+
+def test_g9_ablation_variants(golden):
+    """giga_aff / giga_geo of the reference (networks.py:65-141) == the oracle restricted to their heads."""
+    g = golden("g9_variants.npz")
+    x = torch.from_numpy(synth.tsdf_batch(int(g["first_scene"]), 2))
+    p = torch.from_numpy(synth.query_points(int(g["first_scene"]), 2, 100))
+    q, r, w = O.model_forward(weights.make_state_dict(int(g["aff_seed"]), with_tsdf=False), x, p)
+    for got, key in ((q, "aff_qual"), (r, "aff_rot"), (w, "aff_width")):
+        assert np.abs(got.numpy() - g[key]).max() < 2e-5
+    t = O.infer_geo(weights.make_state_dict(int(g["geo_seed"]), heads=("decoder_tsdf",)), x, p)
+    assert np.abs(t.numpy() - g["geo_tsdf"]).max() < 2e-5 and np.abs(t.numpy() - g["geo_occ_logits"]).max() < 2e-5
