@@ -214,6 +214,41 @@ def g9_variants():
     print("wrote", out)
 
 
+def g10_planner():
+    """G10: the reference's whole planner call VGNImplicit.__call__ (detection_implicit.py:33-85: predict on the 40^3
+    lattice, process, bound, select, metric conversion) on two scenes, best=True (no random permutation),
+    force_detection, qual_th 0.6, out_th 0.1.  The planner object is assembled without load_network (no checkpoint
+    file): same attributes as __init__ (:18-31).  python -m oracle.make_goldens g10"""
+    from giga_amd import synth, weights
+    from oracle import ref_bootstrap
+    ref_bootstrap.install()
+    from vgn import detection_implicit as di
+    net = ref_bootstrap.load_reference_giga(weights.make_state_dict(7))
+    pl = object.__new__(di.VGNImplicit)
+    pl.device, pl.net = torch.device("cpu"), net
+    pl.qual_th, pl.best, pl.force_detection, pl.out_th, pl.visualize, pl.resolution = 0.6, True, True, 0.1, False, 40
+    lin = torch.linspace(-0.5, 0.5 - 1.0 / 40, 40)
+    gx, gy, gz = torch.meshgrid(lin, lin, lin, indexing="ij")
+    pl.pos = torch.stack((gx, gy, gz), dim=-1).float().unsqueeze(0).view(1, 64000, 3)
+    out = {"qual_th": 0.6, "out_th": 0.1}
+
+    class State:
+        pass
+    for k, scene in enumerate((0, 5)):
+        st = State()
+        st.tsdf = synth.tsdf_batch(scene, 1, realistic=True)
+        grasps, scores, _ = pl(st)
+        out[f"s{k}_scene"] = scene
+        out[f"s{k}_scores"] = np.asarray(scores, np.float32)
+        out[f"s{k}_translation"] = np.array([g.pose.translation for g in grasps], np.float32).reshape(-1, 3)
+        out[f"s{k}_quat"] = np.array([g.pose.rotation.as_quat() for g in grasps], np.float32).reshape(-1, 4)
+        out[f"s{k}_width"] = np.array([g.width for g in grasps], np.float32)
+        print("scene", scene, len(grasps), "grasps, best", scores[0] if len(scores) else None)
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g10_planner.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "main"):
@@ -224,3 +259,5 @@ if __name__ == "__main__":
         g8_detach()
     if which in ("all", "g9"):
         g9_variants()
+    if which in ("all", "g10"):
+        g10_planner()

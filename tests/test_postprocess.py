@@ -125,3 +125,32 @@ def test_planner_hipgraph_replay_matches_eager(sd7):
         for a, b in zip(ga, gb):
             assert np.array_equal(a["rotation"], b["rotation"]) and np.array_equal(a["translation"], b["translation"])
             assert a["width"] == b["width"]
+
+
+@pytest.mark.gpu
+def test_planner_matches_reference_planner_golden_g10(golden, sd7):
+    """The whole planner call against golden G10 = the reference's VGNImplicit.__call__ (network on the 40^3 lattice,
+    process, bound, select, metric conversion) with the same weights: same grasps in the same order."""
+    from giga_amd import networks
+    from giga_amd.detection import VGNImplicit
+    g = golden("g10_planner.npz")
+    dev = torch.device("cuda:0")
+    net = networks.get_network("giga")
+    net.load_state_dict(sd7)
+    net = net.to(dev).eval()
+    planner = VGNImplicit(None, "giga", net=net, best=True, force_detection=True, qual_th=float(g["qual_th"]),
+                          out_th=float(g["out_th"]))
+
+    class State:
+        pass
+    for k in range(2):
+        st = State()
+        st.tsdf = synth.tsdf_batch(int(g[f"s{k}_scene"]), 1, realistic=True)
+        grasps, scores, _ = planner(st)
+        ref_scores = g[f"s{k}_scores"]
+        assert len(grasps) == len(ref_scores) > 0
+        np.testing.assert_allclose(scores, ref_scores, rtol=0, atol=2e-5)
+        np.testing.assert_allclose(np.array([x["translation"] for x in grasps]), g[f"s{k}_translation"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(np.array([x["width"] for x in grasps]), g[f"s{k}_width"], rtol=0, atol=1e-5)
+        dots = np.abs((np.array([x["rotation"] for x in grasps]) * g[f"s{k}_quat"]).sum(-1))
+        np.testing.assert_allclose(dots, 1.0, atol=1e-5)
