@@ -249,6 +249,45 @@ def g10_planner():
     print("wrote", path)
 
 
+def g11_train_helpers():
+    """G11: the reference's OWN select / loss_fn / prepare_batch (scripts/train_giga.py:141-195), imported from the script
+    (its tensorboard import gets an empty stand-in module), on stored head outputs and labels.
+    python -m oracle.make_goldens g11"""
+    import importlib.util
+    import types
+    from giga_amd import synth
+    from oracle import ref_bootstrap
+    ref_bootstrap.install()
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = object
+    sys.modules["torch.utils.tensorboard"] = tb
+    spec = importlib.util.spec_from_file_location("ref_train_giga", "/root/reference/scripts/train_giga.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    B, M = 5, 48
+    rng = np.random.default_rng(11)
+    label, rots, width, occ = synth.train_labels(40, B, M)
+    qual = rng.uniform(0.02, 0.98, (B, 1)).astype(np.float32)
+    rot = rng.standard_normal((B, 1, 4)).astype(np.float32)
+    rot /= np.linalg.norm(rot, axis=-1, keepdims=True)
+    wid = rng.uniform(0.0, 0.3, (B, 1)).astype(np.float32)
+    logit = rng.standard_normal((B, M)).astype(np.float32)
+    t = torch.from_numpy
+    y_pred = m.select((t(qual), t(rot), t(wid), t(logit)))
+    loss, d = m.loss_fn(y_pred, (t(label), t(rots), t(width), t(occ)))
+    # prepare_batch: (pc, (label, rotations, width), pos, pos_occ, occ_value) -> device tensors / shapes
+    pc = synth.tsdf_batch(40, B)[:, None]
+    pos = synth.query_points(40, B, 1, stream=2)[:, 0]
+    pos_occ = synth.query_points(40, B, M, stream=3)
+    pb = m.prepare_batch((t(pc), (t(label), t(rots), t(width)), t(pos), t(pos_occ), t(occ)), torch.device("cpu"))
+    shapes = np.array([list(pb[0].shape) + [0] * (5 - pb[0].dim()), list(pb[2].shape) + [0, 0], list(pb[3].shape) + [0, 0]])
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g11_train_helpers.npz")
+    np.savez_compressed(path, first_scene=40, B=B, M=M, qual=qual, rot=rot, width=wid, logit=logit,
+                        sel_occ=y_pred[3].numpy(), loss=float(loss), prepare_shapes=shapes,
+                        **{k: float(v) for k, v in d.items()})
+    print("wrote", path, float(loss))
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "main"):
@@ -261,3 +300,5 @@ if __name__ == "__main__":
         g9_variants()
     if which in ("all", "g10"):
         g10_planner()
+    if which in ("all", "g11"):
+        g11_train_helpers()
