@@ -6,6 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libgiga_hip.so")
+DEMO_SRC = os.path.join(os.path.dirname(HERE), "examples", "c_abi_demo.cpp")
+DEMO = os.path.join(HERE, "lib", "c_abi_demo")
 
 
 def _stale():
@@ -27,6 +29,15 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc build of libgiga_hip.so failed")
     if not os.path.exists(LIB):
         raise RuntimeError("libgiga_hip.so missing after build")
+    # the torch-free C++ host example (examples/c_abi_demo.cpp) links against the library it demonstrates
+    if os.path.exists(DEMO_SRC) and (force or not os.path.exists(DEMO) or
+                                     os.path.getmtime(DEMO) < max(os.path.getmtime(DEMO_SRC), os.path.getmtime(LIB))):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        r = subprocess.run([hipcc, "-O2", "-std=c++17", "--offload-arch=gfx950", DEMO_SRC, "-o", DEMO,
+                            "-L" + os.path.dirname(LIB), "-lgiga_hip", "-Wl,-rpath,$ORIGIN"], capture_output=not verbose, text=True)
+        if r.returncode != 0:
+            sys.stderr.write((r.stdout or "") + (r.stderr or ""))
+            raise RuntimeError("hipcc build of examples/c_abi_demo.cpp failed")
     return LIB
 
 
