@@ -289,3 +289,20 @@ def test_folded_final_conv_matches_piecewise_path(sd7):
         for a, b, r in zip(fused, piece, ref):
             assert (a - b).abs().max().item() < tol_pair
             assert (a.cpu() - r).abs().max().item() < tol_ref
+
+
+@pytest.mark.gpu
+def test_batch_256_c3_scene_consistency(net, dev):
+    """BASELINE c3 runs 256 scenes (32 per GPU on 8 GPUs; here all on one): scene k of the big batch equals the same
+    scene alone, for both precisions (size-independent property; exercises the large-batch index arithmetic)."""
+    x = torch.from_numpy(synth.tsdf_batch(500, 256)).to(dev)
+    p = torch.from_numpy(synth.query_points(500, 256, 64, stream=8)).to(dev)
+    for prec, tol in (("fp32", 1e-5), ("fp16", 1e-2)):
+        net.set_precision(prec)
+        with torch.no_grad():
+            full = net(x, p, p_tsdf=p)
+            for k in (0, 131, 255):
+                one = net(x[k:k + 1].contiguous(), p[k:k + 1].contiguous(), p_tsdf=p[k:k + 1].contiguous())
+                for a, b in zip(full, one):
+                    assert maxerr(a[k:k + 1], b.cpu()) < tol
+    net.set_precision("fp32")
