@@ -55,52 +55,78 @@ def bound_limits(voxel_size, limit=(0.02, 0.02, 0.055)):
     return tuple(int(l / voxel_size) for l in limit)
 
 
-def grasp_select(tsdf, qual, rot, width, voxel_size=None, out_th=0.5, threshold=0.9, force_detection=False,
-                 max_filter_size=4, gaussian_filter_sigma=1.0, min_width=0.033, max_width=0.233,
-                 limit=(0.02, 0.02, 0.055), return_volume=False):
-    """process + bound + select (detection_implicit.py:115-143, 87-97, 146-174) for B scenes on the device.
+class _GraspBuffers:
+    """Device buffers of one `giga_grasp_select` call.  Counters and candidate arrays are views of ONE int32 block, so
+    that with a small `cap` everything the host needs comes back in a single D->H copy."""
 
-    tsdf (B,R,R,R) | (B,1,R,R,R), qual (B,R^3), rot (B,R^3,4), width (B,R^3): float32 device tensors (the
-    network outputs of `predict_batch`).  Returns a list of B dicts with numpy arrays sorted by descending
-    score: index (K,3) voxel indices, score (K,), rot (K,4) quaternions, width (K,), best_only flag; plus the
-    processed quality volume (B,R,R,R) (device tensor) when return_volume is set."""
-    _capi.require_device(tsdf, qual, rot, width)
-    B = qual.shape[0]
-    R = tsdf.shape[-1]
+    def __init__(self, B, R, cap, dev):
+        V = R * R * R
+        self.B, self.R, self.cap = B, R, cap
+        self.pack = torch.empty(B * (2 + 7 * cap), dtype=torch.int32, device=dev)
+        o = 0
+        self.counters = self.pack[o:o + 2 * B].view(B, 2); o += 2 * B
+        self.cand_index = self.pack[o:o + B * cap].view(B, cap); o += B * cap
+        self.cand_score = self.pack[o:o + B * cap].view(torch.float32).view(B, cap); o += B * cap
+        self.cand_rot = self.pack[o:o + 4 * B * cap].view(torch.float32).view(B, cap, 4); o += 4 * B * cap
+        self.cand_width = self.pack[o:o + B * cap].view(torch.float32).view(B, cap)
+        self.qual_out = torch.empty(B, V, device=dev)
+        self.ws = torch.empty(_capi.lib().giga_grasp_workspace_bytes(B, R), dtype=torch.uint8, device=dev)
+
+    def host_views(self, pack_h):
+        B, cap = self.B, self.cap
+        o = 2 * B
+        cnt = pack_h[:o].reshape(B, 2)
+        idx = pack_h[o:o + B * cap].reshape(B, cap); o += B * cap
+        score = pack_h[o:o + B * cap].view(np.float32).reshape(B, cap); o += B * cap
+        rot = pack_h[o:o + 4 * B * cap].view(np.float32).reshape(B, cap, 4); o += 4 * B * cap
+        width = pack_h[o:o + B * cap].view(np.float32).reshape(B, cap)
+        return cnt, idx, score, rot, width
+
+
+def _grasp_params(R, voxel_size, out_th, threshold, force_detection, max_filter_size, gaussian_filter_sigma, min_width,
+                  max_width, limit):
+    if voxel_size is None:
+        voxel_size = 0.3 / R                                  # detection_implicit.py:41
+    lx, ly, lz = bound_limits(voxel_size, limit)
+    return _capi.GraspParams(float(gaussian_filter_sigma), min_width, max_width, out_th, LOW_TH, threshold,
+                             lx, ly, lz, int(max_filter_size), int(bool(force_detection)))
+
+
+def _grasp_launch(tsdf, qual, rot, width, prm, buf):
+    """Enqueue the four post-processing kernels on the current stream (no synchronisation; hipGraph-capturable)."""
+    B, R = buf.B, buf.R
     V = R * R * R
     tsdf = tsdf.reshape(B, V).float().contiguous()
     qual = qual.reshape(B, V).float().contiguous()
     rot = rot.reshape(B, V, 4).float().contiguous()
     width = width.reshape(B, V).float().contiguous()
-    if voxel_size is None:
-        voxel_size = 0.3 / R                                  # detection_implicit.py:41
-    lx, ly, lz = bound_limits(voxel_size, limit)
-    prm = _capi.GraspParams(float(gaussian_filter_sigma), min_width, max_width, out_th, LOW_TH, threshold,
-                            lx, ly, lz, int(max_filter_size), int(bool(force_detection)))
-    dev = qual.device
-    cap = V
-    qual_out = torch.empty(B, V, device=dev)
-    counters = torch.empty(B, 2, dtype=torch.int32, device=dev)
-    cand_index = torch.empty(B, cap, dtype=torch.int32, device=dev)
-    cand_score = torch.empty(B, cap, device=dev)
-    cand_rot = torch.empty(B, cap, 4, device=dev)
-    cand_width = torch.empty(B, cap, device=dev)
-    L = _capi.lib()
-    ws = torch.empty(L.giga_grasp_workspace_bytes(B, R), dtype=torch.uint8, device=dev)
-    _capi.check(L.giga_grasp_select(_capi.ptr(tsdf), _capi.ptr(qual), _capi.ptr(rot), _capi.ptr(width), B, R,
-                                    ctypes.byref(prm), _capi.ptr(qual_out), _capi.ptr(counters), cap,
-                                    _capi.ptr(cand_index), _capi.ptr(cand_score), _capi.ptr(cand_rot),
-                                    _capi.ptr(cand_width), _capi.ptr(ws), ws.numel(), _capi.stream_ptr()),
-                "giga_grasp_select")
-    cnt = counters.cpu().numpy()                              # synchronises; 8 bytes per scene
-    kmax = int(min(cnt[:, 1].max(), cap)) if B else 0
-    idx_h = cand_index[:, :kmax].cpu().numpy()
-    score_h = cand_score[:, :kmax].cpu().numpy()
-    rot_h = cand_rot[:, :kmax].cpu().numpy()
-    width_h = cand_width[:, :kmax].cpu().numpy()
+    _capi.check(_capi.lib().giga_grasp_select(
+        _capi.ptr(tsdf), _capi.ptr(qual), _capi.ptr(rot), _capi.ptr(width), B, R, ctypes.byref(prm),
+        _capi.ptr(buf.qual_out), _capi.ptr(buf.counters), buf.cap, _capi.ptr(buf.cand_index), _capi.ptr(buf.cand_score),
+        _capi.ptr(buf.cand_rot), _capi.ptr(buf.cand_width), _capi.ptr(buf.ws), buf.ws.numel(), _capi.stream_ptr()),
+        "giga_grasp_select")
+
+
+def _grasp_collect(buf, force_detection):
+    """D->H of the survivors and the host-side ordering.  Returns None if a scene produced more candidates than
+    `cap` (the caller then repeats with the full capacity)."""
+    B, R, cap = buf.B, buf.R, buf.cap
+    if B * (2 + 7 * cap) * 4 <= (1 << 20):                    # small block: one copy brings everything
+        cnt, idx_h, score_h, rot_h, width_h = buf.host_views(buf.pack.cpu().numpy())
+        if B and cnt[:, 1].max() > cap:
+            return None
+    else:
+        cnt = buf.counters.cpu().numpy()                      # synchronises; 8 bytes per scene
+        if B and cnt[:, 1].max() > cap:
+            return None
+        kmax = int(cnt[:, 1].max()) if B else 0
+        idx_h = buf.cand_index[:, :kmax].cpu().numpy()
+        score_h = buf.cand_score[:, :kmax].cpu().numpy()
+        rot_h = buf.cand_rot[:, :kmax].cpu().numpy()
+        width_h = buf.cand_width[:, :kmax].cpu().numpy()
     out = []
     for b in range(B):
-        k = int(min(cnt[b, 1], cap))
+        k = int(cnt[b, 1])
         best_only = bool(force_detection) and cnt[b, 0] == 0
         flat = idx_h[b, :k]
         # the reference sorts with reversed(np.argsort(scores)) over the argwhere (ascending index) order
@@ -112,8 +138,31 @@ def grasp_select(tsdf, qual, rot, width, voxel_size=None, out_th=0.5, threshold=
         out.append({"index": np.stack((flat // (R * R), (flat // R) % R, flat % R), -1).reshape(-1, 3),
                     "score": score_h[b, :k][order], "rot": rot_h[b, :k][order], "width": width_h[b, :k][order],
                     "best_only": best_only})
+    return out
+
+
+def grasp_select(tsdf, qual, rot, width, voxel_size=None, out_th=0.5, threshold=0.9, force_detection=False,
+                 max_filter_size=4, gaussian_filter_sigma=1.0, min_width=0.033, max_width=0.233,
+                 limit=(0.02, 0.02, 0.055), return_volume=False):
+    """process + bound + select (detection_implicit.py:115-143, 87-97, 146-174) for B scenes on the device.
+
+    tsdf (B,R,R,R) | (B,1,R,R,R), qual (B,R^3), rot (B,R^3,4), width (B,R^3): float32 device tensors (the
+    network outputs of `predict_batch`).  Returns a list of B dicts with numpy arrays sorted by descending
+    score: index (K,3) voxel indices, score (K,), rot (K,4) quaternions, width (K,), best_only flag; plus the
+    processed quality volume (B,R,R,R) (device tensor) when return_volume is set."""
+    _capi.require_device(tsdf, qual, rot, width)
+    B, R = qual.shape[0], tsdf.shape[-1]
+    prm = _grasp_params(R, voxel_size, out_th, threshold, force_detection, max_filter_size, gaussian_filter_sigma,
+                        min_width, max_width, limit)
+    out = None
+    for cap in (1024, R * R * R):                             # nearly always a few dozen survivors; plateaus need all
+        buf = _GraspBuffers(B, R, cap, qual.device)
+        _grasp_launch(tsdf, qual, rot, width, prm, buf)
+        out = _grasp_collect(buf, force_detection)
+        if out is not None:
+            break
     if return_volume:
-        return out, qual_out.view(B, R, R, R)
+        return out, buf.qual_out.view(B, R, R, R)
     return out
 
 
@@ -141,42 +190,54 @@ class VGNImplicit:
 
     def plan_batch(self, tsdf, tsdf_process=None, voxel_size=None):
         """tsdf (B,R,R,R) device tensor -> per-scene candidate dicts (see grasp_select), lattice positions added."""
-        R = self.resolution
-        if self.use_graph:
-            qual, rot, width = self._graphed_predict(tsdf)
-        else:
+        sel = None
+        if self.use_graph and tsdf.shape[0] <= 4:              # launch-bound regime only: at larger batches the eager
+            sel = self._graphed_plan(tsdf, tsdf_process, voxel_size)   # stream is GPU-bound and graph nodes do not pipeline
+        if sel is None:
             qual, rot, width = predict_batch(tsdf, self.pos, self.net)
-        sel = grasp_select(tsdf if tsdf_process is None else tsdf_process, qual, rot, width, voxel_size=voxel_size,
-                           out_th=self.out_th, threshold=self.qual_th, force_detection=self.force_detection,
-                           max_filter_size=8 if self.visualize else 4)
+            sel = grasp_select(tsdf if tsdf_process is None else tsdf_process, qual, rot, width, voxel_size=voxel_size,
+                               out_th=self.out_th, threshold=self.qual_th, force_detection=self.force_detection,
+                               max_filter_size=8 if self.visualize else 4)
         lin = self._lin_host
         for s in sel:
             s["position"] = lin[s["index"]]                    # center_vol[i, j, k], detection_implicit.py:181
         return sel
 
-    def _graphed_predict(self, tsdf):
-        """The network part of a plan (≈17 kernel launches) replayed as ONE hipGraph launch per batch size: a
-        single-scene plan is launch-bound, not compute-bound.  Inputs/outputs live in static buffers owned by the
-        graph; the outputs are valid until the next call with the same batch size."""
-        B = tsdf.shape[0]
-        ent = self._graphs.get(B)
+    def _graphed_plan(self, tsdf, tsdf_process, voxel_size):
+        """Network (~17 launches) AND post-processing (memset + 4 kernels) replayed as ONE hipGraph launch per batch
+        size, then one small D->H copy: a single-scene plan is launch-bound, not compute-bound.  Inputs live in
+        static buffers owned by the graph.  Returns None (eager path) if a scene has more survivors than the graph's
+        candidate capacity."""
+        B, R = tsdf.shape[0], self.resolution
+        key = (B, None if voxel_size is None else float(voxel_size))
+        ent = self._graphs.get(key)
         if ent is None:
             static_in = torch.empty_like(tsdf, dtype=torch.float32).contiguous()
+            static_proc = torch.empty_like(static_in)
             static_in.copy_(tsdf)
+            static_proc.copy_(tsdf if tsdf_process is None else tsdf_process)
+            prm = _grasp_params(R, voxel_size, self.out_th, self.qual_th, self.force_detection,
+                                8 if self.visualize else 4, 1.0, 0.033, 0.233, (0.02, 0.02, 0.055))
+            buf = _GraspBuffers(B, R, 1024, self.device)
+
+            def run():
+                qual, rot, width = predict_batch(static_in, self.pos, self.net)
+                _grasp_launch(static_proc, qual, rot, width, prm, buf)
             side = torch.cuda.Stream(self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):                      # warm-up outside capture (workspaces, attributes)
                 for _ in range(2):
-                    predict_batch(static_in, self.pos, self.net)
+                    run()
             torch.cuda.current_stream(self.device).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                outs = predict_batch(static_in, self.pos, self.net)
-            ent = self._graphs[B] = (graph, static_in, outs)
-        graph, static_in, outs = ent
+                run()
+            ent = self._graphs[key] = (graph, static_in, static_proc, buf, prm)
+        graph, static_in, static_proc, buf, _ = ent
         static_in.copy_(tsdf)
+        static_proc.copy_(tsdf if tsdf_process is None else tsdf_process)
         graph.replay()
-        return outs
+        return _grasp_collect(buf, self.force_detection)
 
     def __call__(self, state, scene_mesh=None, aff_kwargs={}):
         tsdf_process = state.tsdf_process if hasattr(state, "tsdf_process") else state.tsdf
