@@ -47,6 +47,18 @@ def test_argument_validation_without_gpu():
     flat = torch.zeros(10)
     with pytest.raises(_capi.GigaHipError):
         _capi.pack_weights(flat, 15)
+    # the flag bits of `precision` / `head_present` are masked before validation; unknown precisions still fail
+    assert lib.giga_decoder_forward(None, None, None, 7, None, None, None, None, 0, 5, _capi.FOLD_FINAL, 1, None) == 0
+    assert lib.giga_decoder_forward(None, None, None, 7, None, None, None, None, 1, 5, 2 | _capi.FOLD_FINAL, 1, None) == -5
+    assert lib.giga_encoder_workspace_bytes(4, _capi.FOLD_FINAL) == lib.giga_encoder_workspace_bytes(4, 0)
+    assert lib.giga_backward_workspace_bytes(2, 1, 64, 15 | _capi.DETACH_OCC) == lib.giga_backward_workspace_bytes(2, 1, 64, 15)
+    # grasp post-processing: null pointers, bad sizes
+    import ctypes
+    prm = _capi.GraspParams(1.0, 0.033, 0.233, 0.5, 0.5, 0.9, 2, 2, 7, 4, 0)
+    assert lib.giga_grasp_select(None, None, None, None, 1, 40, ctypes.byref(prm), None, None, 16, None, None, None, None,
+                                 None, 0, None) == -6
+    assert lib.giga_grasp_workspace_bytes(0, 40) == 0 and lib.giga_grasp_workspace_bytes(2, 40) == 2 * 2 * 64000 * 4
+    assert lib.giga_packed_bytes() > 4_000_000          # both precisions, plain and folded head images
 
 
 def test_pack_is_deterministic_and_sensitive(sd7):
