@@ -349,7 +349,7 @@ def bench_train(net, dev, synth, B, M, steps=10, rank=0, world=1):
     pos_occ = torch.from_numpy(synth.query_points(first, B, M, stream=3)).to(dev)
     y = tuple(torch.from_numpy(a).to(dev) for a in synth.train_labels(first, B, M))
     # the reference's optimiser (train_giga.py:49: Adam, lr 2e-4) in torch's single-launch form; the default
-    # per-tensor foreach path costs 6 ms of host time per step for the 98 parameter tensors
+    # per-tensor foreach path costs 6 ms of host time per step for the 164 parameter tensors
     opt = torch.optim.Adam(net.parameters(), lr=2e-4, fused=True)
 
     def step():
