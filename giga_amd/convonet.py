@@ -128,6 +128,9 @@ class _PackedWeights:
         self.blob = None
 
     def get(self, params, head_present, device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:    # "cuda" and "cuda:0" must share one cache entry
+            device = torch.device("cuda", torch.cuda.current_device())
         key = (head_present, str(device)) + tuple((p.data_ptr(), p._version) for p in params)
         if key != self.key:
             flat = _flat_params(params, "cpu")
@@ -139,8 +142,9 @@ class _PackedWeights:
 def _check_no_grad(params):
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         raise NotImplementedError(
-            "giga_amd forward kernels are inference-only in this round; wrap the call in "
-            "torch.no_grad() (the training/backward path is tracked in DESIGN.md).")
+            "the piecewise entry points (encode_inputs / decode / decode_occ / LocalDecoder / LocalVoxelEncoder) are "
+            "inference-only: wrap the call in torch.no_grad().  Training goes through the model's own forward, "
+            "net(inputs, p, p_tsdf=...), which is differentiable w.r.t. the parameters (DESIGN.md 3b).")
 
 
 def _head_param_list(dec):

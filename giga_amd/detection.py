@@ -187,6 +187,7 @@ class VGNImplicit:
         self._rng = np.random.default_rng(seed)
         self.use_graph = bool(use_graph)
         self._graphs = {}
+        self._graph_weights = None
 
     def plan_batch(self, tsdf, tsdf_process=None, voxel_size=None):
         """tsdf (B,R,R,R) device tensor -> per-scene candidate dicts (see grasp_select), lattice positions added."""
@@ -209,6 +210,12 @@ class VGNImplicit:
         static buffers owned by the graph.  Returns None (eager path) if a scene has more survivors than the graph's
         candidate capacity."""
         B, R = tsdf.shape[0], self.resolution
+        # a graph bakes in the packed-weight buffer and the precision: new weights / precision -> new capture
+        blob = self.net.packed_blob(self.device)
+        wkey = (self.net.precision, self.net._packed.key)      # parameter storage + versions, not the blob address
+        if self._graph_weights is None or self._graph_weights[0] != wkey:
+            self._graphs.clear()
+            self._graph_weights = (wkey, blob)                 # keeps the captured buffer alive with its graphs
         key = (B, None if voxel_size is None else float(voxel_size))
         ent = self._graphs.get(key)
         if ent is None:

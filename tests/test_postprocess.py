@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from giga_amd import synth
+from giga_amd import synth, weights
 from oracle import post_oracle
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "g6_postprocess.npz")
@@ -125,6 +125,13 @@ def test_planner_hipgraph_replay_matches_eager(sd7):
         for a, b in zip(ga, gb):
             assert np.array_equal(a["rotation"], b["rotation"]) and np.array_equal(a["translation"], b["translation"])
             assert a["width"] == b["width"]
+    # new weights invalidate the captured graph (it bakes in the packed-weight buffer)
+    net.load_state_dict(weights.make_state_dict(8))
+    st = State()
+    st.tsdf = synth.tsdf_batch(1, 1, realistic=True)
+    ga, sa, _ = eager(st)
+    gb, sb, _ = graphed(st)
+    assert len(ga) == len(gb) and np.array_equal(sa, sb)
 
 
 @pytest.mark.gpu
