@@ -139,8 +139,8 @@ class _PackedWeights:
         return self.blob
 
 
-def _check_no_grad(params):
-    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+def _check_no_grad(module):
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
         raise NotImplementedError(
             "the piecewise entry points (encode_inputs / decode / decode_occ / LocalDecoder / LocalVoxelEncoder) are "
             "inference-only: wrap the call in torch.no_grad().  Training goes through the model's own forward, "
@@ -236,7 +236,7 @@ class LocalVoxelEncoder(nn.Module):
         return nhwc, nchw
 
     def forward(self, x, _blob=None):
-        _check_no_grad(list(self.parameters()))
+        _check_no_grad(self)
         nhwc, nchw = self.encode_nhwc(x, blob=_blob, want_nchw=True)
         fea = PlaneDict((k, nchw[i]) for i, k in enumerate(PLANES))
         fea.nhwc, fea.precision = nhwc, self.precision
@@ -377,7 +377,7 @@ class LocalDecoder(nn.Module):
         return slot, pw.blob
 
     def forward(self, p, c_plane, **kwargs):
-        _check_no_grad(list(self.parameters()))
+        _check_no_grad(self)
         _capi.require_device(p)
         nhwc = _planes_to_nhwc(c_plane, self.precision)
         slot, blob = self._standalone(p.device)
@@ -388,7 +388,27 @@ class LocalDecoder(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # full model
 # ------------------------------------------------------------------------------------------------
-class ConvolutionalOccupancyNetwork(nn.Module):
+class _ParamListCache:
+    """Walking the module tree for the 164 parameters costs ~0.3 ms of Python, as much as the GPU work of one small
+    batch.  The tree is static, so the ordered list is built once and dropped whenever torch may have replaced the
+    Parameter objects (`_apply`: .to()/.half()/.cuda(); `load_state_dict`, which can assign)."""
+
+    def _ordered_params(self):
+        pl = self.__dict__.get("_plist")
+        if pl is None:
+            pl = self.__dict__["_plist"] = self._param_list()
+        return pl
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_plist", None)
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.__dict__.pop("_plist", None)
+        return super().load_state_dict(*args, **kwargs)
+
+
+class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
     """models/__init__.py:15-164: encoder + decoder_qual/rot/width (+ decoder_tsdf)."""
 
     def __init__(self, decoders, encoder=None, device=None, detach_tsdf=False):
@@ -419,12 +439,7 @@ class ConvolutionalOccupancyNetwork(nn.Module):
         return 7 | (8 if hasattr(self, "decoder_tsdf") else 0)
 
     def packed_blob(self, device):
-        params = []
-        for h in HEAD_NAMES:
-            if hasattr(self, h):
-                params += _head_param_list(getattr(self, h))
-        params += _encoder_param_list(self.encoder)
-        return self._packed.get(params, self._head_present(), device)
+        return self._packed.get(self._ordered_params(), self._head_present(), device)
 
     # -- reference API ------------------------------------------------------------------------------
     def forward(self, inputs, p, p_tsdf=None, sample=True, _probe=None, **kwargs):
@@ -432,7 +447,7 @@ class ConvolutionalOccupancyNetwork(nn.Module):
         qual (B,N) [sigmoid], rot (B,N,4) [unit], width (B,N) [, tsdf (B,M) raw logits].
         (`_probe`: bench.py's HIP-event bracket around one encoder kernel; not part of the API.)"""
         _capi.require_device(inputs, p, p_tsdf)
-        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+        if torch.is_grad_enabled() and any(q.requires_grad for q in self._ordered_params()):
             return self._forward_train(inputs, p, p_tsdf)
         blob = self.packed_blob(inputs.device)
         # encoder and decoders are called back to back here, so conv_final is folded into the heads' fc_c weights and
@@ -469,7 +484,7 @@ class ConvolutionalOccupancyNetwork(nn.Module):
         if st is None or st.blob.device != inputs.device:
             st = self._train_state = _TrainState(self._head_present(), inputs.device, detach_occ=self.detach_tsdf)
             st.data_parallel, st.group = getattr(self, "_dp", (False, None))
-        return GigaFunction.apply(st, inputs, p, p_tsdf, *self._param_list())
+        return GigaFunction.apply(st, inputs, p, p_tsdf, *self._ordered_params())
 
     def infer_geo(self, inputs, p_tsdf, **kwargs):
         """models/__init__.py:69-72."""
@@ -480,7 +495,7 @@ class ConvolutionalOccupancyNetwork(nn.Module):
         """models/__init__.py:74-87."""
         if self.encoder is None:
             return torch.empty(inputs.size(0), 0)
-        _check_no_grad(list(self.parameters()))
+        _check_no_grad(self)
         nhwc, nchw = self.encoder.encode_nhwc(inputs, blob=self.packed_blob(inputs.device), want_nchw=True,
                                               precision=self.precision)
         fea = PlaneDict((k, nchw[i]) for i, k in enumerate(PLANES))
@@ -494,12 +509,12 @@ class ConvolutionalOccupancyNetwork(nn.Module):
 
     def decode_occ(self, p, c, **kwargs):
         """models/__init__.py:100-109."""
-        _check_no_grad(list(self.parameters()))
+        _check_no_grad(self)
         return dist.Bernoulli(logits=self._decode_tsdf(p, c))
 
     def decode(self, p, c, **kwargs):
         """models/__init__.py:111-124."""
-        _check_no_grad(list(self.parameters()))
+        _check_no_grad(self)
         _capi.require_device(p)
         blob = self.packed_blob(p.device)
         nhwc = _planes_to_nhwc(c, self.precision)
@@ -513,7 +528,7 @@ class ConvolutionalOccupancyNetwork(nn.Module):
         return model
 
 
-class ConvolutionalOccupancyNetworkGeometry(nn.Module):
+class ConvolutionalOccupancyNetworkGeometry(_ParamListCache, nn.Module):
     """models/__init__.py:166-226 (occupancy head only; `giga_geo`)."""
 
     def __init__(self, decoder, encoder=None, device=None):
@@ -530,12 +545,14 @@ class ConvolutionalOccupancyNetworkGeometry(nn.Module):
         self.encoder.precision = precision
         return self
 
+    def _param_list(self):
+        return _head_param_list(self.decoder_tsdf) + _encoder_param_list(self.encoder)
+
     def packed_blob(self, device):
-        params = _head_param_list(self.decoder_tsdf) + _encoder_param_list(self.encoder)
-        return self._packed.get(params, 8, device)
+        return self._packed.get(self._ordered_params(), 8, device)
 
     def forward(self, inputs, p, p_tsdf, sample=True, **kwargs):
-        _check_no_grad(list(self.parameters()))
+        _check_no_grad(self)
         _capi.require_device(inputs, p_tsdf)
         blob = self.packed_blob(inputs.device)
         nhwc, _ = self.encoder.encode_nhwc(inputs, blob=blob, precision=self.precision)
@@ -545,7 +562,7 @@ class ConvolutionalOccupancyNetworkGeometry(nn.Module):
         return self.forward(inputs, None, p_tsdf)
 
     def encode_inputs(self, inputs):
-        _check_no_grad(list(self.parameters()))
+        _check_no_grad(self)
         nhwc, nchw = self.encoder.encode_nhwc(inputs, blob=self.packed_blob(inputs.device), want_nchw=True,
                                               precision=self.precision)
         fea = PlaneDict((k, nchw[i]) for i, k in enumerate(PLANES))
@@ -553,7 +570,7 @@ class ConvolutionalOccupancyNetworkGeometry(nn.Module):
         return fea
 
     def decode_occ(self, p, c, **kwargs):
-        _check_no_grad(list(self.parameters()))
+        _check_no_grad(self)
         nhwc = _planes_to_nhwc(c, self.precision)
         logits = decode_heads(nhwc, p, self.packed_blob(p.device), 8, self.precision, post=False)["decoder_tsdf"]
         return dist.Bernoulli(logits=logits)

@@ -182,3 +182,16 @@ def test_feed_and_generation_have_no_cpu_path():
     from giga_amd.feed import TSDFFeed
     with pytest.raises(GigaHipError):
         TSDFFeed([], device="cpu")
+
+
+def test_ordered_param_cache_tracks_replaced_parameters(sd7):
+    net = networks.get_network("giga")
+    assert [id(p) for p in net._ordered_params()] == [id(p) for p in net.parameters()]
+    assert net._ordered_params() is net._ordered_params()              # cached
+    old = net._ordered_params()
+    net.load_state_dict(sd7, assign=True)                              # replaces every Parameter object
+    new = net._ordered_params()
+    assert [id(p) for p in new] == [id(p) for p in net.parameters()] and new is not old
+    assert torch.equal(new[0], sd7["decoder_qual.fc_c.0.weight"])
+    net.double()                                                       # _apply drops the cache as well
+    assert net._ordered_params() is not new and net._ordered_params()[0].dtype == torch.float64
