@@ -8,6 +8,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libgiga_hip.so")
 DEMO_SRC = os.path.join(os.path.dirname(HERE), "examples", "c_abi_demo.cpp")
 DEMO = os.path.join(HERE, "lib", "c_abi_demo")
+PEAK_SRC = os.path.join(os.path.dirname(HERE), "tools", "mfma_peak.hip")
+PEAK = os.path.join(HERE, "lib", "mfma_peak")
 
 
 def _stale():
@@ -38,6 +40,13 @@ def build(force=False, verbose=False):
         if r.returncode != 0:
             sys.stderr.write((r.stdout or "") + (r.stderr or ""))
             raise RuntimeError("hipcc build of examples/c_abi_demo.cpp failed")
+    # the MFMA peak micro-benchmark behind the "measured peak" figures (tools/mfma_peak.hip); standalone
+    if os.path.exists(PEAK_SRC) and (force or not os.path.exists(PEAK) or os.path.getmtime(PEAK) < os.path.getmtime(PEAK_SRC)):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        r = subprocess.run([hipcc, "-O2", "--offload-arch=gfx950", PEAK_SRC, "-o", PEAK], capture_output=not verbose, text=True)
+        if r.returncode != 0:
+            sys.stderr.write((r.stdout or "") + (r.stderr or ""))
+            raise RuntimeError("hipcc build of tools/mfma_peak.hip failed")
     return LIB
 
 
