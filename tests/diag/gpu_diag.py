@@ -1,6 +1,6 @@
 """Stage-by-stage GPU diagnosis against the CPU oracle (run on the GPU box):
 
-    python tools/gpu_diag.py [--quick]
+    PYTHONPATH=. python tests/diag/gpu_diag.py [--quick]
 
 Prints max-abs error (and the reference magnitude) for every encoder stage read back from the
 workspace, every decoder head, and the full model, for both precisions; then a few timings.
@@ -13,7 +13,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from giga_amd import _capi, networks, synth, weights  # noqa: E402
 from oracle import giga_oracle as O  # noqa: E402

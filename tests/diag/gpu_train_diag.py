@@ -5,7 +5,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from giga_amd import networks, synth, weights  # noqa: E402
 from giga_amd.training import loss_fn, select  # noqa: E402
