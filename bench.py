@@ -33,8 +33,8 @@ PEAK_F32_MATRIX_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32-input MFMA == 
 PEAK_F16_MFMA_TFLOPS = 2500.0         # dense f16/bf16 MFMA
 # Sustained peaks measured on the round-1 box by tools/mfma_peak.hip (profiles/r01h_mfma_peak.txt): back-to-back
 # register-resident MFMAs on all 1024 SIMDs.  Reported beside the spec fraction; `frac` stays spec-based.
-MEASURED_F32_MATRIX_TFLOPS = 155.2    # v_mfma_f32_32x32x2_f32 (98.7 % of spec)
-MEASURED_F16_MFMA_TFLOPS = 2325.4     # v_mfma_f32_32x32x16_f16 (93 % of spec: the matrix-core clock sags to 2.2 GHz)
+MEASURED_F32_MATRIX_TFLOPS = 156.3    # v_mfma_f32_32x32x2_f32 (99.4 % of spec)
+MEASURED_F16_MFMA_TFLOPS = 2350.6     # v_mfma_f32_32x32x16_f16 (94 % of spec: the matrix-core clock sags to 2.24 GHz)
 FLOP_ENCODER = 1_132_953_600          # SURVEY.md 8d / BASELINE.md section 4
 FLOP_HEAD = {"qual": 51_456, "rot": 51_648, "width": 51_456, "tsdf": 51_456}
 FLOP_GRASP3 = 154_560

@@ -1,4 +1,4 @@
-// MFMA peak micro-benchmark for gfx950 ("confirm peaks on the box with an MFMA micro-benchmark and record
+// MFMA and HBM peak micro-benchmark for gfx950 ("confirm peaks on the box with an MFMA micro-benchmark and record
 // both spec and measured peak").  Every wave issues a long chain of independent MFMAs (4 accumulator sets, operands
 // in registers, no memory traffic); 256 CUs x 4 SIMDs x 2 waves.  Prints achieved TFLOP/s per instruction shape and
 // the implied clock (cycles per instruction are the documented pass counts: 16 passes = 64 cycles for the 32x32
@@ -82,6 +82,47 @@ static void run(const char* name, double flop_per_inst, int cycles_per_inst, dou
            spec_tflops, 100.0 * tflops / spec_tflops, ghz);
 }
 
+// HBM: streaming read (sum reduction so that nothing is elided) and copy over a buffer far larger than the 256 MB
+// Infinity Cache; float4 per lane, grid-stride, 8 workgroups per CU.
+__global__ __launch_bounds__(256) void hbm_read(const f32x4* __restrict__ src, size_t n, float* out) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = __builtin_nontemporal_load(src + i);
+        acc += v[0] + v[1] + v[2] + v[3];
+    }
+    if (acc == 12345.678f) out[0] = acc;
+}
+
+__global__ __launch_bounds__(256) void hbm_copy(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
+static void run_hbm(int ncu) {
+    const size_t bytes = (size_t)4 << 30, n = bytes / sizeof(f32x4);
+    f32x4 *a, *b; float* out;
+    CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&out, 64));
+    CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 0, bytes));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int mode = 0; mode < 2; ++mode) {
+        double best = 1e30;
+        for (int rep = 0; rep < 6; ++rep) {
+            CK(hipEventRecord(e0));
+            if (mode == 0) hbm_read<<<ncu * 8, 256>>>(a, n, out);
+            else hbm_copy<<<ncu * 8, 256>>>(a, b, n);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep && ms < best) best = ms;
+        }
+        const double moved = mode == 0 ? (double)bytes : 2.0 * bytes;
+        printf("%-28s %8.3f ms  %8.1f GB/s   (spec 8000, %5.1f %%)\n", mode == 0 ? "HBM read 4 GiB" : "HBM copy 4 GiB (rd+wr)", best,
+               moved / (best * 1e-3) / 1e9, 100.0 * moved / (best * 1e-3) / 8e12);
+    }
+    CK(hipFree(a)); CK(hipFree(b)); CK(hipFree(out));
+}
+
 int main() {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
@@ -94,5 +135,6 @@ int main() {
     run<F16_32x32x16>("v_mfma_f32_32x32x16_f16", 2.0 * 32 * 32 * 16, 32, 2500.0, out, ncu);
     run<F16_16x16x32>("v_mfma_f32_16x16x32_f16", 2.0 * 16 * 16 * 32, 16, 2500.0, out, ncu);
     CK(hipFree(out));
+    run_hbm(ncu);
     return 0;
 }
