@@ -18,6 +18,7 @@ One JSON line is printed by rank 0; besides the contract keys it carries
   extra         - config c4 (64 000 grasp queries/scene, f16-MFMA fused decoder) numbers
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -127,16 +128,16 @@ def main():
         step()
     torch.cuda.synchronize()
     stage_ms = []
-    ms = __import__("ctypes").c_float()
+    ms = ctypes.c_float()
     for st in range(15):
         reps = []
         for _ in range(5):                 # median of five: two layers are within a few percent of each other
             step(probe=(st, ev_a, ev_b))
-            _capi.check(L.giga_event_elapsed_ms(ev_a, ev_b, __import__("ctypes").byref(ms)), "event")
+            _capi.check(L.giga_event_elapsed_ms(ev_a, ev_b, ctypes.byref(ms)), "event")
             reps.append(ms.value)
         stage_ms.append(float(np.median(reps)))
     step(dec_probe=dec_ev)
-    _capi.check(L.giga_event_elapsed_ms(dec_ev[0], dec_ev[1], __import__("ctypes").byref(ms)), "event")
+    _capi.check(L.giga_event_elapsed_ms(dec_ev[0], dec_ev[1], ctypes.byref(ms)), "event")
     dec_ms_once = ms.value
     dom = int(np.argmax(stage_ms))
 
@@ -153,7 +154,7 @@ def main():
     elapsed = time.perf_counter() - t0
     dom_ms = []
     for a, b in evs:
-        _capi.check(L.giga_event_elapsed_ms(a, b, __import__("ctypes").byref(ms)), "event")
+        _capi.check(L.giga_event_elapsed_ms(a, b, ctypes.byref(ms)), "event")
         dom_ms.append(ms.value)
         L.giga_event_destroy(a); L.giga_event_destroy(b)
     t_elapsed = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -278,7 +279,6 @@ def main():
 
 
 def bench_c4(net, sd, dev, L, _capi, synth, decode_heads, Bc=32, steps=10):
-    import ctypes
     N = 64000
     net.set_precision("fp16")
     blob = net.packed_blob(dev)
