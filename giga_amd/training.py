@@ -90,7 +90,10 @@ class GigaFunction(torch.autograd.Function):
         if state.head_present & 8 and p_tsdf is not None:
             outs[3] = decode_heads(nhwc, p_tsdf, state.blob, 8, "fp32", False)["decoder_tsdf"]
         ctx.state, ctx.dims = state, (B, N, M)
-        ctx.saved = (x, p, p_tsdf, ws, nhwc, outs)
+        # save_for_backward, not a plain attribute: the head outputs are needed by the backward, and a node that holds
+        # its own outputs in a Python attribute is a reference cycle -- the 207 MB activation workspace would then live
+        # until the cyclic GC runs (GBs of growth, a hipMalloc every other step and a ~100 ms collection pause)
+        ctx.save_for_backward(x, p, p_tsdf, ws, nhwc, *outs)
         ctx.shapes = [tuple(q.shape) for q in params]
         result = tuple(o for o in outs if o is not None)
         ctx.out_slots = [i for i, o in enumerate(outs) if o is not None]
@@ -101,7 +104,7 @@ class GigaFunction(torch.autograd.Function):
         L = _capi.lib()
         state = ctx.state
         B, N, M = ctx.dims
-        x, p, p_tsdf, ws, nhwc, outs = ctx.saved
+        x, p, p_tsdf, ws, nhwc, *outs = ctx.saved_tensors
         dev = x.device
         douts = [None, None, None, None]
         for slot, gout in zip(ctx.out_slots, grad_outs):

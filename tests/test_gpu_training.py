@@ -134,3 +134,31 @@ def test_sgd_steps_track_the_oracle(sd7):
         ref_losses.append(rl)
     assert np.allclose(losses, ref_losses, rtol=0, atol=2e-4), (losses, ref_losses)
     assert losses[-1] < losses[0]
+
+
+def test_training_steps_do_not_accumulate_device_memory(sd7):
+    """The autograd node must not keep its activation workspace (207 MB at B=32) alive past the backward: with the
+    cyclic GC off, the allocated bytes after step 6 equal those after step 2 (a node holding its own outputs in a
+    plain attribute is a reference cycle that only the GC frees)."""
+    import gc
+    dev = torch.device("cuda:0")
+    net = networks.get_network("giga")
+    net.load_state_dict(sd7)
+    net = net.to(dev).train()
+    x, pos, pos_occ, y = (t.to(dev) if torch.is_tensor(t) else tuple(a.to(dev) for a in t) for t in _batch(40, 8, 512))
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+    gc.collect()
+    gc.disable()
+    try:
+        seen = []
+        for _ in range(6):
+            opt.zero_grad(set_to_none=True)
+            loss, _ = loss_fn(select(net(x, pos, p_tsdf=pos_occ)), y)
+            loss.backward()
+            opt.step()
+            del loss
+            torch.cuda.synchronize()
+            seen.append(torch.cuda.memory_allocated(dev))
+    finally:
+        gc.enable()
+    assert seen[5] - seen[1] < (1 << 20), seen
