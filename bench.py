@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MATRIX_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32-input MFMA == fp32 vector peak
 PEAK_F16_MFMA_TFLOPS = 2500.0         # dense f16/bf16 MFMA
-# Sustained peaks measured on the round-1 box by tools/mfma_peak.hip (profiles/r01i_hw_peaks.txt): back-to-back
+# Sustained peaks measured on the round-1 box by tools/mfma_peak.hip (profiles/r01j_hw_peaks.txt): back-to-back
 # register-resident MFMAs on all 1024 SIMDs.  Reported beside the spec fraction; `frac` stays spec-based.
 MEASURED_F32_MATRIX_TFLOPS = 156.3    # v_mfma_f32_32x32x2_f32 (99.4 % of spec)
 MEASURED_F16_MFMA_TFLOPS = 2350.6     # v_mfma_f32_32x32x16_f16 (94 % of spec: the matrix-core clock sags to 2.24 GHz)

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdArgs a) {
                     f32x16 t;
                     unsigned m = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { t[r] = relu(net[r]); m |= (net[r] > 0.f ? 1u : 0u) << r; }
+                    for (int r = 0; r < 16; ++r) { t[r] = relu_ieee(net[r]); m |= (net[r] > 0.f ? 1u : 0u) << r; }
                     mnet[blk] = m;
                     store_rows(S + (11 + blk) * AS, g, hi, t, valid);          // XN[blk]
                 }
@@ -159,22 +159,22 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 A = W[(k++) * 64 + lane];
-                    hcur = mfma32(A.x, relu(net[4 * q + 0]), hcur); hcur = mfma32(A.y, relu(net[4 * q + 1]), hcur);
-                    hcur = mfma32(A.z, relu(net[4 * q + 2]), hcur); hcur = mfma32(A.w, relu(net[4 * q + 3]), hcur);
+                    hcur = mfma32(A.x, relu_ieee(net[4 * q + 0]), hcur); hcur = mfma32(A.y, relu_ieee(net[4 * q + 1]), hcur);
+                    hcur = mfma32(A.z, relu_ieee(net[4 * q + 2]), hcur); hcur = mfma32(A.w, relu_ieee(net[4 * q + 3]), hcur);
                 }
                 {
                     f32x16 t;
                     unsigned m = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { t[r] = relu(hcur[r]); m |= (hcur[r] > 0.f ? 1u : 0u) << r; }
+                    for (int r = 0; r < 16; ++r) { t[r] = relu_ieee(hcur[r]); m |= (hcur[r] > 0.f ? 1u : 0u) << r; }
                     mhid[blk] = m;
                     store_rows(S + (16 + blk) * AS, g, hi, t, valid);          // XH[blk]
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 A = W[(k++) * 64 + lane];
-                    net = mfma32(A.x, relu(hcur[4 * q + 0]), net); net = mfma32(A.y, relu(hcur[4 * q + 1]), net);
-                    net = mfma32(A.z, relu(hcur[4 * q + 2]), net); net = mfma32(A.w, relu(hcur[4 * q + 3]), net);
+                    net = mfma32(A.x, relu_ieee(hcur[4 * q + 0]), net); net = mfma32(A.y, relu_ieee(hcur[4 * q + 1]), net);
+                    net = mfma32(A.z, relu_ieee(hcur[4 * q + 2]), net); net = mfma32(A.w, relu_ieee(hcur[4 * q + 3]), net);
                 }
             }
             {   // + fc_1 bias of the last block -> net5
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdArgs a) {
                 f32x16 t;
                 unsigned m = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { t[r] = relu(net[r]); m |= (net[r] > 0.f ? 1u : 0u) << r; }
+                for (int r = 0; r < 16; ++r) { t[r] = relu_ieee(net[r]); m |= (net[r] > 0.f ? 1u : 0u) << r; }
                 mnet[NBLK] = m;
                 store_rows(S + 21 * AS, g, hi, t, valid);
             }
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdArgs a) {
                 for (int o = 0; o < 4; ++o) {
                     float s = 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) s = fmaf(wout[o * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi], relu(net[r]), s);
+                    for (int r = 0; r < 16; ++r) s = fmaf(wout[o * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi], relu_ieee(net[r]), s);
                     s += __shfl_xor(s, 32);
                     z[o] = s;
                 }

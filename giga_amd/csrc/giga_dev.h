@@ -33,7 +33,19 @@ __device__ __forceinline__ f32x4v mfma16_16(half8 a, half8 b, f32x4v c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float relu(float x) { return __builtin_fmaxf(x, 0.f); }
+// ReLU as ONE instruction: a signed-integer max on the float's bits (negative floats, -0 included, are negative
+// integers).  fmaxf(x, 0) on an MFMA result compiles to TWO v_max_f32: IEEE fmaxnum semantics put a canonicalising
+// `v_max_f32 x, x` in front because the compiler cannot prove the accumulator is not a signalling NaN, and with four
+// MFMA-result ReLUs per fp32 MFMA step the extra VALU slot is not free (fp32 MFMA and VALU issue serially).  (An
+// inline-asm v_max_f32 is not an option: the hazard recogniser does not see into it and the MFMA -> VALU wait states
+// go missing.)  Bit-identical to fmaxf for every non-NaN input; NaNs with the sign bit set become 0, others pass.
+__device__ __forceinline__ float relu(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+// fmaxf form.  The backward decoder keeps it: with the integer form its register allocation tips over
+// (462 -> 512 VGPRs + 16 spills).
+__device__ __forceinline__ float relu_ieee(float x) { return __builtin_fmaxf(x, 0.f); }
 
 // round-to-nearest f16 then relu (== relu then round) of D registers 8c..8c+7 -> B operand of the next
 // layer's chunk c.  4x v_cvt_pk_f16_f32 + 4x v_pk_max_f16 instead of 16 canonicalising v_max_f32.

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
             f32x4v part_y = zero4;            // per r: sum over the 5 iy-pairs of this group
 #pragma unroll
             for (int ip = 0; ip < 5; ++ip) {
-                const f32x4v v = __builtin_elementwise_max(d[ip], zero4);
+                const f32x4v v = {relu(d[ip][0]), relu(d[ip][1]), relu(d[ip][2]), relu(d[ip][3])};
                 acc_yz[ip][zg] += v;
                 sum_z[ip] += f32x2v{v[0], v[1]} + f32x2v{v[2], v[3]};
                 part_y += v;
