@@ -125,6 +125,19 @@ def test_planner_hipgraph_replay_matches_eager(sd7):
         for a, b in zip(ga, gb):
             assert np.array_equal(a["rotation"], b["rotation"]) and np.array_equal(a["translation"], b["translation"])
             assert a["width"] == b["width"]
+    # another batch size through the same network evicts the one-entry workspace caches the graph was captured with;
+    # the graph holds its own references, so replaying it afterwards must neither read nor clobber recycled memory
+    st = State()
+    st.tsdf = synth.tsdf_batch(2, 1, realistic=True)
+    want = eager(st)[1]
+    batch = torch.from_numpy(synth.tsdf_batch(10, 3, realistic=True)).to(dev)
+    sel3 = eager.plan_batch(batch)
+    junk = [torch.full((1 << 22,), float("nan"), device=dev) for _ in range(16)]     # reuse whatever was freed
+    assert np.array_equal(graphed(st)[1], want)
+    again = eager.plan_batch(batch)
+    assert all(np.array_equal(a["score"], b["score"]) for a, b in zip(sel3, again))
+    assert all(bool(torch.isnan(j).all()) for j in junk)
+    del junk
     # new weights invalidate the captured graph (it bakes in the packed-weight buffer)
     net.load_state_dict(weights.make_state_dict(8))
     st = State()
