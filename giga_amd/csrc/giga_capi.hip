@@ -97,6 +97,8 @@ size_t giga_encoder_workspace_bytes(int B, int precision) {
 
 int giga_encoder_workspace_layout(int B, int precision, size_t* offsets) {
     if (B <= 0 || !offsets) return -1;
+    precision &= ~GIGA_FOLD_FINAL;
+    if (precision != 0 && precision != 1) return -5;
     const EncWs w = enc_workspace(B, precision);
     const size_t v[17] = {w.P0, w.A0, w.S0, w.Q0, w.A1, w.S1, w.Q1, w.A2, w.S2, w.U0, w.A3, w.A4, w.U1, w.A5, w.A6,
                           w.YZ, w.XZ};
@@ -203,16 +205,17 @@ int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, cons
     if (B == 0 || R == 0 || (head_mask & 15) == 0) return 0;
     if (!planes_nhwc || !lin || !packed || !workspace) return -1;
     if (workspace_bytes < giga_lattice_workspace_bytes(B, R, precision)) return -4;
+    float* outs[NHEADS] = {qual, rot, width, occ};
+    for (int h = 0; h < NHEADS; ++h)
+        if ((head_mask >> h & 1) && !outs[h]) return -6;      // before anything is enqueued
     hipStream_t s = static_cast<hipStream_t>(stream);
     int rc = launch_lattice_resample(planes_nhwc, lin, workspace, B, R, precision, s);
     if (rc) return rc;
     const PackOff ko = pack_offsets();
     DecArgs a{};
     a.planes = workspace; a.p = nullptr; a.blob = static_cast<const uint8_t*>(packed);
-    float* outs[NHEADS] = {qual, rot, width, occ};
     for (int h = 0; h < NHEADS; ++h) {
         if (!(head_mask >> h & 1)) continue;
-        if (!outs[h]) return -6;
         a.head_id[a.nheads] = h;
         a.head_off[a.nheads] = precision == 1 ? (fold ? ko.dec16f[h] : ko.dec16[h]) : (fold ? ko.dec32f[h] : ko.dec32[h]);
         a.out[a.nheads] = outs[h];
@@ -261,7 +264,12 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
         return -1;
     const bool detach_occ = (head_present & GIGA_DETACH_OCC) != 0;     // detach_tsdf, models/__init__.py:61-63
     head_present &= 15;
+    if (N < 0 || M < 0) return -1;
     if (n_params != param_offsets(head_present).total) return -2;
+    for (int h = 0; h < NHEADS; ++h) {                                  // every head that will run needs out and dout
+        const bool runs = (head_present >> h & 1) && (h < 3 ? N > 0 : (M > 0 && p_tsdf != nullptr));
+        if (runs && (!outs[h] || !douts[h])) return -6;
+    }
     if (workspace_bytes < giga_backward_workspace_bytes(B, N, M, head_present)) return -4;
     hipStream_t s = static_cast<hipStream_t>(stream);
     uint8_t* ws = static_cast<uint8_t*>(workspace);

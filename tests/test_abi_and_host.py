@@ -59,6 +59,24 @@ def test_argument_validation_without_gpu():
                                  None, 0, None) == -6
     assert lib.giga_grasp_workspace_bytes(0, 40) == 0 and lib.giga_grasp_workspace_bytes(2, 40) == 2 * 2 * 64000 * 4
     assert lib.giga_packed_bytes() > 4_000_000          # both precisions, plain and folded head images
+    # giga_backward validates before it enqueues anything: fake (host) addresses are never dereferenced here
+    host = (ctypes.c_float * 16)()
+    fake = ctypes.addressof(host)
+    null4 = (ctypes.c_void_p * 4)()                     # outs / douts with every head pointer NULL
+    n15 = lib.giga_param_count(15)
+    bw = lambda **k: lib.giga_backward(fake, fake, fake, fake, fake, fake, k.get("p_tsdf", fake), k.get("outs", null4),
+                                       k.get("douts", null4), fake, k.get("n", n15), k.get("heads", 15), k.get("B", 2),
+                                       k.get("N", 1), k.get("M", 8), fake, k.get("wsb", 0), None)
+    assert bw(B=0) == 0                                 # empty batch
+    assert bw(N=-1) == -1 and bw(M=-3) == -1
+    assert bw(n=n15 - 1) == -2 and bw(heads=7) == -2    # parameter count must match the head set
+    assert bw() == -6                                   # a head that runs needs its out and dout pointers
+    some = (ctypes.c_void_p * 4)(fake, fake, fake, None)
+    assert bw(outs=some, douts=some) == -6              # ... the occupancy head too (M > 0, p_tsdf given)
+    assert bw(outs=some, douts=some, p_tsdf=None) == -4 # without occupancy queries that head does not run; next check
+    assert lib.giga_encoder_workspace_layout(2, 7, (ctypes.c_size_t * 17)()) == -5
+    assert lib.giga_decoder_forward_lattice(fake, fake, fake, 1, None, None, None, None, 1, 4, 0, 1, fake, 1 << 30, None,
+                                            None, None) == -6
 
 
 def test_pack_is_deterministic_and_sensitive(sd7):
