@@ -122,7 +122,9 @@ int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, cons
  * kept alive (it holds every U-Net activation).  giga_backward computes the gradient of a scalar loss with
  * respect to EVERY parameter, given the gradients of the four head outputs:
  *   outs / douts : arrays of 4 device pointers (qual [B*N], rot [B*N][4], width [B*N], occ [B*M]); entries of
- *                  absent heads are ignored.  outs are the forward results (post sigmoid / normalize).
+ *                  absent heads are ignored, a NULL entry of a head that runs (grasp heads: N > 0; occupancy head:
+ *                  M > 0 and p_tsdf given) is GIGA -6.  outs are the forward results (post sigmoid / normalize).
+ *                  Every argument is validated before anything is enqueued on the stream.
  *   grads        : flat fp32 buffer in reference state-dict order (giga_param_count), overwritten.
  *   head_present : head bits, optionally | GIGA_DETACH_OCC: the occupancy head then reads detached planes, i.e. its
  *                  loss does not reach the encoder (detach_tsdf of `giga_detach`, models/__init__.py:61-63,
