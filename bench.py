@@ -88,7 +88,11 @@ def main():
         # code path of the multi-GPU runs can be exercised on a single-GPU box)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # Rendezvous and the barriers that bracket the timed region run over gloo (host side, TCP on 127.0.0.1); the
+        # RCCL communicator for the collectives proper (MAX of the times, all_gather of the counters, the data-parallel
+        # gradient all-reduce) is created AFTER the timed region: the hot path has no collective, and a live RCCL
+        # communicator (its streams / hardware queues) was measured to slow the single-GPU step by 2-5 %
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from giga_amd import _capi, networks, synth, weights
     from giga_amd.convonet import decode_heads
@@ -161,12 +165,14 @@ def main():
         dom_ms.append(ms.value)
         L.giga_event_destroy(a); L.giga_event_destroy(b)
     t_elapsed = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    rccl = None
     if dist is not None:
-        dist.all_reduce(t_elapsed, op=dist.ReduceOp.MAX)
+        rccl = dist.new_group(backend="nccl")                # one rank per GPU over RCCL / xGMI
+        dist.all_reduce(t_elapsed, op=dist.ReduceOp.MAX, group=rccl)
         # the north-star's single data-path-free collective: gather per-rank counters
         counters = torch.tensor([float(B * K), elapsed], dtype=torch.float64, device=dev)
         gathered = [torch.zeros_like(counters) for _ in range(world)]
-        dist.all_gather(gathered, counters)
+        dist.all_gather(gathered, counters, group=rccl)
         total_scenes = sum(float(c[0]) for c in gathered)
     else:
         total_scenes = float(B * K)
@@ -178,7 +184,7 @@ def main():
     dp_train = None
     if dist is not None and world > 1 and args.dp_train:
         try:
-            net.enable_data_parallel()
+            net.enable_data_parallel(group=rccl)
             dp_train = bench_train(net, dev, synth, B, M, rank=rank, world=world)
         except Exception as e:  # noqa: BLE001
             dp_train = {"error": f"{type(e).__name__}: {e}"}
