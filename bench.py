@@ -88,6 +88,7 @@ def main():
         # code path of the multi-GPU runs can be exercised on a single-GPU box)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")    # one node by contract; the hostname may not resolve
         # Rendezvous and the barriers that bracket the timed region run over gloo (host side, TCP on 127.0.0.1); the
         # RCCL communicator for the collectives proper (MAX of the times, all_gather of the counters, the data-parallel
         # gradient all-reduce) is created AFTER the timed region: the hot path has no collective, and a live RCCL
