@@ -9,7 +9,8 @@ A "step" is one forward pass of BASELINE.json configs[1] on every rank:
     (1 grasp query point for the three grasp heads + 2048 occupancy queries per scene),
     encoder + decoders in exact fp32 (fp32 MFMA), inputs resident in HBM, outputs left in HBM.
 Scenes are independent, so ranks are pure replicas on different scenes (weak scaling); the only
-collective is one all_gather of per-rank counters at the end (RCCL over xGMI).
+collectives are the MAX-reduce of the elapsed times and one all_gather of per-rank counters at the
+end (RCCL over xGMI; the group is created after the timed region, whose two barriers run over gloo).
 
 One JSON line is printed by rank 0; besides the contract keys it carries
   roofline      - the dominant kernel of the timed workload, timed live with HIP events on the
