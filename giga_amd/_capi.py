@@ -17,7 +17,8 @@ HEAD_QUAL, HEAD_ROT, HEAD_WIDTH, HEAD_TSDF = 1, 2, 4, 8
 DETACH_OCC = 16          # GIGA_DETACH_OCC: flag for giga_backward's head_present
 FOLD_FINAL = 16          # GIGA_FOLD_FINAL: OR-ed into `precision` of an encoder call and of the decoder calls on its planes
 HEAD_BITS = {"decoder_qual": 1, "decoder_rot": 2, "decoder_width": 4, "decoder_tsdf": 8}
-PRECISION = {"fp32": 0, "fp16": 1}
+PRECISION = {"fp32": 0, "fp16": 1, "fp16x3": 2}     # include/giga_hip.h `precision`
+PLANE_DTYPE = {0: torch.float32, 1: torch.float16, 2: torch.float32}   # element type of the NHWC planes per precision
 
 _lib = None
 

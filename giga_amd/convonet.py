@@ -216,8 +216,7 @@ class LocalVoxelEncoder(nn.Module):
         B = x.shape[0]
         L = _capi.lib()
         blob = self._blob(x.device, blob)
-        nhwc = torch.empty((3, B, RES, RES, C_DIM), device=x.device,
-                           dtype=torch.float16 if prec == 1 else torch.float32)
+        nhwc = torch.empty((3, B, RES, RES, C_DIM), device=x.device, dtype=_capi.PLANE_DTYPE[prec])
         nchw = torch.empty((3, B, C_DIM, RES, RES), device=x.device, dtype=torch.float32) if want_nchw else None
         key = (B, prec, str(x.device))
         ws = self._ws.get(key)
@@ -248,7 +247,8 @@ class LocalVoxelEncoder(nn.Module):
 # ------------------------------------------------------------------------------------------------
 def _planes_to_nhwc(c_plane, precision):
     """PlaneDict fast path, else repack the reference-layout tensors on the device."""
-    if isinstance(c_plane, PlaneDict) and c_plane.nhwc is not None and c_plane.precision == precision:
+    if isinstance(c_plane, PlaneDict) and c_plane.nhwc is not None and \
+            c_plane.nhwc.dtype == _capi.PLANE_DTYPE[_capi.PRECISION[precision]]:
         return c_plane.nhwc
     if list(c_plane.keys()) != list(PLANES):
         raise NotImplementedError("GIGA decoders sample the three planes ['xz','xy','yz']")
@@ -259,8 +259,7 @@ def _planes_to_nhwc(c_plane, precision):
         if tuple(t.shape) != (B, C_DIM, RES, RES):
             raise ValueError(f"expected (B,{C_DIM},{RES},{RES}) planes, got {tuple(t.shape)}")
     prec = _capi.PRECISION[precision]
-    nhwc = torch.empty((3, B, RES, RES, C_DIM), device=xs[0].device,
-                       dtype=torch.float16 if prec == 1 else torch.float32)
+    nhwc = torch.empty((3, B, RES, RES, C_DIM), device=xs[0].device, dtype=_capi.PLANE_DTYPE[prec])
     _capi.check(_capi.lib().giga_planes_pack(_capi.ptr(xs[0]), _capi.ptr(xs[1]), _capi.ptr(xs[2]),
                                              _capi.ptr(nhwc), B, prec, _capi.stream_ptr()),
                 "giga_planes_pack")
@@ -426,7 +425,8 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
 
     # -- weights ----------------------------------------------------------------------------------
     def set_precision(self, precision):
-        """'fp32' (exact fp32 MFMA, default) or 'fp16' (f16 operands, fp32 accumulate)."""
+        """'fp32' (exact fp32 MFMA, default), 'fp16' (f16 operands, fp32 accumulate: 2-5e-3 on raw logits) or 'fp16x3'
+        (f16 MFMA on split hi/lo operands: fp32-grade results, <= 1e-5, at ~5x the fp32-MFMA rate; fp32 encoder)."""
         if precision not in _capi.PRECISION:
             raise ValueError(precision)
         self.precision = precision

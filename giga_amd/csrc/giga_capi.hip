@@ -36,6 +36,13 @@ int launch_planes_unpack(const void* src, float* dst, int B, int precision, hipS
 
 using namespace giga;
 
+// byte offset of head h's weight image for a precision (0 fp32, 1 f16, 2 f16x3 split), plain or with conv_final folded in
+static size_t head_image_offset(const PackOff& ko, int h, int precision, bool fold) {
+    if (precision == 2) return fold ? ko.dec16sf[h] : ko.dec16s[h];
+    if (precision == 1) return fold ? ko.dec16f[h] : ko.dec16[h];
+    return fold ? ko.dec32f[h] : ko.dec32[h];
+}
+
 // blob word w <- params[map[w]] (map >= 0) | 0 (map == -1) | untouched (map == -2)
 __global__ void repack_kernel(const float* __restrict__ params, const int32_t* __restrict__ map,
                               float* __restrict__ words, size_t nwords) {
@@ -98,7 +105,7 @@ size_t giga_encoder_workspace_bytes(int B, int precision) {
 int giga_encoder_workspace_layout(int B, int precision, size_t* offsets) {
     if (B <= 0 || !offsets) return -1;
     precision &= ~GIGA_FOLD_FINAL;
-    if (precision != 0 && precision != 1) return -5;
+    if (precision < 0 || precision > 2) return -5;
     const EncWs w = enc_workspace(B, precision);
     const size_t v[17] = {w.P0, w.A0, w.S0, w.Q0, w.A1, w.S1, w.Q1, w.A2, w.S2, w.U0, w.A3, w.A4, w.U1, w.A5, w.A6,
                           w.YZ, w.XZ};
@@ -112,7 +119,7 @@ int giga_encoder_forward_probe(const float* tsdf, const void* packed, void* plan
     if (B < 0 || (B > 0 && (!tsdf || !packed || !planes_nhwc || !workspace))) return -1;
     const bool fold = (precision & GIGA_FOLD_FINAL) != 0;     // stop before conv_final (folded decoder images)
     precision &= ~GIGA_FOLD_FINAL;
-    if (precision != 0 && precision != 1) return -5;
+    if (precision < 0 || precision > 2) return -5;
     if (fold && planes_nchw) return -1;                       // the reference-layout copy is the FINAL planes only
     if (workspace_bytes < giga_encoder_workspace_bytes(B, precision)) return -4;
     return launch_encoder(tsdf, static_cast<const uint8_t*>(packed), planes_nhwc, planes_nchw, B,
@@ -142,13 +149,13 @@ int giga_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms) {
 int giga_planes_pack(const float* xz, const float* xy, const float* yz, void* planes_nhwc, int B, int precision,
                      void* stream) {
     if (B < 0 || (B > 0 && (!xz || !xy || !yz || !planes_nhwc))) return -1;
-    if (precision != 0 && precision != 1) return -5;
+    if (precision < 0 || precision > 2) return -5;
     return launch_planes_pack(xz, xy, yz, planes_nhwc, B, precision, static_cast<hipStream_t>(stream));
 }
 
 int giga_planes_unpack(const void* planes_nhwc, float* planes_nchw, int B, int precision, void* stream) {
     if (B < 0 || (B > 0 && (!planes_nhwc || !planes_nchw))) return -1;
-    if (precision != 0 && precision != 1) return -5;
+    if (precision < 0 || precision > 2) return -5;
     return launch_planes_unpack(planes_nhwc, planes_nchw, B, precision, static_cast<hipStream_t>(stream));
 }
 
@@ -169,7 +176,7 @@ int giga_decoder_forward_probe(const void* planes_nhwc, const float* p, const vo
     if (B < 0 || N < 0) return -1;
     const bool fold = (precision & GIGA_FOLD_FINAL) != 0;     // planes are the encoder output BEFORE conv_final
     precision &= ~GIGA_FOLD_FINAL;
-    if (precision != 0 && precision != 1) return -5;
+    if (precision < 0 || precision > 2) return -5;
     if ((long long)B * N == 0 || (head_mask & 15) == 0) return 0;
     if (!planes_nhwc || !p || !packed) return -1;
     const PackOff ko = pack_offsets();
@@ -180,7 +187,7 @@ int giga_decoder_forward_probe(const void* planes_nhwc, const float* p, const vo
         if (!(head_mask >> h & 1)) continue;
         if (!outs[h]) return -6;
         a.head_id[a.nheads] = h;
-        a.head_off[a.nheads] = precision == 1 ? (fold ? ko.dec16f[h] : ko.dec16[h]) : (fold ? ko.dec32f[h] : ko.dec32[h]);
+        a.head_off[a.nheads] = head_image_offset(ko, h, precision, fold);
         a.out[a.nheads] = outs[h];
         ++a.nheads;
     }
@@ -201,7 +208,7 @@ int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, cons
     if (B < 0 || R < 0 || R > 64) return -1;
     const bool fold = (precision & GIGA_FOLD_FINAL) != 0;
     precision &= ~GIGA_FOLD_FINAL;
-    if (precision != 0 && precision != 1) return -5;
+    if (precision < 0 || precision > 2) return -5;
     if (B == 0 || R == 0 || (head_mask & 15) == 0) return 0;
     if (!planes_nhwc || !lin || !packed || !workspace) return -1;
     if (workspace_bytes < giga_lattice_workspace_bytes(B, R, precision)) return -4;
@@ -217,7 +224,7 @@ int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, cons
     for (int h = 0; h < NHEADS; ++h) {
         if (!(head_mask >> h & 1)) continue;
         a.head_id[a.nheads] = h;
-        a.head_off[a.nheads] = precision == 1 ? (fold ? ko.dec16f[h] : ko.dec16[h]) : (fold ? ko.dec32f[h] : ko.dec32[h]);
+        a.head_off[a.nheads] = head_image_offset(ko, h, precision, fold);
         a.out[a.nheads] = outs[h];
         ++a.nheads;
     }

@@ -287,6 +287,220 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16_kernel(DecArgs a) {
     }
 }
 
+
+// =============================== f16x3 split-operand MFMA path =====================================
+// Same transposed, lane-local chain on v_mfma_f32_32x32x16_f16, but every operand is a PAIR hi = f16(v), lo = f16(v - hi)
+// and every product is evaluated as  W_lo*x_hi + W_hi*x_lo + W_hi*x_hi  with fp32 accumulation (the dropped W_lo*x_lo term is
+// 2^-22 relative): operands are carried to ~22 bits at 3x the f16 MFMA count, i.e. fp32-grade results (<= 1e-5 on the head
+// outputs against the fp32 oracle) at ~5x the rate of the fp32-input MFMA.  This is the mode that satisfies both clauses of the
+// north star: "MFMA fp16 tiles" and "within 1e-3".
+// Structure: HEAD-RESIDENT workgroups.  A workgroup serves ONE head for its whole life: the 111 KiB [hi, lo] image of that
+// head is filled into LDS once (LDS-DMA) and there is no barrier, no weight traffic and no head switching afterwards;
+// workgroup i takes head i % nheads and an equal contiguous share of the 32-point tiles.  The features are gathered per
+// head (three pixels of 128 B per point on the lattice path -- the planes were resampled AND split by
+// lattice_resample_split_kernel, so the B operands are loaded ready-made; 12 bilinear taps on fp32 planes otherwise), which
+// costs a few percent of the 162-MFMA chain.  8 waves of T = 2 tiles.
+constexpr int DEC16S_CHUNKS = (int)(DEC16S_BYTES / FRAG);    // 111
+
+template <int T, bool LATTICE, int NW>
+__global__ __launch_bounds__(NW * 64) void decoder_f16s_kernel(DecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, hi = lane >> 5;
+    const int hsel = blockIdx.x % a.nheads, slot = blockIdx.x / a.nheads, slots = gridDim.x / a.nheads;
+    dma_head_image<NW, DEC16S_CHUNKS>(a.blob + a.head_off[hsel], smem, wave, lane);
+
+    const long long tiles_total = (a.P + 31) / 32;
+    const long long tile_lo = tiles_total * slot / slots;
+    const long long tile_hi = tiles_total * (slot + 1) / slots;
+    const half8* W = reinterpret_cast<const half8*>(smem);
+    const float* ctab = reinterpret_cast<const float*>(smem + (size_t)DEC16S_FRAGS * FRAG);
+    const size_t plane_stride = LATTICE ? (size_t)a.B * a.R * a.R * CD : (size_t)a.B * RES * RES * CD;   // elements (4 B each)
+
+    half8 cfh[T][6], cfl[T][6], ax[T];
+    long long gidx[T];
+    bool valid[T];
+    long long tile0 = tile_lo + (long long)wave * T;
+    for (int iter = 0;; ++iter, tile0 += NW * T) {
+        const bool has = tile0 < tile_hi;
+        if (has) {
+            float pxs[T], pys[T], pzs[T];
+            int bs[T], rs[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                long long g = (tile0 + t) * 32 + n;
+                valid[t] = tile0 + t < tile_hi && g < a.P;
+                if (!valid[t]) g = a.P - 1;
+                gidx[t] = g;
+                split_scene(g, a.N, a.invN, bs[t], rs[t]);
+                if constexpr (LATTICE) {
+                    const int R = a.R, R2 = R * R;
+                    const int ix = div_magic(rs[t], a.mR2), rz = rs[t] - ix * R2;
+                    const int iy = div_magic(rz, a.mR), iz = rz - iy * R;
+                    pxs[t] = a.lin[ix]; pys[t] = a.lin[iy]; pzs[t] = a.lin[iz];
+                    // split planes: pixel = 4 groups of 8 channels x [8 hi halfs | 8 lo halfs]; chunk c = 2*pl + hf of lane
+                    // half `hi` is group 2*hf + hi of plane pl  ->  one 32-byte read per chunk
+                    const half_t* base = reinterpret_cast<const half_t*>(a.planes) + 2 * ((size_t)bs[t] * R2 * CD) + 16 * hi;
+                    const int off[3] = {iz * R + ix, iy * R + ix, iz * R + iy};   // (H,W): xz->(z,x) xy->(y,x) yz->(z,y)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                        for (int hf = 0; hf < 2; ++hf) {
+                            const half_t* q = base + 2 * (pl * plane_stride + (size_t)off[pl] * CD) + 32 * hf;
+                            cfh[t][2 * pl + hf] = *reinterpret_cast<const half8*>(q);
+                            cfl[t][2 * pl + hf] = *reinterpret_cast<const half8*>(q + 8);
+                        }
+                } else {
+                    pxs[t] = a.p[3 * g + 0]; pys[t] = a.p[3 * g + 1]; pzs[t] = a.p[3 * g + 2];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                // aux chunk: [p_hi(3), 1, p_lo(3), 1] on hi=0 lanes, [p_hi(3), 0...] on hi=1 lanes (exact by itself)
+                const float px = pxs[t], py = pys[t], pz = pzs[t];
+                half_t xh = (half_t)px, yh = (half_t)py, zh = (half_t)pz;
+                half8 av = {xh, yh, zh, (half_t)0, (half_t)0, (half_t)0, (half_t)0, (half_t)0};
+                if (hi == 0) {
+                    av[3] = (half_t)1.0f;
+                    av[4] = (half_t)(px - (float)xh); av[5] = (half_t)(py - (float)yh);
+                    av[6] = (half_t)(pz - (float)zh); av[7] = (half_t)1.0f;
+                }
+                ax[t] = av;
+            }
+            if constexpr (!LATTICE) {
+                // ---------------- generic gather on fp32 planes: per (tile, plane, channel half) the lane's 8 channels of the
+                // 4 bilinear taps (8 x 16 B), interpolated in fp32 in aten's tap order, then split.  Software pipeline of
+                // depth 3 groups (24 loads in flight per lane).
+                const float* planes = reinterpret_cast<const float*>(a.planes);
+                Bilin bl[T][3];
+                const float* pbase[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const float nx = norm_coord(pxs[t]), ny = norm_coord(pys[t]), nz = norm_coord(pzs[t]);
+                    bl[t][0] = bilin_setup(nx, nz);      // xz: (u,v)=(x,z)  xy: (x,y)  yz: (y,z)      common.py:246-251
+                    bl[t][1] = bilin_setup(nx, ny);
+                    bl[t][2] = bilin_setup(ny, nz);
+                    pbase[t] = planes + (size_t)bs[t] * RES * RES * CD + 8 * hi;
+                }
+                constexpr int NG = T * 6, DEPTH = 3;
+                float4 raw[NG][4][2];
+                auto issue = [&](int k) {
+                    const int t = k / 6, pl = (k % 6) / 2, hf = k % 2;
+                    const float* base = pbase[t] + pl * plane_stride + 16 * hf;
+                    const int o[4] = {bl[t][pl].o00, bl[t][pl].o01, bl[t][pl].o10, bl[t][pl].o11};
+#pragma unroll
+                    for (int tp = 0; tp < 4; ++tp) {
+                        raw[k][tp][0] = *reinterpret_cast<const float4*>(base + (size_t)o[tp] * CD);
+                        raw[k][tp][1] = *reinterpret_cast<const float4*>(base + (size_t)o[tp] * CD + 4);
+                    }
+                };
+#pragma unroll
+                for (int k = 0; k < DEPTH; ++k) issue(k);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < NG; ++k) {
+                    const int t = k / 6, pl = (k % 6) / 2;
+                    const Bilin& B4 = bl[t][pl];
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const float4 v00 = raw[k][0][q], v01 = raw[k][1][q], v10 = raw[k][2][q], v11 = raw[k][3][q];
+                        v[4 * q + 0] = fmaf(v11.x, B4.w11, fmaf(v10.x, B4.w10, fmaf(v01.x, B4.w01, v00.x * B4.w00)));
+                        v[4 * q + 1] = fmaf(v11.y, B4.w11, fmaf(v10.y, B4.w10, fmaf(v01.y, B4.w01, v00.y * B4.w00)));
+                        v[4 * q + 2] = fmaf(v11.z, B4.w11, fmaf(v10.z, B4.w10, fmaf(v01.z, B4.w01, v00.z * B4.w00)));
+                        v[4 * q + 3] = fmaf(v11.w, B4.w11, fmaf(v10.w, B4.w10, fmaf(v01.w, B4.w01, v00.w * B4.w00)));
+                    }
+                    split8(v, cfh[t][k % 6], cfl[t][k % 6]);
+                    if (k + DEPTH < NG) issue(k + DEPTH);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        if (iter == 0) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): my share of the weight image has landed
+            __syncthreads();                                  // everyone's share (all waves run iteration 0)
+        }
+        if (!has) break;
+        // ---------------- the chain: fragment indices per block b: fc_c 21b + 2c (+1 = lo), aux 21b + 12,
+        // fc_0 21b + 13 + 2c, fc_1 21b + 17 + 2c; tail aux 105, fc_out 106 + 2c
+        f32x16 net[T], hh[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) net[t][r] = 0.f;
+        auto fc_c = [&](int blk) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const half8 Ah = W[(DEC16S_BLK * blk + 2 * c) * 64 + lane], Al = W[(DEC16S_BLK * blk + 2 * c + 1) * 64 + lane];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    net[t] = mfma16(Al, cfh[t][c], net[t]);
+                    net[t] = mfma16(Ah, cfl[t][c], net[t]);
+                    net[t] = mfma16(Ah, cfh[t][c], net[t]);
+                }
+            }
+            const half8 A = W[(DEC16S_BLK * blk + 12) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < T; ++t) net[t] = mfma16(A, ax[t], net[t]);
+        };
+        auto ctab_regs = [&](int row) {
+            f32x16 c0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(ctab + row * 32 + 8 * q + 4 * hi);
+                c0[4 * q + 0] = v.x; c0[4 * q + 1] = v.y; c0[4 * q + 2] = v.z; c0[4 * q + 3] = v.w;
+            }
+            return c0;
+        };
+        // dst[t] += Wpair(frag0 + 2c) * split(relu(src[t]))
+        auto dense = [&](int frag0, const f32x16 (&src)[T], f32x16 (&dst)[T]) {
+            half8 xh[T][2], xl[T][2];
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) split_relu8(src[t], c, xh[t][c], xl[t][c]);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const half8 Ah = W[(frag0 + 2 * c) * 64 + lane], Al = W[(frag0 + 2 * c + 1) * 64 + lane];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    dst[t] = mfma16(Al, xh[t][c], dst[t]);
+                    dst[t] = mfma16(Ah, xl[t][c], dst[t]);
+                    dst[t] = mfma16(Ah, xh[t][c], dst[t]);
+                }
+            }
+        };
+        fc_c(0);
+#pragma unroll
+        for (int blk = 0; blk < NBLK; ++blk) {
+            const f32x16 c0 = ctab_regs(blk);
+#pragma unroll
+            for (int t = 0; t < T; ++t) hh[t] = c0;
+            dense(DEC16S_BLK * blk + 13, net, hh);            // hh = fc_0(relu(net)) + b0
+            // every term of the residual stream is an accumulation, so the next block's fc_c (+ folded biases) is issued
+            // here, where it covers the split of hh
+            if (blk + 1 < NBLK) fc_c(blk + 1);
+            else {
+                const half8 A = W[(DEC16S_BLK * NBLK) * 64 + lane];       // tail aux: fc_1 bias of the last block
+#pragma unroll
+                for (int t = 0; t < T; ++t) net[t] = mfma16(A, ax[t], net[t]);
+            }
+            dense(DEC16S_BLK * blk + 17, hh, net);            // net += fc_1(relu(hh))
+        }
+        {
+            const f32x16 c0 = ctab_regs(NBLK);
+            f32x16 o[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) o[t] = c0;
+            dense(DEC16S_BLK * NBLK + 1, net, o);             // fc_out(relu(net))
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (hi == 0 && valid[t]) store_head(a, hsel, gidx[t], o[t][0], o[t][1], o[t][2], o[t][3]);
+        }
+    }
+}
+
 // =============================== exact fp32 MFMA path ==============================================
 // Same chain on v_mfma_f32_32x32x2_f32 (bitwise an fp32 fma chain).  B operand of MFMA s of a hidden
 // layer is simply relu(D[s]) of the previous layer: no conversion, no data movement.
@@ -566,6 +780,39 @@ __global__ void lattice_resample_kernel(const TP* __restrict__ planes, const flo
     }
 }
 
+
+// f16x3 variant: fp32 planes in, interpolated in fp32, written as split pixels: 4 groups of 8 channels x
+// [8 hi halfs | 8 lo halfs] (128 B per pixel, the same bytes as fp32) -- the decoder's B operands, ready-made.
+__global__ void lattice_resample_split_kernel(const float* __restrict__ planes, const float* __restrict__ lin,
+                                              half_t* __restrict__ out, int B, int R) {
+    const long long total = 3LL * B * R * R * 4;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cg = (int)(i & 3);
+    const long long pix = i >> 2;
+    const int iu = (int)(pix % R), iv = (int)((pix / R) % R);
+    const long long img = pix / ((long long)R * R);
+    const Bilin bl = bilin_setup(norm_coord(lin[iu]), norm_coord(lin[iv]));
+    const float* src = planes + (size_t)img * RES * RES * CD + 8 * cg;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float4 v00 = *reinterpret_cast<const float4*>(src + (size_t)bl.o00 * CD + 4 * q);
+        const float4 v01 = *reinterpret_cast<const float4*>(src + (size_t)bl.o01 * CD + 4 * q);
+        const float4 v10 = *reinterpret_cast<const float4*>(src + (size_t)bl.o10 * CD + 4 * q);
+        const float4 v11 = *reinterpret_cast<const float4*>(src + (size_t)bl.o11 * CD + 4 * q);
+        v[4 * q + 0] = fmaf(v11.x, bl.w11, fmaf(v10.x, bl.w10, fmaf(v01.x, bl.w01, v00.x * bl.w00)));
+        v[4 * q + 1] = fmaf(v11.y, bl.w11, fmaf(v10.y, bl.w10, fmaf(v01.y, bl.w01, v00.y * bl.w00)));
+        v[4 * q + 2] = fmaf(v11.z, bl.w11, fmaf(v10.z, bl.w10, fmaf(v01.z, bl.w01, v00.z * bl.w00)));
+        v[4 * q + 3] = fmaf(v11.w, bl.w11, fmaf(v10.w, bl.w10, fmaf(v01.w, bl.w01, v00.w * bl.w00)));
+    }
+    half8 h, l;
+    split8(v, h, l);
+    half_t* dst = out + (size_t)pix * 2 * CD + 16 * cg;
+    *reinterpret_cast<half8*>(dst) = h;
+    *reinterpret_cast<half8*>(dst + 8) = l;
+}
+
 // ------------------------------- launchers ----------------------------------------------------------
 constexpr size_t DEC32_LDS = DEC32_BYTES + 4 * 32 * 96 * sizeof(float);     // weight image + the gather's per-wave stage
 static_assert(DEC32_LDS <= 160 * 1024, "LDS budget of the fp32 decoder");
@@ -580,7 +827,17 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
         a.mR = (unsigned)((0x100000000ULL + a.R - 1) / a.R);
         a.mR2 = (unsigned)((0x100000000ULL + (unsigned long long)a.R * a.R - 1) / ((unsigned long long)a.R * a.R));
     }
-    if (precision == 1 && lat) {
+    if (precision == 2) {
+        // f16x3 split: head-resident workgroups, grid = slots x nheads <= 256 (one per CU)
+        constexpr int T = 2, NW = 8;
+        int slots = (int)((tiles + NW * T - 1) / (NW * T));
+        if (slots > 256 / a.nheads) slots = 256 / a.nheads;
+        a.nbatch = slots;
+        auto kern = lat ? decoder_f16s_kernel<T, true, NW> : decoder_f16s_kernel<T, false, NW>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)DEC16S_BYTES);
+        hipLaunchKernelGGL(kern, dim3(slots * a.nheads), dim3(NW * 64), DEC16S_BYTES, s, a);
+    } else if (precision == 1 && lat) {
         // lattice variant: 155 VGPRs -> 12 waves (3 per SIMD, phases 0/1/2 over the heads)
         constexpr int T = 2, NW = 12;
         a.nbatch = (int)((tiles + NW * T - 1) / (NW * T));
@@ -628,7 +885,10 @@ int launch_lattice_resample(const void* planes, const float* lin, void* out, int
     const long long total = 3LL * B * R * R * 4;
     if (total <= 0) return 0;
     const unsigned grid = (unsigned)((total + 255) / 256);
-    if (precision == 1)
+    if (precision == 2)
+        hipLaunchKernelGGL(lattice_resample_split_kernel, dim3(grid), dim3(256), 0, s,
+                           reinterpret_cast<const float*>(planes), lin, reinterpret_cast<half_t*>(out), B, R);
+    else if (precision == 1)
         hipLaunchKernelGGL(lattice_resample_kernel<half_t>, dim3(grid), dim3(256), 0, s,
                            reinterpret_cast<const half_t*>(planes), lin, reinterpret_cast<half_t*>(out), B, R);
     else

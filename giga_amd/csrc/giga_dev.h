@@ -57,6 +57,27 @@ __device__ __forceinline__ half8 pack_relu8(const f32x16& d, int c) {
     return __builtin_elementwise_max(x, z);
 }
 
+// f16x3 split of relu(D registers 8c..8c+7): hi = f16(x) (round to nearest), lo = f16(x - hi); hi + lo carries x to
+// ~2^-22 relative.  The subtraction is written as an fma on the widened half so that it selects v_fma_mix_f32 (one
+// instruction, exact: x - hi has at most 13 significant bits).
+__device__ __forceinline__ void split_relu8(const f32x16& d, int c, half8& hi, half8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = relu(d[8 * c + j]);
+        const half_t h = (half_t)x;
+        hi[j] = h;
+        lo[j] = (half_t)__builtin_fmaf((float)h, -1.0f, x);
+    }
+}
+__device__ __forceinline__ void split8(const float (&x)[8], half8& hi, half8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const half_t h = (half_t)x[j];
+        hi[j] = h;
+        lo[j] = (half_t)__builtin_fmaf((float)h, -1.0f, x[j]);
+    }
+}
+
 // ---- coordinates: reference ConvONets/common.py:238-261 with padding = 0 -------------------------
 // xy = p / (1 + 0 + 10e-6) + 0.5 ; >= 1 -> 1 - 10e-6 ; < 0 -> 0     (fp32, true division)
 __device__ __forceinline__ float norm_coord(float p) {

@@ -106,6 +106,13 @@ constexpr int DEC16_FRAGS = NBLK * (7 + 2 + 2) + 1 + 2;                   // 58
 constexpr size_t DEC_CTAB_BYTES = (NBLK + 1) * CD * sizeof(float);        // 768
 constexpr size_t DEC16_BYTES = (DEC16_FRAGS + 1) * FRAG;                  // 59 KiB: 58 fragments + the C table in a
                                                                           // 59th 1 KiB chunk (whole image = 59 LDS-DMA wave-chunks)
+// precision f16x3 ("split": every operand is a pair hi = f16(v), lo = f16(v - hi); products hi*hi + hi*lo + lo*hi with fp32
+// accumulation, i.e. ~22-bit operands at 3x the f16 MFMA count).  Fragments in order of use, [hi, lo] pairs:
+//   for blk 0..4: 6 x [hi, lo] feature frags, 1 aux frag (already exact: it carries its own hi/lo slots),
+//                 2 x [hi, lo] fc_0, 2 x [hi, lo] fc_1;   tail: 1 aux frag, 2 x [hi, lo] fc_out;   then the C table
+constexpr int DEC16S_BLK = 12 + 1 + 4 + 4;                                // 21 fragments per block
+constexpr int DEC16S_FRAGS = NBLK * DEC16S_BLK + 1 + 4;                   // 110
+constexpr size_t DEC16S_BYTES = (DEC16S_FRAGS + 1) * FRAG;                // 111 KiB, resident in LDS per workgroup
 // precision f32: per block 12 feature frags (48 MFMAs) + 1 aux frag (2 MFMAs used) + 4 + 4; tail 1 + 4
 constexpr int DEC32_FRAGS = NBLK * (12 + 1 + 4 + 4) + 1 + 4;              // 110
 constexpr size_t DEC32_BYTES = (DEC32_FRAGS + 1) * FRAG;                  // 111 KiB: fragments + C table chunk (LDS-DMA image)
@@ -117,6 +124,7 @@ struct PackOff {
     ConvPackOff conv[NCONV];
     size_t dec16[NHEADS], dec32[NHEADS];
     size_t dec16f[NHEADS], dec32f[NHEADS];   // the same heads with the encoder's final 1x1 conv folded into fc_c (see giga_pack.cpp)
+    size_t dec16s[NHEADS], dec16sf[NHEADS];  // f16x3 split images (plain, folded)
     size_t total;
 };
 
@@ -144,6 +152,10 @@ inline PackOff pack_offsets() {
     for (int h = 0; h < NHEADS; ++h) {
         o.dec16f[h] = at; at += align_up(DEC16_BYTES, 256);
         o.dec32f[h] = at; at += align_up(DEC32_BYTES, 256);
+    }
+    for (int h = 0; h < NHEADS; ++h) {       // appended: the offsets above are unchanged from ABI version 1 blobs
+        o.dec16s[h] = at; at += align_up(DEC16S_BYTES, 256);
+        o.dec16sf[h] = at; at += align_up(DEC16S_BYTES, 256);
     }
     o.total = at;
     return o;

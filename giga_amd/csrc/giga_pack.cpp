@@ -74,6 +74,62 @@ static void pack_head16(const float* P, const HeadParamOff& o, int out_dim, uint
     for (int n = 0; n < 32; ++n) ctab[NBLK * 32 + n] = n < out_dim ? P[o.out_b + n] : 0.f;
 }
 
+// f16x3 split image (giga_layout.h DEC16S_*): every weight w is stored as the pair hi = f16(w), lo = f16(w - hi) in two
+// consecutive fragments with the k-slot maps of pack_head16.  lo is subnormal in f16 for |w| < 2^-3; the f16 MFMA keeps
+// subnormal inputs (profiles/r02a_f16_mfma_denormals.txt), so hi + lo carries w to ~2^-22 relative (2^-25 absolute).
+static void pack_head16s(const float* P, const HeadParamOff& o, int out_dim, uint8_t* dst) {
+    std::memset(dst, 0, DEC16S_BYTES);
+    half_t* f = reinterpret_cast<half_t*>(dst);
+    auto frag = [&](int idx, int lane, int j) -> half_t& { return f[(size_t)idx * 512 + lane * 8 + j]; };
+    auto put = [&](int idx, int lane, int j, float w) {     // pair (idx, idx + 1)
+        const half_t h = f2h(w);
+        frag(idx, lane, j) = h;
+        frag(idx + 1, lane, j) = f2h(w - (float)h);
+    };
+    auto aux = [&](int idx, const float* wp, const float* bias_a, const float* bias_b) {   // as pack_head16
+        for (int n = 0; n < 32; ++n) {
+            float b = (bias_a ? bias_a[n] : 0.f) + (bias_b ? bias_b[n] : 0.f);
+            half_t bh = f2h(b), bl = f2h(b - (float)bh);
+            for (int k = 0; k < 3; ++k) {
+                float w = wp ? wp[n * 3 + k] : 0.f;
+                half_t wh = f2h(w), wl = f2h(w - (float)wh);
+                frag(idx, n, k) = wh;
+                frag(idx, n, 4 + k) = wh;
+                frag(idx, 32 + n, k) = wl;
+            }
+            frag(idx, n, 3) = bh;
+            frag(idx, n, 7) = bl;
+        }
+    };
+    auto dense32 = [&](int idx0, const float* W, int rows) {   // (rows,32) weight: 2 chunks x [hi, lo]
+        for (int c = 0; c < 2; ++c)
+            for (int lane = 0; lane < 64; ++lane) {
+                int n = lane & 31, hi = lane >> 5;
+                for (int j = 0; j < 8; ++j) put(idx0 + 2 * c, lane, j, n < rows ? W[n * 32 + hid16(c, hi, j)] : 0.f);
+            }
+    };
+    int idx = 0;
+    for (int b = 0; b < NBLK; ++b) {
+        const float* Wc = P + o.fc_c_w[b];
+        for (int c = 0; c < 6; ++c, idx += 2)
+            for (int lane = 0; lane < 64; ++lane) {
+                int n = lane & 31, hi = lane >> 5;
+                for (int j = 0; j < 8; ++j) put(idx, lane, j, Wc[n * 96 + feat16(c, hi, j)]);
+            }
+        if (b == 0) aux(idx, P + o.fc_p_w, P + o.fc_p_b, P + o.fc_c_b[0]);
+        else aux(idx, nullptr, P + o.fc_c_b[b], P + o.fc1_b[b - 1]);
+        ++idx;
+        dense32(idx, P + o.fc0_w[b], 32); idx += 4;
+        dense32(idx, P + o.fc1_w[b], 32); idx += 4;
+    }
+    aux(idx, nullptr, P + o.fc1_b[NBLK - 1], nullptr); ++idx;
+    dense32(idx, P + o.out_w, out_dim); idx += 4;
+    float* ctab = reinterpret_cast<float*>(dst + (size_t)DEC16S_FRAGS * FRAG);
+    for (int b = 0; b < NBLK; ++b)
+        for (int n = 0; n < 32; ++n) ctab[b * 32 + n] = P[o.fc0_b[b] + n];
+    for (int n = 0; n < 32; ++n) ctab[NBLK * 32 + n] = n < out_dim ? P[o.out_b + n] : 0.f;
+}
+
 static void pack_head32(const float* P, const HeadParamOff& o, int out_dim, uint8_t* dst) {
     std::memset(dst, 0, DEC32_BYTES);
     float* f = reinterpret_cast<float*>(dst);
@@ -191,6 +247,7 @@ int pack_weights_host(const float* P, size_t n_params, int head_present, uint8_t
         if (!(head_present >> h & 1)) continue;
         pack_head16(P, po.head[h], HEAD_OUT[h], blob + ko.dec16[h]);
         pack_head32(P, po.head[h], HEAD_OUT[h], blob + ko.dec32[h]);
+        pack_head16s(P, po.head[h], HEAD_OUT[h], blob + ko.dec16s[h]);
     }
     // Folded variants.  The encoder ends with conv_final, a 1x1 convolution WITHOUT activation (unet.py:238), and the
     // decoder's first use of the planes is linear too: bilinear sampling (decoder.py:117-122) followed by fc_c (:169).
@@ -221,6 +278,7 @@ int pack_weights_host(const float* P, size_t n_params, int head_present, uint8_t
             }
             pack_head16(Pf.data(), ho, HEAD_OUT[h], blob + ko.dec16f[h]);
             pack_head32(Pf.data(), ho, HEAD_OUT[h], blob + ko.dec32f[h]);
+            pack_head16s(Pf.data(), ho, HEAD_OUT[h], blob + ko.dec16sf[h]);
         }
     }
     return 0;

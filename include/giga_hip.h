@@ -14,7 +14,11 @@
  *   - return value 0 = success, negative = error (giga_strerror); nothing throws across the ABI;
  *   - `precision`: 0 = exact fp32 (v_mfma_f32_32x32x2_f32, bitwise fp32 fma chains),
  *                  1 = f16 operands / fp32 accumulate (v_mfma_f32_32x32x16_f16);
- *   - "NHWC planes": one buffer [3 (xz,xy,yz)][B][40 (H)][40 (W)][32 (C)] of float (precision 0) or
+ *                  2 = f16x3 split operands / fp32 accumulate: every operand is the pair hi = f16(v), lo = f16(v - hi)
+ *                      and every product W_lo*x_hi + W_hi*x_lo + W_hi*x_hi on the f16 MFMA (~22-bit operands, results
+ *                      within 1e-5 of the fp32 path).  Decoder entry points only change arithmetic; planes are fp32
+ *                      (as for precision 0) and the encoder entry points run their fp32 kernels for this value;
+ *   - "NHWC planes": one buffer [3 (xz,xy,yz)][B][40 (H)][40 (W)][32 (C)] of float (precision 0 and 2) or
  *     _Float16 (precision 1).  H/W follow the reference's plane indexing (ConvONets/common.py:246-251,
  *     303-318): xz -> (H=z, W=x), xy -> (H=y, W=x), yz -> (H=z, W=y).
  */

@@ -35,7 +35,11 @@ def _blob_and_offsets(sd):
     for _ in range(4):
         dec16f.append(at); at += up(59 * 1024)
         dec32f.append(at); at += up(111 * 1024)
+    dec16s = []                                        # f16x3 split images (plain, folded), appended
+    for _ in range(4):
+        dec16s.append(at); at += 2 * up(111 * 1024)
     assert at == blob.size
+    _blob_and_offsets.dec16s = dec16s
     return blob, dec16, dec32
 
 
@@ -138,6 +142,61 @@ def test_decoder_f32_fragment_chain(sd7):
                 o = one(W[k], j, np.maximum(net[:, 4 * q + j], 0), o)
             k += 1
         assert k == 110
+        got = o[:32, :OUT_DIM[name]]
+        ref = O.decoder_mlp(sd7, name, torch.from_numpy(p), torch.from_numpy(c)).numpy().reshape(32, -1)
+        err = np.abs(got - ref).max()
+        assert err < 2e-5, (name, err)
+
+
+def test_decoder_f16x3_split_fragment_chain(sd7):
+    """The split image [hi, lo] pairs + the kernel's product order W_lo*x_hi + W_hi*x_lo + W_hi*x_hi
+    (decoder_f16s_kernel) reproduce the fp32 oracle to fp32-rounding level."""
+    blob, _, _ = _blob_and_offsets(sd7)
+    dec16s = _blob_and_offsets.dec16s
+    c, p = _inputs(11)
+
+    def split(x):
+        h = x.astype(np.float16)
+        return h, (x - h.astype(np.float32)).astype(np.float16)
+
+    for h, name in enumerate(HEADS):
+        raw = blob[dec16s[h]:dec16s[h] + 110 * 1024 + 768]
+        W = raw[:110 * 1024].view(np.float16).reshape(110, 64, 8)
+        ctab = raw[110 * 1024:].view(np.float32)
+        cf = np.zeros((6, 64, 8), np.float32)
+        for ch in range(6):
+            for hi in range(2):
+                for j in range(8):
+                    cf[ch, hi * 32:(hi + 1) * 32, j] = c[0, :, (ch // 2) * 32 + (ch % 2) * 16 + 8 * hi + j]
+        cfh, cfl = split(cf)
+        ph = p[0].astype(np.float16)
+        plo = (p[0] - ph.astype(np.float32)).astype(np.float16)
+        ax = np.zeros((64, 8), np.float16)
+        ax[:32, 0:3] = ph; ax[:32, 3] = 1; ax[:32, 4:7] = plo; ax[:32, 7] = 1
+        ax[32:, 0:3] = ph
+
+        def mm3(f, xh, xl, acc):
+            acc = mfma(W[f + 1], xh, acc)
+            acc = mfma(W[f], xl, acc)
+            return mfma(W[f], xh, acc)
+
+        def dense(f0, src, dst):
+            for ch in range(2):
+                xh, xl = split(np.maximum(src[:, 8 * ch:8 * ch + 8], 0))
+                dst = mm3(f0 + 2 * ch, xh, xl, dst)
+            return dst
+
+        def fc_c(blk, net):
+            for ch in range(6):
+                net = mm3(21 * blk + 2 * ch, cfh[ch], cfl[ch], net)
+            return mfma(W[21 * blk + 12], ax, net)
+
+        net = fc_c(0, np.zeros((64, 16), np.float32))
+        for blk in range(5):
+            hh = dense(21 * blk + 13, net, _ctab_regs(ctab, blk))
+            net = fc_c(blk + 1, net) if blk < 4 else mfma(W[105], ax, net)
+            net = dense(21 * blk + 17, hh, net)
+        o = dense(106, net, _ctab_regs(ctab, 5))
         got = o[:32, :OUT_DIM[name]]
         ref = O.decoder_mlp(sd7, name, torch.from_numpy(p), torch.from_numpy(c)).numpy().reshape(32, -1)
         err = np.abs(got - ref).max()
