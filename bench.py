@@ -2,26 +2,33 @@
 """Benchmark of the GIGA dense inference path on MI355X (driver contract in the task brief).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With N > 1 and no launcher environment the script starts its own N ranks (`python -m torch.distributed.run`, one per GPU,
+rendezvous on 127.0.0.1) and rank 0 prints the JSON line; under an external `torch.distributed.run` it uses the ranks it
+is given.  WORLD_SIZE must equal --gpus.
 
 A "step" is one forward pass of BASELINE.json configs[1] on every rank:
     32 synthetic 40^3 TSDF scenes per GPU, the literal `train_giga` call shape
     (1 grasp query point for the three grasp heads + 2048 occupancy queries per scene),
     encoder + decoders in exact fp32 (fp32 MFMA), inputs resident in HBM, outputs left in HBM.
-Scenes are independent, so ranks are pure replicas on different scenes (weak scaling); the only
-collectives are the MAX-reduce of the elapsed times and one all_gather of per-rank counters at the
-end (RCCL over xGMI; the group is created after the timed region, whose two barriers run over gloo).
+Scenes are independent, so ranks are pure replicas on different scenes (scene i -> rank i mod N, weak scaling) and the
+timed region has no collective; its two barriers run over gloo.  After it an RCCL group (backend "nccl" over xGMI) does the
+MAX-reduce of the elapsed times, one all_gather of per-rank counters, the all_gather of the real head outputs of all
+N x 32 scenes (BASELINE config c3) and, at N > 1, the data-parallel training step of config c5.
 
 One JSON line is printed by rank 0; besides the contract keys it carries
-  roofline      - the dominant kernel of the timed workload, timed live with HIP events on the
-                  launch stream inside the timed steps
-  cpu_baseline  - the CPU oracle (a port of the reference's PyTorch path) on the host cores
-  extra         - config c4 (64 000 grasp queries/scene, f16-MFMA fused decoder) numbers
+  roofline      - the headline kernel of the timed workload, timed live with HIP events on the launch stream inside the
+                  timed steps, plus `stages`: time, algorithmic FLOPs and fraction of the fp32-MFMA peak of EVERY kernel
+  cpu_baseline  - the CPU oracle (a port of the reference's PyTorch path) on the host cores (N = 1 only)
+  extra         - c4 (64 000 grasp queries/scene) with the f16 and the f16x3 split decoders, c2 (ii), the c2 workload in
+                  the fp16x3 mode, the c5-shaped training step, and at N > 1 the c3 gather and the data-parallel step
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,6 +47,7 @@ MEASURED_F16_MFMA_TFLOPS = 2350.6     # v_mfma_f32_32x32x16_f16 (94 % of spec: t
 FLOP_ENCODER = 1_132_953_600          # SURVEY.md 8d / BASELINE.md section 4
 FLOP_HEAD = {"qual": 51_456, "rot": 51_648, "width": 51_456, "tsdf": 51_456}
 FLOP_GRASP3 = 154_560
+SPLIT_MFMA_PER_PLAIN = 162.0 / 58.0   # f16x3: MFMA instructions per tile and head relative to the plain f16 chain
 
 # U-Net layer table (kind, cin, cout, H, W): algorithmic FLOPs per image = 2*H*W*taps*cin*cout
 _CONV = [(9, 32, 32, 40), (9, 32, 32, 40), (9, 32, 64, 20), (9, 64, 64, 20), (9, 64, 128, 10), (9, 128, 128, 10),
@@ -49,6 +57,7 @@ STAGE_NAMES = ["convin_project", "plane_finalize"] + [
     "unet.down0.conv1", "unet.down0.conv2+pool", "unet.down1.conv1", "unet.down1.conv2+pool", "unet.down2.conv1",
     "unet.down2.conv2", "unet.up0.upconv", "unet.up0.conv1", "unet.up0.conv2", "unet.up1.upconv",
     "unet.up1.conv1", "unet.up1.conv2", "unet.conv_final"]
+HEADLINE_STAGE = 0                      # convin_project: the kernel VERDICT r01 names; see pick_headline()
 
 
 def stage_flops(stage, B):
@@ -61,6 +70,31 @@ def stage_flops(stage, B):
     return 2 * hw * hw * taps * cin * cout * 3 * B
 
 
+def pick_headline(stage_ms):
+    """Deterministic choice of the roofline kernel: the conv_in + projection kernel unless another stage takes more than
+    1.15x its time (two stages used to sit within 1 us of each other and the argmax flipped between runs)."""
+    top = int(np.argmax(stage_ms))
+    return HEADLINE_STAGE if stage_ms[HEADLINE_STAGE] * 1.15 >= stage_ms[top] else top
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks ourselves and relay rank 0's JSON line."""
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"--gpus {n} but only {have} HIP device(s) are visible")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,34 +103,32 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="scenes per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--dp-train", action="store_true",
-                    help="with --gpus N > 1: also time the data-parallel training step of BASELINE c5 (one RCCL "
-                         "all-reduce of the flat gradient bucket per step) and report it under extra")
     args = ap.parse_args()
 
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if args.gpus > 1 and not launched:
+        spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU, WORLD_SIZE must equal --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (MI355X); no CPU fallback for the timed path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):
-        # launched by torch.distributed.run: one rank per GPU over RCCL (also at world size 1, so that the collective
-        # code path of the multi-GPU runs can be exercised on a single-GPU box)
+    if launched:
+        # one rank per GPU (also at world size 1, so that the whole N > 1 code path runs on a single-GPU box).
+        # Rendezvous and the barriers that bracket the timed region run over gloo (host side, TCP on 127.0.0.1); the
+        # RCCL communicator for the collectives proper is created AFTER the timed region: the hot path has no collective,
+        # and a live RCCL communicator (its streams / hardware queues) was measured to slow the single-GPU step by 2-5 %
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")    # one node by contract; the hostname may not resolve
-        # Rendezvous and the barriers that bracket the timed region run over gloo (host side, TCP on 127.0.0.1); the
-        # RCCL communicator for the collectives proper (MAX of the times, all_gather of the counters, the data-parallel
-        # gradient all-reduce) is created AFTER the timed region: the hot path has no collective, and a live RCCL
-        # communicator (its streams / hardware queues) was measured to slow the single-GPU step by 2-5 %
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    from giga_amd import _capi, networks, synth, weights
+    from giga_amd import _capi, networks, sharding, synth, weights
     from giga_amd.convonet import decode_heads
 
     B, M = args.batch, 2048
@@ -104,22 +136,21 @@ def main():
     net = networks.get_network("giga")
     net.load_state_dict(sd)
     net = net.to(dev).eval().set_precision("fp32")
-    first = rank * B                                     # each rank owns its own scenes
-    x = torch.from_numpy(synth.tsdf_batch(first, B)).to(dev)
-    pos = torch.from_numpy(synth.query_points(first, B, 1, stream=2)).to(dev)
-    pos_occ = torch.from_numpy(synth.query_points(first, B, M, stream=3)).to(dev)
+    mine = sharding.scene_shard(world * B, rank, world)  # scene i -> rank i mod world (giga_amd/sharding.py)
+    x = torch.from_numpy(synth.tsdf_scenes(mine)).to(dev)
+    pos = torch.from_numpy(synth.query_points_for(mine, 1, stream=2)).to(dev)
+    pos_occ = torch.from_numpy(synth.query_points_for(mine, M, stream=3)).to(dev)
     blob = net.packed_blob(dev)
     L = _capi.lib()
 
     def barrier():
-        # drain the device first, so that the barrier collective is enqueued on an idle device (dist.barrier() +
-        # synchronize then cost 27 us); the order made no measurable difference at world size 1
+        # drain the device first, so that the barrier is entered with an idle device on every rank
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    # -------- find the dominant kernel of the workload (untimed pre-pass, every stage probed once) ----
+    # -------- untimed pre-pass: every stage probed, median of seven ---------------------------------------
     ev_a, ev_b = L.giga_event_create(), L.giga_event_create()
     dec_ev = (L.giga_event_create(), L.giga_event_create())
 
@@ -128,68 +159,87 @@ def main():
         with torch.no_grad():
             if dec_probe is None:
                 return net(x, pos, p_tsdf=pos_occ, _probe=probe)
-            nhwc, _ = net.encoder.encode_nhwc(x, blob=blob, precision="fp32")
-            g = decode_heads(nhwc, pos, blob, 7, "fp32", True)
-            t = decode_heads(nhwc, pos_occ, blob, 8, "fp32", False, probe=dec_probe)
+            nhwc, _ = net.encoder.encode_nhwc(x, blob=blob, precision="fp32", fold_final=True)
+            g = decode_heads(nhwc, pos, blob, 7, "fp32", True, probe=dec_probe[0], folded=True)
+            t = decode_heads(nhwc, pos_occ, blob, 8, "fp32", False, probe=dec_probe[1], folded=True)
         return g, t
 
-    for _ in range(2):
+    for _ in range(3):
         step()
     torch.cuda.synchronize()
-    stage_ms = []
     ms = ctypes.c_float()
+
+    def elapsed(a, b):
+        _capi.check(L.giga_event_elapsed_ms(a, b, ctypes.byref(ms)), "event")
+        return ms.value
+
+    stage_ms = []
     for st in range(15):
         reps = []
-        for _ in range(5):                 # median of five: two layers are within a few percent of each other
+        for _ in range(7):
             step(probe=(st, ev_a, ev_b))
-            _capi.check(L.giga_event_elapsed_ms(ev_a, ev_b, ctypes.byref(ms)), "event")
-            reps.append(ms.value)
+            reps.append(elapsed(ev_a, ev_b))
         stage_ms.append(float(np.median(reps)))
-    step(dec_probe=dec_ev)
-    _capi.check(L.giga_event_elapsed_ms(dec_ev[0], dec_ev[1], ctypes.byref(ms)), "event")
-    dec_ms_once = ms.value
-    dom = int(np.argmax(stage_ms))
+    dec2 = (L.giga_event_create(), L.giga_event_create())
+    dg, dt = [], []
+    for _ in range(7):
+        step(dec_probe=(dec_ev, dec2))
+        dg.append(elapsed(*dec_ev)); dt.append(elapsed(*dec2))
+    dec_grasp_ms, dec_occ_ms = float(np.median(dg)), float(np.median(dt))
+    dom = pick_headline(stage_ms)
 
     # -------- timed region ----------------------------------------------------------------------------
     for _ in range(args.warmup):
         step()
     K = args.steps
     evs = [(L.giga_event_create(), L.giga_event_create()) for _ in range(K)]
-    barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]     # per-step durations (torch's current stream
+    barrier()                                                                # is the stream the kernels are launched on)
     t0 = time.perf_counter()
     for i in range(K):
+        marks[i].record()
         step(probe=(dom, evs[i][0], evs[i][1]))
+    marks[K].record()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_s = time.perf_counter() - t0
     dom_ms = []
     for a, b in evs:
-        _capi.check(L.giga_event_elapsed_ms(a, b, ctypes.byref(ms)), "event")
-        dom_ms.append(ms.value)
+        dom_ms.append(elapsed(a, b))
         L.giga_event_destroy(a); L.giga_event_destroy(b)
-    t_elapsed = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(K)]
+    t_elapsed = torch.tensor([elapsed_s], dtype=torch.float64, device=dev)
     rccl = None
+    multi = {}
     if dist is not None:
         rccl = dist.new_group(backend="nccl")                # one rank per GPU over RCCL / xGMI
+        if dist.get_world_size(rccl) != args.gpus:
+            raise SystemExit(f"RCCL group has {dist.get_world_size(rccl)} ranks, expected {args.gpus}")
         dist.all_reduce(t_elapsed, op=dist.ReduceOp.MAX, group=rccl)
         # the north-star's single data-path-free collective: gather per-rank counters
-        counters = torch.tensor([float(B * K), elapsed], dtype=torch.float64, device=dev)
+        counters = torch.tensor([float(B * K), elapsed_s, float(torch.cuda.current_device())], dtype=torch.float64, device=dev)
         gathered = [torch.zeros_like(counters) for _ in range(world)]
         dist.all_gather(gathered, counters, group=rccl)
         total_scenes = sum(float(c[0]) for c in gathered)
+        if len({int(c[2]) for c in gathered}) != world and world > 1:
+            raise SystemExit("two ranks share a GPU")
+        multi["rccl_ranks"] = dist.get_world_size(rccl)
+        multi["per_rank_seconds"] = [float(c[1]) for c in gathered]
     else:
         total_scenes = float(B * K)
     T = float(t_elapsed.item())
     scenes_per_s = total_scenes / T
 
-    # -------- opt-in extra at N > 1 (--dp-train): the data-parallel training step of BASELINE c5 (every rank takes part;
-    # off by default so that the scaling run consists of the data-path-free forward only) ----------
-    dp_train = None
-    if dist is not None and world > 1 and args.dp_train:
+    # -------- N > 1 legs (every rank takes part; outside the timed region) ---------------------------------
+    if dist is not None and not args.no_extra:
+        try:
+            multi["c3_gather"] = bench_c3_gather(net, x, pos, pos_occ, sharding, dist, rccl, rank, world, B, dev)
+        except Exception as e:  # noqa: BLE001
+            multi["c3_gather"] = {"error": f"{type(e).__name__}: {e}"}
         try:
             net.enable_data_parallel(group=rccl)
-            dp_train = bench_train(net, dev, synth, B, M, rank=rank, world=world)
+            multi["c5_train_step_fp32_data_parallel"] = bench_train(net, dev, synth, B, M, rank=rank, world=world, sync=barrier)
         except Exception as e:  # noqa: BLE001
-            dp_train = {"error": f"{type(e).__name__}: {e}"}
+            multi["c5_train_step_fp32_data_parallel"] = {"error": f"{type(e).__name__}: {e}"}
         finally:
             net.enable_data_parallel(enabled=False)
             net.eval().set_precision("fp32")
@@ -203,21 +253,35 @@ def main():
         finish()
         return
 
-    # HBM bytes per launch of the dominant kernel: PMC counters cannot be collected from inside this process,
-    # so they come from the committed rocprofv3 PMC table of the same workload (profiles/r01_traffic_c2.json,
-    # produced by tools/gpu_traffic.sh); null when the table has no entry for this kernel / batch size.
-    traffic = None
-    try:
-        tab = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic_c2.json")))
-        if B == 32 and STAGE_NAMES[dom] in tab["stages"]:
-            traffic = tab["stages"][STAGE_NAMES[dom]]["bytes"]
-    except (OSError, ValueError, KeyError):
-        pass
+    # HBM bytes per launch: PMC counters cannot be collected from inside this process, so they come from the committed
+    # rocprofv3 PMC table of the same workload (tools/gpu_traffic.sh -> profiles/*traffic_c2.json), stamped with the commit
+    # and kernel it was measured on; null when the table has no entry for this kernel / batch size.
+    traffic, traffic_src = None, None
+    for name in ("r02_traffic_c2.json", "r01_traffic_c2.json"):
+        try:
+            tab = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if B == 32 and STAGE_NAMES[dom] in tab["stages"]:
+                traffic = tab["stages"][STAGE_NAMES[dom]]["bytes"]
+                traffic_src = {"table": "profiles/" + name, "commit": tab.get("commit"),
+                               "kernel": tab["stages"][STAGE_NAMES[dom]].get("kernel")}
+                break
+        except (OSError, ValueError, KeyError):
+            pass
     dom_avg_ms = float(np.mean(dom_ms))
     dom_flops = stage_flops(dom, B)
     achieved = dom_flops / (dom_avg_ms * 1e-3) / 1e12
     flop_scene = FLOP_ENCODER + FLOP_GRASP3 * 1 + FLOP_HEAD["tsdf"] * M
     points_per_scene = 1 * 3 + M          # head evaluations per scene
+    step_total = sum(stage_ms) + dec_grasp_ms + dec_occ_ms
+    stages = {}
+    for i, v in enumerate(stage_ms):
+        fl = stage_flops(i, B)
+        stages[STAGE_NAMES[i]] = {"ms": round(v, 4), "gflop": round(fl / 1e9, 3), "share_of_step": round(v / step_total, 3),
+                                  "frac_of_fp32_mfma_peak": round(fl / (v * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 3) if fl and v > 0 else None}
+    for nm, v, fl in (("decoder.grasp_heads(1 query)", dec_grasp_ms, B * FLOP_GRASP3),
+                      ("decoder.occupancy(2048 queries)", dec_occ_ms, B * M * FLOP_HEAD["tsdf"])):
+        stages[nm] = {"ms": round(v, 4), "gflop": round(fl / 1e9, 3), "share_of_step": round(v / step_total, 3),
+                      "frac_of_fp32_mfma_peak": round(fl / (v * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 3)}
     out = {
         "metric": "scenes/sec",
         "value": scenes_per_s,
@@ -234,53 +298,40 @@ def main():
         "config": {"workload": "c2: batch=32/GPU synthetic 40^3 TSDF, encoder + 3 grasp heads @1 query + "
                                "occupancy head @2048 queries/scene (literal train_giga call), fp32 MFMA",
                    "scenes_per_gpu_per_step": B, "occ_points_per_scene": M, "grasp_points_per_scene": 1,
-                   "parallelism": f"scene-sharded x{world} (replicas, one all_gather of counters)"},
+                   "parallelism": f"scene-sharded x{world} (scene i -> rank i mod {world}; replicas, no data-path collective)"},
+        "step_ms_median": float(np.median(step_ms)), "step_ms_max": float(np.max(step_ms)),
         "query_points_per_sec": scenes_per_s * points_per_scene,
         "algorithmic_tflops": scenes_per_s * flop_scene / 1e12,
         "roofline": {
             "kernel": STAGE_NAMES[dom], "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic,
+            "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
             "frac_of_measured_peak": achieved / MEASURED_F32_MATRIX_TFLOPS,
-            "avg_launch_ms": dom_avg_ms, "flops_per_launch": dom_flops,
-            "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) peak; events on the launch stream inside the timed steps",
+            "avg_launch_ms": dom_avg_ms, "median_launch_ms": float(np.median(dom_ms)), "flops_per_launch": dom_flops,
+            "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) peak; events on the launch stream inside the timed steps; "
+                    "kernel = conv_in + projection unless another stage exceeds 1.15x its time (pick_headline)",
+            "stages": stages,
         },
-        "stage_ms": {STAGE_NAMES[i]: round(v, 4) for i, v in enumerate(stage_ms)},
         "stage_note": "unet.conv_final is not launched in this call: the 1x1 convolution is folded into the heads' fc_c weights "
                       "(GIGA_FOLD_FINAL); its entry is the empty event bracket",
-        "decoder_occ_ms": round(dec_ms_once, 4),
     }
-
-    if dp_train is not None:
-        out["extra"] = {"c5_train_step_fp32_data_parallel": dp_train}
-    # -------- extra: c4 (64 000 grasp queries per scene, f16 MFMA fused decoder); single-GPU runs only ----
-    single = world == 1
+    extra = dict(multi)
+    single = world == 1 and dist is None
     if single and not args.no_extra:
-        try:
-            out["extra"] = {"c4": bench_c4(net, sd, dev, L, _capi, synth, decode_heads)}
-            # BASELINE c4 is a sweep over the scenes per GPU; the decoder's MFMA fraction per batch size
-            sweep = []
-            for bc in (1, 8, 128):
-                r = bench_c4(net, sd, dev, L, _capi, synth, decode_heads, Bc=bc, steps=10)
-                sweep.append({"scenes": bc, "scenes_per_sec": r["scenes_per_sec"], "ms_per_step": r["ms_per_step"],
-                              "decoder_ms": r["roofline"]["avg_launch_ms"], "decoder_tflops": r["roofline"]["achieved"],
-                              "decoder_frac_of_f16_mfma_peak": r["roofline"]["frac"]})
-            out["extra"]["c4_sweep"] = sweep
-        except Exception as e:  # noqa: BLE001
-            out["extra"] = {"c4_error": f"{type(e).__name__}: {e}"}
-
-    # -------- extra: c2 (ii), N = M = 2048 queries per scene on all four heads -------------------
-    if single and not args.no_extra:
-        try:
-            out["extra"]["c2_ii"] = bench_c2_ii(net, dev, synth, B)
-        except Exception as e:  # noqa: BLE001
-            out["extra"]["c2_ii_error"] = f"{type(e).__name__}: {e}"
-
-    # -------- extra: c5-shaped training step (fp32 here; BASELINE c5 names bf16 -- see DESIGN.md) -----------
-    if single and not args.no_extra:
-        try:
-            out["extra"]["c5_train_step_fp32"] = bench_train(net, dev, synth, B, M)
-        except Exception as e:  # noqa: BLE001
-            out["extra"]["c5_error"] = f"{type(e).__name__}: {e}"
+        legs = (("c4", lambda: bench_c4_all(net, dev, L, _capi, synth, decode_heads)),
+                ("c2_ii", lambda: bench_c2_ii(net, dev, synth, B)),
+                ("c2_fp16x3", lambda: bench_c2_mode(net, x, pos, pos_occ, "fp16x3")),
+                ("c5_train_step_fp32", lambda: bench_train(net, dev, synth, B, M)))
+        for key, fn in legs:
+            try:
+                r = fn()
+                if key == "c4":
+                    extra.update(r)
+                else:
+                    extra[key] = r
+            except Exception as e:  # noqa: BLE001
+                extra[key + "_error"] = f"{type(e).__name__}: {e}"
+    if extra:
+        out["extra"] = extra
 
     # -------- CPU baseline: the oracle (port of the reference path) on the host cores -------------------
     if single and not args.no_cpu_baseline:               # rank 0 at N = 1 only
@@ -289,9 +340,53 @@ def main():
     finish()
 
 
-def bench_c4(net, sd, dev, L, _capi, synth, decode_heads, Bc=32, steps=10):
+def bench_c3_gather(net, x, pos, pos_occ, sharding, dist, rccl, rank, world, B, dev):
+    """BASELINE config c3: world x B scenes sharded over the ranks, the head outputs of ALL scenes gathered on every rank
+    with one RCCL all_gather per output tensor (giga_amd.sharding.all_gather_scenes).  Checks the gathered result against
+    this rank's own rows and reports the time of the collective (not part of `value`)."""
+    n = world * B
+    with torch.no_grad():
+        local = net(x, pos, p_tsdf=pos_occ)
+        torch.cuda.synchronize()
+        full = sharding.all_gather_scenes(tuple(local), n, rank, world, rccl)     # warm-up (communicator setup)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        full = sharding.all_gather_scenes(tuple(local), n, rank, world, rccl)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    mine = sharding.scene_shard(n, rank, world)
+    ok = all(tuple(f.shape[1:]) == tuple(l.shape[1:]) and f.shape[0] == n and torch.equal(f[mine], l)
+             for f, l in zip(full, local))
+    okt = torch.tensor([1.0 if ok else 0.0], device=dev)
+    dist.all_reduce(okt, op=dist.ReduceOp.MIN, group=rccl)
+    nbytes = sum(f.numel() * 4 for f in full)
+    return {"workload": f"c3: {n} scenes = {B}/GPU x {world}, all_gather of qual/rot/width/occ of every scene over RCCL",
+            "scenes": n, "gathered_bytes_per_rank": nbytes, "all_gather_ms": dt * 1e3, "own_rows_match_on_every_rank": bool(okt.item() == 1.0),
+            "checksum_qual": float(full[0].double().sum())}
+
+
+def _time_steps(fn, steps, warm):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        marks[i].record()
+        fn()
+    marks[steps].record()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    per = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    return el / steps, per
+
+
+def bench_c4(net, dev, L, _capi, synth, decode_heads, prec, Bc=32, steps=10):
+    """c4: Bc scenes x the 64 000-point inference lattice, three grasp heads, decoder precision `prec` ('fp16': f16
+    encoder + f16 decoder; 'fp16x3': fp32 encoder + split-operand f16 decoder, fp32-grade results)."""
     N = 64000
-    net.set_precision("fp16")
+    net.set_precision(prec)
     blob = net.packed_blob(dev)
     from giga_amd.detection import query_lattice
     x = torch.from_numpy(synth.tsdf_batch(1000, Bc)).to(dev)
@@ -300,8 +395,8 @@ def bench_c4(net, sd, dev, L, _capi, synth, decode_heads, Bc=32, steps=10):
 
     def step(pr=None):
         with torch.no_grad():
-            nhwc, _ = net.encoder.encode_nhwc(x, blob=blob, precision="fp16", fold_final=True)
-            return decode_heads(nhwc, lat, blob, 7, "fp16", True, probe=pr, folded=True)
+            nhwc, _ = net.encoder.encode_nhwc(x, blob=blob, precision=prec, fold_final=True)
+            return decode_heads(nhwc, lat, blob, 7, prec, True, probe=pr, folded=True)
 
     for _ in range(8):                     # also absorbs the allocator's one-off work after a change of batch size
         step()
@@ -317,48 +412,78 @@ def bench_c4(net, sd, dev, L, _capi, synth, decode_heads, Bc=32, steps=10):
         _capi.check(L.giga_event_elapsed_ms(a, b, ctypes.byref(ms)), "event")
         dms.append(ms.value)
         L.giga_event_destroy(a); L.giga_event_destroy(b)
-    dec_ms = float(np.mean(dms))
+    dec_ms = float(np.median(dms))
     flops = Bc * N * FLOP_GRASP3
     ach = flops / (dec_ms * 1e-3) / 1e12
     net.set_precision("fp32")
+    split = prec == "fp16x3"
+    roof = {"kernel": "decoder_f16s_kernel" if split else "decoder_f16_kernel", "bound": "mfma", "achieved": ach,
+            "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+            "frac_of_measured_peak": ach / MEASURED_F16_MFMA_TFLOPS, "avg_launch_ms": dec_ms, "flops_per_launch": flops}
+    if split:
+        roof["issued_mfma_tflops"] = ach * SPLIT_MFMA_PER_PLAIN
+        roof["issued_mfma_frac_of_peak"] = ach * SPLIT_MFMA_PER_PLAIN / PEAK_F16_MFMA_TFLOPS
+        roof["note"] = ("`achieved`/`frac` count ALGORITHMIC FLOPs (154 560 per point); the split chain issues 162 f16 MFMAs per "
+                        "tile and head instead of 58, so the matrix pipe is busy with issued_mfma_tflops")
     return {
-        "workload": f"c4: batch={Bc} scenes x the 64000-point inference lattice, 3 grasp heads, f16 MFMA decoder "
-                    f"(lattice path) + f16 encoder",
+        "workload": f"c4: batch={Bc} scenes x the 64000-point inference lattice, 3 grasp heads, "
+                    + ("f16x3 split-operand f16-MFMA decoder (fp32-grade, <= 6e-6 vs oracle) + fp32 encoder" if split else
+                       "f16 MFMA decoder (lattice path) + f16 encoder"),
         "scenes_per_sec": Bc * steps / el, "query_points_per_sec": Bc * steps * N / el,
-        "ms_per_step": el / steps * 1e3, "dtype": "f16 operands / f32 accumulate",
-        "roofline": {"kernel": "decoder_f16_kernel", "bound": "mfma", "achieved": ach, "peak": PEAK_F16_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": None,
-                     "frac_of_measured_peak": ach / MEASURED_F16_MFMA_TFLOPS,
-                     "avg_launch_ms": dec_ms, "flops_per_launch": flops},
+        "ms_per_step": el / steps * 1e3, "dtype": "f16x3 split operands / f32 accumulate" if split else "f16 operands / f32 accumulate",
+        "roofline": roof,
     }
 
 
+def bench_c4_all(net, dev, L, _capi, synth, decode_heads):
+    out = {}
+    for prec, key in (("fp16", "c4"), ("fp16x3", "c4_fp16x3")):
+        out[key] = bench_c4(net, dev, L, _capi, synth, decode_heads, prec)
+        sweep = []
+        for bc in (1, 8, 128):           # BASELINE c4 is a sweep over the scenes per GPU
+            r = bench_c4(net, dev, L, _capi, synth, decode_heads, prec, Bc=bc, steps=10)
+            sweep.append({"scenes": bc, "scenes_per_sec": r["scenes_per_sec"], "ms_per_step": r["ms_per_step"],
+                          "decoder_ms": r["roofline"]["avg_launch_ms"], "decoder_tflops": r["roofline"]["achieved"],
+                          "decoder_frac_of_f16_mfma_peak": r["roofline"]["frac"]})
+        out[key + "_sweep"] = sweep
+    return out
+
+
 def bench_c2_ii(net, dev, synth, B, steps=20):
-    """BASELINE c2 (ii): every scene gets 2048 grasp queries (3 heads) and 2048 occupancy queries, fp32."""
+    """BASELINE c2 (ii): every scene gets 2048 grasp queries (3 heads) and 2048 occupancy queries; fp32 and fp16x3."""
     N = 2048
-    net.set_precision("fp32").eval()
     x = torch.from_numpy(synth.tsdf_batch(3000, B)).to(dev)
     p = torch.from_numpy(synth.query_points(3000, B, N, stream=2)).to(dev)
     po = torch.from_numpy(synth.query_points(3000, B, N, stream=3)).to(dev)
-    with torch.no_grad():
-        for _ in range(5):
-            net(x, p, p_tsdf=po)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            net(x, p, p_tsdf=po)
-        torch.cuda.synchronize()
-    el = (time.perf_counter() - t0) / steps
     flop_scene = FLOP_ENCODER + N * (FLOP_GRASP3 + FLOP_HEAD["tsdf"])
-    return {"workload": f"c2 (ii): batch={B}, 2048 grasp queries x 3 heads + 2048 occupancy queries per scene, fp32",
-            "ms_per_step": el * 1e3, "scenes_per_sec": B / el, "query_points_per_sec": B * 2 * N / el,
-            "algorithmic_tflops": B * flop_scene / el / 1e12}
+    res = {}
+    for prec in ("fp32", "fp16x3"):
+        net.set_precision(prec).eval()
+        with torch.no_grad():
+            el, per = _time_steps(lambda: net(x, p, p_tsdf=po), steps, 5)
+        res[prec] = {"ms_per_step": el * 1e3, "step_ms_median": float(np.median(per)), "scenes_per_sec": B / el,
+                     "query_points_per_sec": B * 2 * N / el, "algorithmic_tflops": B * flop_scene / el / 1e12}
+    net.set_precision("fp32")
+    res["workload"] = f"c2 (ii): batch={B}, 2048 grasp queries x 3 heads + 2048 occupancy queries per scene"
+    return res
 
 
-def bench_train(net, dev, synth, B, M, steps=10, rank=0, world=1):
-    """One optimisation step of scripts/train_giga.py:198-211 on this rank's scenes.  world > 1: the backward
+def bench_c2_mode(net, x, pos, pos_occ, prec, steps=30):
+    """The headline workload (c2, literal train_giga call) in another precision mode, for comparison with `value`."""
+    net.set_precision(prec).eval()
+    with torch.no_grad():
+        el, per = _time_steps(lambda: net(x, pos, p_tsdf=pos_occ), steps, 5)
+    net.set_precision("fp32")
+    B = x.shape[0]
+    return {"workload": f"c2 in mode {prec}: fp32 encoder + f16x3 split-operand decoders (fp32-grade results)",
+            "ms_per_step": el * 1e3, "step_ms_median": float(np.median(per)), "scenes_per_sec": B / el}
+
+
+def bench_train(net, dev, synth, B, M, steps=50, rank=0, world=1, sync=None):
+    """One optimisation step of scripts/train_giga.py:198-211 on this rank's scenes: forward, the fused joint loss
+    (giga_amd.training.giga_loss = select + loss_fn of the reference), HIP backward, fused Adam.  world > 1: the backward
     all-reduces (means) the flat gradient bucket over RCCL (net.enable_data_parallel), BASELINE config c5."""
-    from giga_amd.training import loss_fn, select
+    from giga_amd.training import giga_loss
     net.set_precision("fp32").train()
     first = 2000 + rank * B
     x = torch.from_numpy(synth.tsdf_batch(first, B)).to(dev)
@@ -368,27 +493,29 @@ def bench_train(net, dev, synth, B, M, steps=10, rank=0, world=1):
     # the reference's optimiser (train_giga.py:49: Adam, lr 2e-4) in torch's single-launch form; the default
     # per-tensor foreach path costs 6 ms of host time per step for the 164 parameter tensors
     opt = torch.optim.Adam(net.parameters(), lr=2e-4, fused=True)
+    last = {}
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss, _ = loss_fn(select(net(x, pos, p_tsdf=pos_occ)), y)
+        loss, _ = giga_loss(net(x, pos, p_tsdf=pos_occ), y)
         loss.backward()
         opt.step()
-        return loss
+        last["loss"] = loss
 
-    for _ in range(3):
+    for _ in range(5):
         step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    torch.cuda.synchronize()
-    el = (time.perf_counter() - t0) / steps
+    if sync is not None:
+        sync()
+    el, per = _time_steps(step, steps, 0)
+    if sync is not None:
+        sync()
     net.eval()
     return {"workload": f"joint GIGA training step (train_giga.py:198-211): B={B} scenes/GPU, 1 grasp query + {M} "
-                        f"occupancy queries, forward + HIP backward + fused Adam, fp32, {world} GPU"
+                        f"occupancy queries, forward + fused loss + HIP backward + fused Adam, fp32, {world} GPU"
                         + (", one RCCL all-reduce of the flat gradient bucket per step" if world > 1 else ""),
-            "ms_per_step": el * 1e3, "scenes_per_sec": world * B / el, "final_loss": float(loss.detach())}
+            "steps": steps, "ms_per_step": el * 1e3, "step_ms_median": float(np.median(per)), "step_ms_max": float(np.max(per)),
+            "step_ms_p90": float(np.percentile(per, 90)), "scenes_per_sec": world * B / el,
+            "final_loss": float(last["loss"].detach())}
 
 
 def cpu_baseline(sd, synth, M, budget_s=20.0):

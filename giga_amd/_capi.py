@@ -54,6 +54,9 @@ _SIGNATURES = {
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "giga_train_loss": (ctypes.c_int, [ctypes.c_void_p] * 8 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                               ctypes.c_void_p]),
+    "giga_train_loss_backward": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5),
     "giga_event_create": (ctypes.c_void_p, []),
     "giga_event_destroy": (None, [ctypes.c_void_p]),
     "giga_event_elapsed_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
@@ -119,8 +122,26 @@ def check(code, what):
         raise GigaHipError(f"{what} failed: {lib().giga_strerror(code).decode()} ({code})")
 
 
-def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream_ptr(device=None):
+    """hipStream_t of torch's current stream on `device` (default: the current device).  Callers launch inside
+    `torch.cuda.device(t.device)` so that the library's kernels, attribute calls and this stream all refer to the device
+    the tensors live on, whatever torch's current device is."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def device_of(*tensors):
+    """The one HIP device all given tensors live on (GigaHipError for CPU tensors or mixed devices)."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            require_device(t)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise GigaHipError(f"tensors live on different devices ({dev} and {t.device})")
+    return dev
 
 
 def ptr(t):

@@ -121,9 +121,16 @@ def _flat_params(named_tensors, device):
 
 
 class _PackedWeights:
-    """Caches the device blob; repacks when any parameter tensor changes (version / storage)."""
+    """Caches the device blob; repacks when any parameter tensor changes (storage pointer or autograd version counter).
+    CAVEAT: an in-place update through `.data` (`p.data.copy_()`, `p.data.mul_()`: EMA, weight clipping, old-style
+    loaders) bumps neither -- call `module.invalidate_packed()` after such an update (optimizers, `load_state_dict`,
+    `.to()`, `train()`/`eval()` are covered)."""
 
     def __init__(self):
+        self.key = None
+        self.blob = None
+
+    def invalidate(self):
         self.key = None
         self.blob = None
 
@@ -227,11 +234,12 @@ class LocalVoxelEncoder(nn.Module):
         stage, ev0, ev1 = probe if probe is not None else (-1, None, None)
         if fold_final and want_nchw:
             raise ValueError("fold_final planes are an internal representation; the reference layout needs the final planes")
-        _capi.check(L.giga_encoder_forward_probe(_capi.ptr(x), _capi.ptr(blob), _capi.ptr(nhwc), _capi.ptr(nchw),
-                                                 B, prec | (_capi.FOLD_FINAL if fold_final else 0),
-                                                 _capi.ptr(ws), ws.numel(), _capi.stream_ptr(),
-                                                 stage, ev0, ev1),
-                    "giga_encoder_forward")
+        with torch.cuda.device(x.device):      # launch on the tensors' device and ITS current stream, whatever torch's current device is
+            _capi.check(L.giga_encoder_forward_probe(_capi.ptr(x), _capi.ptr(blob), _capi.ptr(nhwc), _capi.ptr(nchw),
+                                                     B, prec | (_capi.FOLD_FINAL if fold_final else 0),
+                                                     _capi.ptr(ws), ws.numel(), _capi.stream_ptr(x.device),
+                                                     stage, ev0, ev1),
+                        "giga_encoder_forward")
         return nhwc, nchw
 
     def forward(self, x, _blob=None):
@@ -260,9 +268,10 @@ def _planes_to_nhwc(c_plane, precision):
             raise ValueError(f"expected (B,{C_DIM},{RES},{RES}) planes, got {tuple(t.shape)}")
     prec = _capi.PRECISION[precision]
     nhwc = torch.empty((3, B, RES, RES, C_DIM), device=xs[0].device, dtype=_capi.PLANE_DTYPE[prec])
-    _capi.check(_capi.lib().giga_planes_pack(_capi.ptr(xs[0]), _capi.ptr(xs[1]), _capi.ptr(xs[2]),
-                                             _capi.ptr(nhwc), B, prec, _capi.stream_ptr()),
-                "giga_planes_pack")
+    with torch.cuda.device(_capi.device_of(*xs)):
+        _capi.check(_capi.lib().giga_planes_pack(_capi.ptr(xs[0]), _capi.ptr(xs[1]), _capi.ptr(xs[2]),
+                                                 _capi.ptr(nhwc), B, prec, _capi.stream_ptr(xs[0].device)),
+                    "giga_planes_pack")
     return nhwc
 
 
@@ -293,14 +302,13 @@ def decode_heads(nhwc, p, blob, head_mask, precision, post, probe=None, folded=F
     probe = (ev_start, ev_stop) brackets the launch with HIP events (bench.py).
     folded: `nhwc` came from `encode_nhwc(..., fold_final=True)` (planes before conv_final).
     A registered lattice tensor (shape (1, R^3, 3)) is shared by all scenes and takes the lattice path."""
-    _capi.require_device(nhwc, p, blob)
+    dev = _capi.device_of(nhwc, p, blob)
     if p.dim() != 3 or p.shape[-1] != 3:
         raise ValueError(f"expected (B,N,3) query points, got {tuple(p.shape)}")
     lat = _lattice_of(p)
     B, N = (nhwc.shape[1] if lat is not None else p.shape[0]), p.shape[1]
     if nhwc.shape[1] != B:
         raise ValueError("batch size of planes and points differ")
-    dev = p.device
     if lat is None:
         p = p.contiguous().float()
     out = {}
@@ -324,20 +332,22 @@ def decode_heads(nhwc, p, blob, head_mask, precision, post, probe=None, folded=F
             _LATTICE_WS.clear()
             ws = torch.empty(L.giga_lattice_workspace_bytes(B, R, prec), dtype=torch.uint8, device=dev)
             _LATTICE_WS[key] = ws
-        _capi.check(L.giga_decoder_forward_lattice(
-            _capi.ptr(nhwc), _capi.ptr(lin), _capi.ptr(blob), head_mask,
+        with torch.cuda.device(dev):
+            _capi.check(L.giga_decoder_forward_lattice(
+                _capi.ptr(nhwc), _capi.ptr(lin), _capi.ptr(blob), head_mask,
+                _capi.ptr(out.get("decoder_qual")), _capi.ptr(out.get("decoder_rot")),
+                _capi.ptr(out.get("decoder_width")), _capi.ptr(out.get("decoder_tsdf")),
+                B, R, prec | fold, 1 if post else 0, _capi.ptr(ws), ws.numel(), _capi.stream_ptr(dev), ev0, ev1),
+                "giga_decoder_forward_lattice")
+        return out
+    with torch.cuda.device(dev):
+        _capi.check(_capi.lib().giga_decoder_forward_probe(
+            _capi.ptr(nhwc), _capi.ptr(p), _capi.ptr(blob), head_mask,
             _capi.ptr(out.get("decoder_qual")), _capi.ptr(out.get("decoder_rot")),
             _capi.ptr(out.get("decoder_width")), _capi.ptr(out.get("decoder_tsdf")),
-            B, R, prec | fold, 1 if post else 0, _capi.ptr(ws), ws.numel(), _capi.stream_ptr(), ev0, ev1),
-            "giga_decoder_forward_lattice")
-        return out
-    _capi.check(_capi.lib().giga_decoder_forward_probe(
-        _capi.ptr(nhwc), _capi.ptr(p), _capi.ptr(blob), head_mask,
-        _capi.ptr(out.get("decoder_qual")), _capi.ptr(out.get("decoder_rot")),
-        _capi.ptr(out.get("decoder_width")), _capi.ptr(out.get("decoder_tsdf")),
-        B, N, _capi.PRECISION[precision] | (_capi.FOLD_FINAL if folded else 0), 1 if post else 0, _capi.stream_ptr(),
-        ev0, ev1),
-        "giga_decoder_forward")
+            B, N, _capi.PRECISION[precision] | (_capi.FOLD_FINAL if folded else 0), 1 if post else 0,
+            _capi.stream_ptr(dev), ev0, ev1),
+            "giga_decoder_forward")
     return out
 
 
@@ -398,13 +408,32 @@ class _ParamListCache:
             pl = self.__dict__["_plist"] = self._param_list()
         return pl
 
-    def _apply(self, fn, *args, **kwargs):
+    def invalidate_packed(self):
+        """Drop every cached derivative of the parameters: the ordered parameter list, the packed weight blobs (module,
+        encoder, standalone decoders) and anything keyed on them (the planner's hipGraphs re-capture when the blob
+        changes).  Needed only after updates torch cannot see: in-place writes through `.data`, or Parameter objects
+        re-assigned on a submodule."""
         self.__dict__.pop("_plist", None)
+        for m in self.modules():
+            pw = m.__dict__.get("_packed")
+            if pw is not None:
+                pw.invalidate()
+        st = self.__dict__.get("_train_state")
+        if st is not None:
+            st._wkey = None
+        return self
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_packed()
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
-        self.__dict__.pop("_plist", None)
+        self.invalidate_packed()
         return super().load_state_dict(*args, **kwargs)
+
+    def train(self, mode=True):
+        self.invalidate_packed()
+        return super().train(mode)
 
 
 class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
@@ -439,6 +468,11 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
         return 7 | (8 if hasattr(self, "decoder_tsdf") else 0)
 
     def packed_blob(self, device):
+        if self.__dict__.pop("_stale_after_training", False):
+            # a training forward ran since the blob was packed.  torch's fused optimizers (Adam(fused=True)) update the
+            # parameters WITHOUT bumping their version counters (measured: 0 bumps per step), so the cache key cannot see
+            # those steps; the training path therefore marks the inference caches stale itself
+            self.invalidate_packed()
         return self._packed.get(self._ordered_params(), self._head_present(), device)
 
     # -- reference API ------------------------------------------------------------------------------
@@ -484,6 +518,7 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
         if st is None or st.blob.device != inputs.device:
             st = self._train_state = _TrainState(self._head_present(), inputs.device, detach_occ=self.detach_tsdf)
             st.data_parallel, st.group = getattr(self, "_dp", (False, None))
+        self.__dict__["_stale_after_training"] = True
         return GigaFunction.apply(st, inputs, p, p_tsdf, *self._ordered_params())
 
     def infer_geo(self, inputs, p_tsdf, **kwargs):
@@ -526,6 +561,12 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
         model = super().to(device)
         model._device = device
         return model
+
+    def grad_refine(self, x, pos, bound_value=0.0125, lr=1e-6, num_step=1):
+        """models/__init__.py:136-164 optimises the query POSITIONS by gradient ascent on the predicted quality; it needs
+        d qual / d p, which the HIP decoder does not produce (its backward yields parameter gradients only)."""
+        raise NotImplementedError("grad_refine needs gradients with respect to the query points; libgiga_hip's backward "
+                                  "computes parameter gradients only (DESIGN.md, out of SURVEY 8's scope)")
 
 
 class ConvolutionalOccupancyNetworkGeometry(_ParamListCache, nn.Module):

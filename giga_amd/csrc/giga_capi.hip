@@ -22,6 +22,14 @@ size_t dec_bwd_scratch_floats(long long P, int nheads);
 int launch_decoder_backward(const float* planes, const float* p, const uint8_t* blob, const uint8_t* bwd_blob,
                             int head_mask, const float* const* outs, const float* const* douts, float* gplanes,
                             float* grads, int head_present, float* scratch, int B, int N, hipStream_t s);
+// giga_loss.hip
+int launch_train_loss(const float* qual, const float* rot, const float* width, const float* occ, const float* label,
+                      const float* rot_t, const float* width_t, const float* occ_t, int B, int M, float* losses,
+                      float* scene_loss, hipStream_t s);
+int launch_train_loss_backward(const float* qual, const float* rot, const float* width, const float* occ,
+                               const float* label, const float* rot_t, const float* width_t, const float* occ_t,
+                               const float* gout, int B, int M, float* dqual, float* drot, float* dwidth, float* docc,
+                               hipStream_t s);
 // giga_encoder.hip
 struct EncWs { size_t P0, A0, S0, Q0, A1, S1, Q1, A2, S2, U0, A3, A4, U1, A5, A6, YZ, XZ, total; };
 EncWs enc_workspace(int B, int precision);
@@ -301,6 +309,30 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
     rc |= launch_encoder_backward(tsdf, blob, bblob, static_cast<const uint8_t*>(enc_workspace_fwd), gplanes, gws,
                                   grads, head_present, B, s);
     return rc;
+}
+
+int giga_train_loss(const float* qual, const float* rot, const float* width, const float* occ_logits, const float* label,
+                    const float* rot_targets, const float* width_target, const float* occ_target, int B, int M,
+                    float* losses, float* scene_losses, void* stream) {
+    if (B < 0 || M < 0) return -1;
+    if (B == 0) return 0;
+    if (!qual || !rot || !width || !label || !rot_targets || !width_target || !losses || !scene_losses) return -1;
+    if (M > 0 && (!occ_logits || !occ_target)) return -1;
+    return launch_train_loss(qual, rot, width, occ_logits, label, rot_targets, width_target, occ_target, B, M, losses,
+                             scene_losses, static_cast<hipStream_t>(stream));
+}
+
+int giga_train_loss_backward(const float* qual, const float* rot, const float* width, const float* occ_logits,
+                             const float* label, const float* rot_targets, const float* width_target,
+                             const float* occ_target, const float* grad_loss, int B, int M, float* dqual, float* drot,
+                             float* dwidth, float* docc, void* stream) {
+    if (B < 0 || M < 0) return -1;
+    if (B == 0) return 0;
+    if (!qual || !rot || !width || !label || !rot_targets || !width_target || !grad_loss || !dqual || !drot || !dwidth)
+        return -1;
+    if (M > 0 && (!occ_logits || !occ_target || !docc)) return -1;
+    return launch_train_loss_backward(qual, rot, width, occ_logits, label, rot_targets, width_target, occ_target, grad_loss,
+                                      B, M, dqual, drot, dwidth, docc, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -828,12 +828,18 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
         a.mR2 = (unsigned)((0x100000000ULL + (unsigned long long)a.R * a.R - 1) / ((unsigned long long)a.R * a.R));
     }
     if (precision == 2) {
-        // f16x3 split: head-resident workgroups, grid = slots x nheads <= 256 (one per CU)
-        constexpr int T = 2, NW = 8;
-        int slots = (int)((tiles + NW * T - 1) / (NW * T));
-        if (slots > 256 / a.nheads) slots = 256 / a.nheads;
+        // f16x3 split: head-resident workgroups, grid = slots x nheads <= 256 (one per CU).  Two tiles per wave (the weight
+        // fragments of an MFMA triple are read from LDS once per two tiles) when every workgroup gets at least two such
+        // rounds; smaller problems take one tile per wave so that twice as many CUs share the work.
+        constexpr int NW = 8;
+        const int cap = 256 / a.nheads;
+        const bool two = tiles >= 2LL * cap * NW * 2;
+        const int per_round = NW * (two ? 2 : 1);
+        int slots = (int)((tiles + per_round - 1) / per_round);
+        if (slots > cap) slots = cap;
         a.nbatch = slots;
-        auto kern = lat ? decoder_f16s_kernel<T, true, NW> : decoder_f16s_kernel<T, false, NW>;
+        auto kern = two ? (lat ? decoder_f16s_kernel<2, true, NW> : decoder_f16s_kernel<2, false, NW>)
+                        : (lat ? decoder_f16s_kernel<1, true, NW> : decoder_f16s_kernel<1, false, NW>);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)DEC16S_BYTES);
         hipLaunchKernelGGL(kern, dim3(slots * a.nheads), dim3(NW * 64), DEC16S_BYTES, s, a);

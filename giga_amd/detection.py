@@ -62,24 +62,35 @@ class _GraspBuffers:
     def __init__(self, B, R, cap, dev):
         V = R * R * R
         self.B, self.R, self.cap = B, R, cap
-        self.pack = torch.empty(B * (2 + 7 * cap), dtype=torch.int32, device=dev)
-        o = 0
-        self.counters = self.pack[o:o + 2 * B].view(B, 2); o += 2 * B
-        self.cand_index = self.pack[o:o + B * cap].view(B, cap); o += B * cap
-        self.cand_score = self.pack[o:o + B * cap].view(torch.float32).view(B, cap); o += B * cap
-        self.cand_rot = self.pack[o:o + 4 * B * cap].view(torch.float32).view(B, cap, 4); o += 4 * B * cap
-        self.cand_width = self.pack[o:o + B * cap].view(torch.float32).view(B, cap)
+        off = self.offsets(B, cap)
+        self.pack = torch.empty(off[-1], dtype=torch.int32, device=dev)
+        self.counters = self.pack[off[0]:off[0] + 2 * B].view(B, 2)
+        self.cand_index = self.pack[off[1]:off[1] + B * cap].view(B, cap)
+        self.cand_score = self.pack[off[2]:off[2] + B * cap].view(torch.float32).view(B, cap)
+        self.cand_rot = self.pack[off[3]:off[3] + 4 * B * cap].view(torch.float32).view(B, cap, 4)
+        self.cand_width = self.pack[off[4]:off[4] + B * cap].view(torch.float32).view(B, cap)
         self.qual_out = torch.empty(B, V, device=dev)
         self.ws = torch.empty(_capi.lib().giga_grasp_workspace_bytes(B, R), dtype=torch.uint8, device=dev)
 
+    @staticmethod
+    def offsets(B, cap):
+        """int32 offsets of the five sections (+ the total), each rounded up to 4 words: the kernels store quaternions as
+        float4, so every section starts 16-byte aligned whatever B is (an odd B used to leave cand_rot 8-byte aligned)."""
+        sizes = (2 * B, B * cap, B * cap, 4 * B * cap, B * cap)
+        off, at = [], 0
+        for n in sizes:
+            off.append(at)
+            at += (n + 3) // 4 * 4
+        return off + [at]
+
     def host_views(self, pack_h):
         B, cap = self.B, self.cap
-        o = 2 * B
-        cnt = pack_h[:o].reshape(B, 2)
-        idx = pack_h[o:o + B * cap].reshape(B, cap); o += B * cap
-        score = pack_h[o:o + B * cap].view(np.float32).reshape(B, cap); o += B * cap
-        rot = pack_h[o:o + 4 * B * cap].view(np.float32).reshape(B, cap, 4); o += 4 * B * cap
-        width = pack_h[o:o + B * cap].view(np.float32).reshape(B, cap)
+        off = self.offsets(B, cap)
+        cnt = pack_h[off[0]:off[0] + 2 * B].reshape(B, 2)
+        idx = pack_h[off[1]:off[1] + B * cap].reshape(B, cap)
+        score = pack_h[off[2]:off[2] + B * cap].view(np.float32).reshape(B, cap)
+        rot = pack_h[off[3]:off[3] + 4 * B * cap].view(np.float32).reshape(B, cap, 4)
+        width = pack_h[off[4]:off[4] + B * cap].view(np.float32).reshape(B, cap)
         return cnt, idx, score, rot, width
 
 
@@ -100,18 +111,19 @@ def _grasp_launch(tsdf, qual, rot, width, prm, buf):
     qual = qual.reshape(B, V).float().contiguous()
     rot = rot.reshape(B, V, 4).float().contiguous()
     width = width.reshape(B, V).float().contiguous()
-    _capi.check(_capi.lib().giga_grasp_select(
-        _capi.ptr(tsdf), _capi.ptr(qual), _capi.ptr(rot), _capi.ptr(width), B, R, ctypes.byref(prm),
-        _capi.ptr(buf.qual_out), _capi.ptr(buf.counters), buf.cap, _capi.ptr(buf.cand_index), _capi.ptr(buf.cand_score),
-        _capi.ptr(buf.cand_rot), _capi.ptr(buf.cand_width), _capi.ptr(buf.ws), buf.ws.numel(), _capi.stream_ptr()),
-        "giga_grasp_select")
+    with torch.cuda.device(qual.device):
+        _capi.check(_capi.lib().giga_grasp_select(
+            _capi.ptr(tsdf), _capi.ptr(qual), _capi.ptr(rot), _capi.ptr(width), B, R, ctypes.byref(prm),
+            _capi.ptr(buf.qual_out), _capi.ptr(buf.counters), buf.cap, _capi.ptr(buf.cand_index), _capi.ptr(buf.cand_score),
+            _capi.ptr(buf.cand_rot), _capi.ptr(buf.cand_width), _capi.ptr(buf.ws), buf.ws.numel(),
+            _capi.stream_ptr(qual.device)), "giga_grasp_select")
 
 
 def _grasp_collect(buf, force_detection):
     """D->H of the survivors and the host-side ordering.  Returns None if a scene produced more candidates than
     `cap` (the caller then repeats with the full capacity)."""
     B, R, cap = buf.B, buf.R, buf.cap
-    if B * (2 + 7 * cap) * 4 <= (1 << 20):                    # small block: one copy brings everything
+    if buf.pack.numel() * 4 <= (1 << 20):                     # small block: one copy brings everything
         cnt, idx_h, score_h, rot_h, width_h = buf.host_views(buf.pack.cpu().numpy())
         if B and cnt[:, 1].max() > cap:
             return None

@@ -21,6 +21,16 @@ def tsdf_batch(first_scene, n, realistic=False):
     return np.stack([tsdf_scene(first_scene + i, realistic) for i in range(n)], axis=0)
 
 
+def tsdf_scenes(indices, realistic=False):
+    """TSDF grids of an arbitrary list of scene indices (a rank's shard: scene i -> rank i mod world)."""
+    return np.stack([tsdf_scene(i, realistic) for i in indices], axis=0)
+
+
+def query_points_for(indices, n_points, stream=0, half_width=0.5):
+    """query_points for an arbitrary list of scene indices: row k equals query_points(indices[k], 1, ...)[0]."""
+    return np.concatenate([query_points(i, 1, n_points, stream, half_width) for i in indices], axis=0)
+
+
 def query_points(first_scene, n_scenes, n_points, stream=0, half_width=0.5):
     """(n_scenes, n_points, 3) float32, U[-half_width, half_width)."""
     out = np.empty((n_scenes, n_points, 3), np.float32)

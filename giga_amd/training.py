@@ -1,46 +1,103 @@
-"""Training path: autograd bridge to the HIP forward/backward kernels (fp32) and the counterparts of the
-training caller's helpers (reference scripts/train_giga.py:141-218).
+"""Training path: autograd bridge to the HIP forward/backward kernels (fp32) and the fused loss of the joint objective
+(reference scripts/train_giga.py:154-211).
 
-`ConvolutionalOccupancyNetwork.forward` dispatches here when autograd is enabled and parameters require
-grad, so the reference loop works unchanged:
+`ConvolutionalOccupancyNetwork.forward` dispatches here when autograd is enabled and parameters require grad, so the
+reference loop works unchanged with ITS OWN helpers (`select`, `loss_fn` of train_giga.py stay in the caller):
 
     y_pred = select(net(x, pos, p_tsdf=pos_occ)); loss, _ = loss_fn(y_pred, y); loss.backward(); optimizer.step()
 
-Every step the fp32 weight images (forward fragments and the transposed/flipped backward fragments) are
-rebuilt ON THE DEVICE from the current parameters with a gather map (giga_repack_device); activations of
-the forward stay in the encoder workspace that the backward consumes; gradients come back as one flat
-buffer in state-dict order and are handed to autograd as per-parameter views."""
+and `giga_loss(net(x, pos, p_tsdf=pos_occ), y)` is the fused replacement of `loss_fn(select(...), y)`: three HIP launches
+instead of ~40 ATen kernels (csrc/giga_loss.hip).
+
+Every step the fp32 weight images (forward fragments and the transposed/flipped backward fragments) are rebuilt ON THE
+DEVICE from the current parameters with a gather map (giga_repack_device); the activations of the forward stay in an
+encoder workspace that the backward consumes; gradients come back as one flat buffer in state-dict order and are handed
+to autograd as per-parameter views.  The large device buffers of a step (activation workspace, planes, backward
+workspace) are owned by the module's `_TrainState` and recycled, so a steady-state step only takes the small head outputs
+and the 2.3 MB gradient bucket from torch's caching allocator."""
 import ctypes
 
 import torch
-import torch.nn.functional as F
 
 from . import _capi
 
 RES, C_DIM = 40, 32
 
 
+class _StepBuffers:
+    """The large device buffers of one forward/backward pair for a fixed (B, N, M): activation workspace (207 MB at
+    B = 32), planes, backward workspace.  `generation` counts how often the set was handed out, so a backward can tell
+    that its activations were recycled by a later forward.  (The head outputs and the flat gradient buffer are NOT
+    recycled: callers keep the outputs, and autograd's AccumulateGrad adopts the gradient views as `param.grad`.)"""
+
+    def __init__(self, state, B, N, M, dev):
+        L = _capi.lib()
+        hp = state.head_present
+        self.key = (B, N, M)
+        self.busy = False
+        self.generation = 0
+        self.ws = torch.empty(max(L.giga_encoder_workspace_bytes(B, 0), 16), dtype=torch.uint8, device=dev)
+        self.nhwc = torch.empty((3, B, RES, RES, C_DIM), device=dev, dtype=torch.float32)
+        self.wsb = torch.empty(max(L.giga_backward_workspace_bytes(B, N, M, hp), 16), dtype=torch.uint8, device=dev)
+
+
 class _TrainState:
-    """Per-module device state: gather maps and the two weight images."""
+    """Per-module device state: gather maps, the two weight images and the recycled step buffers."""
 
     def __init__(self, head_present, device, detach_occ=False):
         self.bwd_flags = _capi.DETACH_OCC if detach_occ else 0     # detach_tsdf (models/__init__.py:61-63)
         L = _capi.lib()
         self.head_present = head_present
+        self.device = device
         self.map_fwd = _capi.pack_map(head_present).to(device)
         self.map_bwd = _capi.pack_bwd_map(head_present).to(device)
         self.blob = torch.zeros(L.giga_packed_bytes(), dtype=torch.uint8, device=device)
         self.bwd_blob = torch.zeros(L.giga_bwd_packed_bytes(), dtype=torch.uint8, device=device)
         self.n_params = L.giga_param_count(head_present)
+        self.flat = torch.empty(self.n_params, device=device, dtype=torch.float32)
+        self.repacks = 0                # how often the images were rebuilt: identifies the weights they currently hold
+        self._wkey = None               # (storage, version) of every parameter the images were built from
         self.data_parallel = False      # set by ConvolutionalOccupancyNetwork.enable_data_parallel()
         self.group = None
+        self._pool = []
 
-    def repack(self, flat):
+    def repack(self, params):
+        """Flatten the parameters (state-dict order) and rebuild both fp32 weight images from them on the device.
+        Unconditional (two small gather kernels): correctness of a step never depends on torch's version counters, which
+        in-place updates through `.data` do not bump.  `_wkey` (storage + version of every parameter) only serves the
+        stale-graph check in GigaFunction.backward."""
+        key = tuple((q.data_ptr(), q._version) for q in params)
         L = _capi.lib()
+        flat = self.flat
+        views, at = [], 0
+        for q in params:
+            n = q.numel()
+            views.append(flat[at:at + n].view(q.shape))
+            at += n
+        if at != self.n_params:
+            raise _capi.GigaHipError("parameter list does not match the head set")
+        torch._foreach_copy_(views, [q.detach() for q in params])
+        s = _capi.stream_ptr(self.device)
         _capi.check(L.giga_repack_device(_capi.ptr(flat), _capi.ptr(self.map_fwd), _capi.ptr(self.blob),
-                                         self.map_fwd.numel(), _capi.stream_ptr()), "giga_repack_device")
+                                         self.map_fwd.numel(), s), "giga_repack_device")
         _capi.check(L.giga_repack_device(_capi.ptr(flat), _capi.ptr(self.map_bwd), _capi.ptr(self.bwd_blob),
-                                         self.map_bwd.numel(), _capi.stream_ptr()), "giga_repack_device")
+                                         self.map_bwd.numel(), s), "giga_repack_device")
+        if key != self._wkey:
+            self.repacks += 1
+        self._wkey = key
+
+    def acquire(self, B, N, M):
+        """A free buffer set for (B, N, M); sets of other shapes are dropped (one shape per training run is the norm)."""
+        for sb in self._pool:
+            if sb.key == (B, N, M) and not sb.busy:
+                break
+        else:
+            self._pool = [sb for sb in self._pool if sb.key == (B, N, M)]
+            sb = _StepBuffers(self, B, N, M, self.device)
+            self._pool.append(sb)
+        sb.busy = True
+        sb.generation += 1
+        return sb
 
 
 def allreduce_mean_(flat, group=None):
@@ -61,12 +118,26 @@ def _ptr_array(tensors):
     return arr
 
 
+class _Lease:
+    """Held by the autograd node only: when the graph dies without a backward (an evaluation under enable_grad, an
+    exception), the buffer set returns to the pool instead of staying marked busy."""
+
+    def __init__(self, sb):
+        self.sb, self.generation = sb, sb.generation
+
+    def release(self):
+        if self.sb is not None and self.sb.generation == self.generation:
+            self.sb.busy = False
+        self.sb = None
+
+    __del__ = release
+
+
 class GigaFunction(torch.autograd.Function):
     """(x, p, p_tsdf, *params) -> (qual, rot, width[, tsdf]) on the HIP kernels, differentiable w.r.t. params."""
 
     @staticmethod
     def forward(ctx, state, x, p, p_tsdf, *params):
-        from .convonet import decode_heads
         L = _capi.lib()
         dev = x.device
         x = x.contiguous().float()
@@ -74,96 +145,123 @@ class GigaFunction(torch.autograd.Function):
         p_tsdf = p_tsdf.contiguous().float() if p_tsdf is not None else None
         B, N = p.shape[0], p.shape[1]
         M = p_tsdf.shape[1] if p_tsdf is not None else 0
-        flat = torch.cat([q.detach().reshape(-1).float() for q in params])
-        if flat.numel() != state.n_params:
-            raise _capi.GigaHipError("parameter list does not match the head set")
-        state.repack(flat)
-        ws = torch.empty(max(L.giga_encoder_workspace_bytes(B, 0), 16), dtype=torch.uint8, device=dev)
-        nhwc = torch.empty((3, B, RES, RES, C_DIM), device=dev, dtype=torch.float32)
-        _capi.check(L.giga_encoder_forward(_capi.ptr(x), _capi.ptr(state.blob), _capi.ptr(nhwc), None, B, 0,
-                                           _capi.ptr(ws), ws.numel(), _capi.stream_ptr()), "giga_encoder_forward")
-        grasp_mask = state.head_present & 7
-        outs = [None, None, None, None]
-        if grasp_mask:
-            g = decode_heads(nhwc, p, state.blob, grasp_mask, "fp32", True)
-            outs[0], outs[1], outs[2] = g.get("decoder_qual"), g.get("decoder_rot"), g.get("decoder_width")
-        if state.head_present & 8 and p_tsdf is not None:
-            outs[3] = decode_heads(nhwc, p_tsdf, state.blob, 8, "fp32", False)["decoder_tsdf"]
-        ctx.state, ctx.dims = state, (B, N, M)
-        # save_for_backward, not a plain attribute: the head outputs are needed by the backward, and a node that holds
-        # its own outputs in a Python attribute is a reference cycle -- the 207 MB activation workspace would then live
-        # until the cyclic GC runs (GBs of growth, a hipMalloc every other step and a ~100 ms collection pause)
-        ctx.save_for_backward(x, p, p_tsdf, ws, nhwc, *outs)
+        with torch.cuda.device(dev):
+            state.repack(params)
+            sb = state.acquire(B, N, M)
+            s = _capi.stream_ptr(dev)
+            _capi.check(L.giga_encoder_forward(_capi.ptr(x), _capi.ptr(state.blob), _capi.ptr(sb.nhwc), None, B, 0,
+                                               _capi.ptr(sb.ws), sb.ws.numel(), s), "giga_encoder_forward")
+            hp = state.head_present
+            o = [torch.empty((B, N), device=dev) if hp & 1 and N > 0 else None,
+                 torch.empty((B, N, 4), device=dev) if hp & 2 and N > 0 else None,
+                 torch.empty((B, N), device=dev) if hp & 4 and N > 0 else None,
+                 torch.empty((B, M), device=dev) if hp & 8 and M > 0 else None]
+            if state.head_present & 7 and N > 0:
+                _capi.check(L.giga_decoder_forward(_capi.ptr(sb.nhwc), _capi.ptr(p), _capi.ptr(state.blob),
+                                                   state.head_present & 7, _capi.ptr(o[0]), _capi.ptr(o[1]), _capi.ptr(o[2]),
+                                                   None, B, N, 0, 1, s), "giga_decoder_forward")
+            if state.head_present & 8 and M > 0:
+                _capi.check(L.giga_decoder_forward(_capi.ptr(sb.nhwc), _capi.ptr(p_tsdf), _capi.ptr(state.blob), 8, None,
+                                                   None, None, _capi.ptr(o[3]), B, M, 0, 0, s), "giga_decoder_forward")
+        ctx.state, ctx.dims, ctx.lease, ctx.repacks = state, (B, N, M), _Lease(sb), state.repacks
+        # save_for_backward, not a plain attribute: a node that holds its own outputs in a Python attribute is a reference
+        # cycle (output -> grad_fn -> ctx -> output) that only the cyclic GC would free
+        ctx.save_for_backward(x, p, p_tsdf, *o)
         ctx.shapes = [tuple(q.shape) for q in params]
-        result = tuple(o for o in outs if o is not None)
-        ctx.out_slots = [i for i, o in enumerate(outs) if o is not None]
-        return result
+        ctx.out_slots = [i for i, t in enumerate(o) if t is not None]
+        return tuple(o[i] for i in ctx.out_slots)
 
     @staticmethod
     def backward(ctx, *grad_outs):
         L = _capi.lib()
         state = ctx.state
         B, N, M = ctx.dims
-        x, p, p_tsdf, ws, nhwc, *outs = ctx.saved_tensors
+        lease = ctx.lease
+        sb = lease.sb
+        if sb is None or sb.generation != lease.generation:
+            raise RuntimeError("giga_amd: the activations of this forward were recycled (its backward already ran, or "
+                               "its buffers were released); re-run the forward")
+        if state.repacks != ctx.repacks:
+            raise RuntimeError("giga_amd: another training forward has re-packed the weight images since this forward ran "
+                               "(interleaved forwards with different weights are not supported); backward it first")
+        x, p, p_tsdf, *outs = ctx.saved_tensors
         dev = x.device
         douts = [None, None, None, None]
         for slot, gout in zip(ctx.out_slots, grad_outs):
             douts[slot] = (gout if gout is not None else torch.zeros_like(outs[slot])).contiguous().float()
         grads = torch.empty(state.n_params, device=dev, dtype=torch.float32)
-        wsb = torch.empty(L.giga_backward_workspace_bytes(B, N, M, state.head_present), dtype=torch.uint8, device=dev)
-        _capi.check(L.giga_backward(
-            _capi.ptr(x), _capi.ptr(state.blob), _capi.ptr(state.bwd_blob), _capi.ptr(ws), _capi.ptr(nhwc),
-            _capi.ptr(p), _capi.ptr(p_tsdf), _ptr_array(outs), _ptr_array(douts), _capi.ptr(grads),
-            grads.numel(), state.head_present | state.bwd_flags, B, N, M, _capi.ptr(wsb), wsb.numel(), _capi.stream_ptr()),
-            "giga_backward")
+        with torch.cuda.device(dev):
+            _capi.check(L.giga_backward(
+                _capi.ptr(x), _capi.ptr(state.blob), _capi.ptr(state.bwd_blob), _capi.ptr(sb.ws), _capi.ptr(sb.nhwc),
+                _capi.ptr(p), _capi.ptr(p_tsdf), _ptr_array(outs), _ptr_array(douts), _capi.ptr(grads),
+                grads.numel(), state.head_present | state.bwd_flags, B, N, M, _capi.ptr(sb.wsb), sb.wsb.numel(),
+                _capi.stream_ptr(dev)), "giga_backward")
         if state.data_parallel:
             allreduce_mean_(grads, state.group)
         views, at = [], 0
         for shp in ctx.shapes:
             n = 1
-            for s in shp:
-                n *= s
+            for d in shp:
+                n *= d
             views.append(grads[at:at + n].view(shp))
             at += n
+        lease.release()
         return (None, None, None, None) + tuple(views)
 
 
 # ---------------------------------------------------------------------------------------------------------
-# caller-side helpers: scripts/train_giga.py:141-195 (plain torch on the device; they touch only the head
-# outputs, i.e. O(B) and O(B*M) elementwise work)
+# fused loss: the counterpart of loss_fn(select(out), y) (scripts/train_giga.py:154-195) on the device
 # ---------------------------------------------------------------------------------------------------------
-def prepare_batch(batch, device):
-    """train_giga.py:141-151."""
-    pc, (label, rotations, width), pos, pos_occ, occ_value = batch
-    pc = pc.float().to(device)
-    label = label.float().to(device)
-    rotations = rotations.float().to(device)
-    width = width.float().to(device)
-    pos = pos.unsqueeze(1).float().to(device)          # B, 1, 3
-    pos_occ = pos_occ.float().to(device)
-    occ_value = occ_value.float().to(device)
-    return pc, (label, rotations, width, occ_value), pos, pos_occ
+LOSS_KEYS = ("loss_qual", "loss_rot", "loss_width", "loss_occ", "loss_all")      # train_giga.py:169-173
 
 
-def select(out):
-    """train_giga.py:154-158."""
-    qual_out, rot_out, width_out, occ = out
-    return qual_out.squeeze(-1), rot_out.squeeze(1), width_out.squeeze(-1), torch.sigmoid(occ)
+class _GigaLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qual, rot, width, occ, label, rot_t, width_t, occ_t):
+        L = _capi.lib()
+        B, M = occ.shape[0], occ.shape[1]
+        dev = occ.device
+        args = [t.contiguous().float() for t in (qual, rot, width, occ, label, rot_t, width_t, occ_t)]
+        losses = torch.empty(5, device=dev)
+        scene = torch.empty((B, 5), device=dev)
+        with torch.cuda.device(dev):
+            _capi.check(L.giga_train_loss(*[_capi.ptr(t) for t in args], B, M, _capi.ptr(losses), _capi.ptr(scene),
+                                          _capi.stream_ptr(dev)), "giga_train_loss")
+        ctx.save_for_backward(*args)
+        ctx.shapes = (qual.shape, rot.shape, width.shape, occ.shape)
+        parts = losses[:4]
+        ctx.mark_non_differentiable(parts)
+        return losses[4], parts
+
+    @staticmethod
+    def backward(ctx, gloss, _gparts):
+        L = _capi.lib()
+        args = ctx.saved_tensors
+        occ = args[3]
+        B, M = occ.shape[0], occ.shape[1]
+        dev = occ.device
+        g = gloss.contiguous().float().reshape(1)
+        dq, dr, dw, do = (torch.empty(s, device=dev) for s in ctx.shapes)
+        with torch.cuda.device(dev):
+            _capi.check(L.giga_train_loss_backward(*[_capi.ptr(t) for t in args], _capi.ptr(g), B, M, _capi.ptr(dq),
+                                                   _capi.ptr(dr), _capi.ptr(dw), _capi.ptr(do), _capi.stream_ptr(dev)),
+                        "giga_train_loss_backward")
+        return dq, dr, dw, do, None, None, None, None
 
 
-def _quat_loss_fn(pred, target):
-    return 1.0 - torch.abs(torch.sum(pred * target, dim=1))
+def giga_loss(out, y):
+    """Fused `loss_fn(select(out), y)` of scripts/train_giga.py:154-195 for the literal call shape.
 
-
-def loss_fn(y_pred, y):
-    """train_giga.py:161-195."""
-    label_pred, rotation_pred, width_pred, occ_pred = y_pred
-    label, rotations, width, occ = y
-    loss_qual = F.binary_cross_entropy(label_pred, label, reduction="none")
-    loss_rot = torch.min(_quat_loss_fn(rotation_pred, rotations[:, 0]), _quat_loss_fn(rotation_pred, rotations[:, 1]))
-    loss_width = F.mse_loss(40 * width_pred, 40 * width, reduction="none")
-    loss_occ = F.binary_cross_entropy(occ_pred, occ, reduction="none").mean(-1)
-    loss = loss_qual + label * (loss_rot + 0.01 * loss_width) + loss_occ
-    loss_dict = {"loss_qual": loss_qual.mean(), "loss_rot": loss_rot.mean(), "loss_width": loss_width.mean(),
-                 "loss_occ": loss_occ.mean(), "loss_all": loss.mean()}
-    return loss.mean(), loss_dict
+    out: the model's 4-tuple for ONE grasp query per scene -- qual (B,1), rot (B,1,4), width (B,1), occupancy logits (B,M);
+    y:   (label (B,), rotations (B,2,4), width (B,), occ (B,M)) as `prepare_batch` builds them (train_giga.py:141-151).
+    Returns (loss, loss_dict) with the reference's keys; `loss` is differentiable w.r.t. the four head outputs."""
+    qual, rot, width, occ = out
+    label, rot_t, width_t, occ_t = y
+    _capi.require_device(qual, rot, width, occ, label, rot_t, width_t, occ_t)
+    B = occ.shape[0]
+    if qual.numel() != B or rot.numel() != 4 * B or width.numel() != B:
+        raise ValueError("giga_loss is the fused form of the literal train_giga call: one grasp query per scene")
+    loss, parts = _GigaLoss.apply(qual, rot, width, occ, label, rot_t, width_t, occ_t)
+    d = {k: parts[i] for i, k in enumerate(LOSS_KEYS[:4])}
+    d["loss_all"] = loss.detach()
+    return loss, d

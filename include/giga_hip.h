@@ -149,6 +149,24 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
                   const float* const* douts, float* grads, size_t n_params, int head_present, int B, int N, int M,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- fused training loss (scripts/train_giga.py:154-195: `select` + `loss_fn`, literal call shape N = 1) -----
+ * Inputs are the head outputs of the model's forward for one grasp query per scene -- qual [B] (post sigmoid), rot [B][4]
+ * (unit), width [B], occ_logits [B][M] (raw; the sigmoid of `select` is part of this function) -- and the labels of
+ * `prepare_batch` (train_giga.py:141-151): label [B], rot_targets [B][2][4], width_target [B], occ_target [B][M].
+ *   giga_train_loss          : losses [5] (device) = means over the batch of loss_qual, loss_rot, loss_width, loss_occ and
+ *                              loss_all = mean(loss_qual + label (loss_rot + 0.01 loss_width) + loss_occ), the `loss_dict`
+ *                              of train_giga.py:169-173; scene_losses [B][5] (device, scratch and per-scene values).
+ *   giga_train_loss_backward : d loss_all / d(qual, rot, width, occ_logits), scaled by the device scalar *grad_loss.
+ * Arithmetic follows ATen's fp32 formulas (BCE logs clamped at -100, BCE gradient (p-y)/max(p(1-p),1e-12)); the mean
+ * over scenes is summed in scene order (deterministic). */
+int giga_train_loss(const float* qual, const float* rot, const float* width, const float* occ_logits, const float* label,
+                    const float* rot_targets, const float* width_target, const float* occ_target, int B, int M,
+                    float* losses, float* scene_losses, void* stream);
+int giga_train_loss_backward(const float* qual, const float* rot, const float* width, const float* occ_logits,
+                             const float* label, const float* rot_targets, const float* width_target,
+                             const float* occ_target, const float* grad_loss, int B, int M, float* dqual, float* drot,
+                             float* dwidth, float* docc, void* stream);
+
 /* ---- grasp post-processing (src/vgn/detection_implicit.py:115-143 process, :87-97 bound, :146-174 select) -----
  * Replaces the host-side scipy stage that follows `predict` in VGNImplicit.__call__ (detection_implicit.py:55-58)
  * for B scenes at once; every volume is [B][R][R][R] float32 (rot: [B][R^3][4]) on the device.

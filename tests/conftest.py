@@ -15,6 +15,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """GPU-marked tests are SKIPPED (not failed) where no HIP device is visible, so a plain `pytest` run in the build
+    container reports real CPU regressions only; on the GPU box nothing is skipped."""
+    try:
+        import torch
+        have_gpu = torch.cuda.is_available()
+    except Exception:  # noqa: BLE001
+        have_gpu = False
+    if have_gpu:
+        return
+    skip = pytest.mark.skip(reason="needs a HIP device (MI355X); run with -m gpu on the GPU box")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

@@ -49,7 +49,7 @@ def test_argument_validation_without_gpu():
         _capi.pack_weights(flat, 15)
     # the flag bits of `precision` / `head_present` are masked before validation; unknown precisions still fail
     assert lib.giga_decoder_forward(None, None, None, 7, None, None, None, None, 0, 5, _capi.FOLD_FINAL, 1, None) == 0
-    assert lib.giga_decoder_forward(None, None, None, 7, None, None, None, None, 1, 5, 2 | _capi.FOLD_FINAL, 1, None) == -5
+    assert lib.giga_decoder_forward(None, None, None, 7, None, None, None, None, 1, 5, 3 | _capi.FOLD_FINAL, 1, None) == -5
     assert lib.giga_encoder_workspace_bytes(4, _capi.FOLD_FINAL) == lib.giga_encoder_workspace_bytes(4, 0)
     assert lib.giga_backward_workspace_bytes(2, 1, 64, 15 | _capi.DETACH_OCC) == lib.giga_backward_workspace_bytes(2, 1, 64, 15)
     # grasp post-processing: null pointers, bad sizes

@@ -7,10 +7,19 @@ import pytest
 import torch
 
 from giga_amd import networks, synth, weights
-from giga_amd.training import loss_fn, select
+from giga_amd.training import giga_loss
 from oracle import giga_oracle as O
 
 pytestmark = pytest.mark.gpu
+
+
+def ref_style_loss(out, y):
+    """The caller-side helpers of scripts/train_giga.py:154-195 (the oracle's restatement, plain torch on the device):
+    what the reference's own training script runs on top of the drop-in network."""
+    return O.train_loss(O.train_select(out), y)
+
+
+LOSSES = {"torch-helpers": ref_style_loss, "fused": giga_loss}
 
 
 def _batch(first, B, M):
@@ -29,7 +38,8 @@ def _oracle_grads(sd, x, pos, pos_occ, y, detach_tsdf=False):
     return loss.item(), {k: v.grad for k, v in sdg.items()}, d
 
 
-def test_train_step_gradients_match_oracle_and_g4(golden, sd7):
+@pytest.mark.parametrize("loss_kind", ["torch-helpers", "fused"])
+def test_train_step_gradients_match_oracle_and_g4(golden, sd7, loss_kind):
     dev = torch.device("cuda:0")
     g4 = golden("g4_train_step.npz")
     B, M, s0 = int(g4["B"]), int(g4["M"]), int(g4["first_scene"])
@@ -39,7 +49,7 @@ def test_train_step_gradients_match_oracle_and_g4(golden, sd7):
     net.load_state_dict(sd7)
     net = net.to(dev).train()
     out = net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev))
-    loss, d = loss_fn(select(out), tuple(t.to(dev) for t in y))
+    loss, d = LOSSES[loss_kind](out, tuple(t.to(dev) for t in y))
     for k in ("loss_qual", "loss_rot", "loss_width", "loss_occ", "loss_all"):
         assert abs(d[k].item() - float(g4[k])) <= 1e-4 * max(1.0, abs(float(g4[k]))), k
     assert abs(loss.item() - ref_loss) < 1e-5
@@ -59,22 +69,112 @@ def test_train_step_gradients_match_oracle_and_g4(golden, sd7):
         assert abs(got_norms[n] - ref) <= 2e-3 * max(ref, 1e-6) + 1e-8, (n, got_norms[n], ref)
 
 
-def test_gradients_at_batch_32(sd7):
+@pytest.mark.parametrize("M,loss_kind", [(96, "torch-helpers"), (2048, "fused")])
+def test_gradients_at_batch_32(sd7, M, loss_kind):
     """From 32 scenes up the conv_in kernels (forward and backward) switch to the one-x-part decomposition; hold that
-    variant's gradients to the oracle too (M kept small: the oracle's CPU autograd runs the whole 32-scene encoder)."""
+    variant's gradients to the oracle too, including the full BASELINE c5 shape (B = 32, M = 2048)."""
     dev = torch.device("cuda:0")
-    x, pos, pos_occ, y = _batch(300, 32, 96)
+    x, pos, pos_occ, y = _batch(300, 32, M)
     ref_loss, ref_grads, _ = _oracle_grads(sd7, x, pos, pos_occ, y)
     net = networks.get_network("giga")
     net.load_state_dict(sd7)
     net = net.to(dev).train()
-    loss, _ = loss_fn(select(net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev))), tuple(t.to(dev) for t in y))
+    loss, _ = LOSSES[loss_kind](net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev)), tuple(t.to(dev) for t in y))
     assert abs(loss.item() - ref_loss) < 1e-5
     loss.backward()
     for name, prm in net.named_parameters():
         ref, got = ref_grads[name], prm.grad.detach().cpu()
         scale = ref.abs().max().item()
         assert (got - ref).abs().max().item() <= 2e-3 * scale + 1e-6, name
+
+
+def test_fused_loss_matches_reference_helpers_g11(golden):
+    """giga_loss (csrc/giga_loss.hip) against golden G11 -- the reference's OWN select + loss_fn on fixed head outputs --
+    and its gradients against autograd through the torch restatement of those helpers."""
+    dev = torch.device("cuda:0")
+    g = golden("g11_train_helpers.npz")
+    B, M, s0 = int(g["B"]), int(g["M"]), int(g["first_scene"])
+    t = torch.from_numpy
+    y = tuple(t(a) for a in synth.train_labels(s0, B, M))
+    heads = [t(g["qual"]), t(g["rot"]), t(g["width"]), t(g["logit"])]
+    hd = [h.clone().to(dev).requires_grad_(True) for h in heads]
+    loss, d = giga_loss(tuple(hd), tuple(a.to(dev) for a in y))
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    for k in ("loss_qual", "loss_rot", "loss_width", "loss_occ", "loss_all"):
+        assert abs(float(d[k]) - float(g[k])) <= 2e-6 * max(1.0, abs(float(g[k]))), k
+    (3.0 * loss).backward()                                  # a non-trivial upstream gradient
+    hc = [h.clone().requires_grad_(True) for h in heads]
+    ref_loss, _ = ref_style_loss(tuple(hc), y)
+    (3.0 * ref_loss).backward()
+    for a, b, name in zip(hd, hc, ("qual", "rot", "width", "occ")):
+        scale = b.grad.abs().max().item()
+        assert (a.grad.cpu() - b.grad).abs().max().item() <= 1e-5 * scale + 1e-9, name
+    # label = 0 scenes get no rotation / width gradient; saturated logits keep ATen's clamped BCE arithmetic
+    z = torch.tensor([[-120.0, -30.0, 0.0, 30.0, 120.0]] * 2)
+    hz = [torch.tensor([[1e-9], [1.0 - 1e-7]]), torch.nn.functional.normalize(torch.randn(2, 1, 4), dim=2), torch.rand(2, 1), z]
+    yz = (torch.tensor([0.0, 1.0]), torch.nn.functional.normalize(torch.randn(2, 2, 4), dim=2), torch.rand(2) * 0.3,
+          torch.tensor([[1.0, 0.0, 1.0, 0.0, 0.0]] * 2))
+    a = [h.clone().to(dev).requires_grad_(True) for h in hz]
+    b = [h.clone().requires_grad_(True) for h in hz]
+    la, _ = giga_loss(tuple(a), tuple(v.to(dev) for v in yz))
+    lb, _ = ref_style_loss(tuple(b), yz)
+    assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
+    la.backward(); lb.backward()
+    for u, v in zip(a, b):
+        assert torch.allclose(u.grad.cpu(), v.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_interleaved_forwards_and_recycled_buffers(sd7):
+    """The large step buffers are recycled.  Two graphs alive at once (same weights) get separate sets and both backward
+    correctly; a second backward through a finished graph, and a backward after the weights were re-packed for a later
+    forward (an optimizer step in between), raise instead of silently using stale data."""
+    dev = torch.device("cuda:0")
+    net = networks.get_network("giga"); net.load_state_dict(sd7); net = net.to(dev).train()
+    x, pos, pos_occ, y = (t.to(dev) if torch.is_tensor(t) else tuple(a.to(dev) for a in t) for t in _batch(70, 2, 64))
+    la, _ = giga_loss(net(x, pos, p_tsdf=pos_occ), y)
+    la.backward()
+    g1 = [p.grad.clone() for p in net.parameters()]
+    with pytest.raises(RuntimeError):
+        la.backward()                                        # autograd / the recycled-buffer check: the graph is spent
+    net.zero_grad(set_to_none=True)
+    l1, _ = giga_loss(net(x, pos, p_tsdf=pos_occ), y)
+    l2, _ = giga_loss(net(x.flip(0), pos.flip(0), p_tsdf=pos_occ.flip(0)), tuple(t.flip(0) for t in y))
+    l1.backward()                                            # the second forward must not have clobbered these activations
+    for p, g in zip(net.parameters(), g1):
+        assert (p.grad - g).abs().max().item() <= 2e-3 * g.abs().max().item() + 1e-6
+    net.zero_grad(set_to_none=True)
+    l2.backward()                                            # same batch with the scenes permuted: same gradients
+    for p, g in zip(net.parameters(), g1):
+        assert (p.grad - g).abs().max().item() <= 2e-3 * g.abs().max().item() + 1e-6
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
+    l3, _ = giga_loss(net(x, pos, p_tsdf=pos_occ), y)
+    opt.step()                                               # weights change ...
+    l4, _ = giga_loss(net(x, pos, p_tsdf=pos_occ), y)        # ... and this forward rebuilds the weight images
+    with pytest.raises(RuntimeError, match="re-packed"):
+        l3.backward()
+    l4.backward()
+
+
+def test_inference_after_fused_adam_steps_uses_the_new_weights(sd7):
+    """torch.optim.Adam(fused=True) updates parameters without bumping their version counters, so the packed-weight cache
+    of the inference path cannot see those steps; the training forward marks it stale instead.  No eval()/train() toggle
+    here on purpose."""
+    dev = torch.device("cuda:0")
+    net = networks.get_network("giga"); net.load_state_dict(sd7); net = net.to(dev)
+    x, pos, pos_occ, y = (t.to(dev) if torch.is_tensor(t) else tuple(a.to(dev) for a in t) for t in _batch(20, 2, 128))
+    with torch.no_grad():
+        before = net(x, pos, p_tsdf=pos_occ)                 # packs + caches the blob
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2, fused=True)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        loss, _ = giga_loss(net(x, pos, p_tsdf=pos_occ), y)
+        loss.backward(); opt.step()
+    with torch.no_grad():
+        after = net(x, pos, p_tsdf=pos_occ)
+        ref = O.model_forward({k: v.detach().cpu() for k, v in net.state_dict().items()}, x.cpu(), pos.cpu(), p_tsdf=pos_occ.cpu())
+    assert (after[3] - before[3]).abs().max().item() > 1e-3      # the weights really moved
+    for a, r in zip(after, ref):
+        assert (a.cpu() - r).abs().max().item() < 1e-4
 
 
 def test_giga_detach_matches_reference_golden_g8(golden, sd7):
@@ -86,7 +186,7 @@ def test_giga_detach_matches_reference_golden_g8(golden, sd7):
     net = networks.get_network("giga_detach")
     net.load_state_dict(sd7)
     net = net.to(dev).train()
-    loss, _ = loss_fn(select(net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev))), tuple(t.to(dev) for t in y))
+    loss, _ = ref_style_loss(net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev)), tuple(t.to(dev) for t in y))
     assert abs(loss.item() - float(g["loss_all"])) < 1e-4
     loss.backward()
     got = {n: p.grad.double().norm().item() for n, p in net.named_parameters()}
@@ -103,7 +203,7 @@ def test_giga_detach_gradients(sd7):
     net = networks.get_network("giga_detach")
     net.load_state_dict(sd7)
     net = net.to(dev).train()
-    loss, _ = loss_fn(select(net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev))), tuple(t.to(dev) for t in y))
+    loss, _ = ref_style_loss(net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev)), tuple(t.to(dev) for t in y))
     assert abs(loss.item() - ref_loss) < 1e-5
     loss.backward()
     differs = 0
@@ -127,7 +227,7 @@ def test_sgd_steps_track_the_oracle(sd7):
     losses, ref_losses = [], []
     for _ in range(3):
         opt.zero_grad()
-        loss, _ = loss_fn(select(net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev))), tuple(t.to(dev) for t in y))
+        loss, _ = ref_style_loss(net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev)), tuple(t.to(dev) for t in y))
         loss.backward(); opt.step(); losses.append(loss.item())
         rl, rg, _ = _oracle_grads(sd, x, pos, pos_occ, y)
         sd = {k: v - 1e-2 * rg[k] for k, v in sd.items()}
@@ -153,7 +253,7 @@ def test_training_steps_do_not_accumulate_device_memory(sd7):
         seen = []
         for _ in range(6):
             opt.zero_grad(set_to_none=True)
-            loss, _ = loss_fn(select(net(x, pos, p_tsdf=pos_occ)), y)
+            loss, _ = giga_loss(net(x, pos, p_tsdf=pos_occ), y)
             loss.backward()
             opt.step()
             del loss

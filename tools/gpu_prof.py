@@ -72,7 +72,7 @@ with torch.no_grad():
                 print(prec, "B", Bt, "stage us:", out, "sum", round(sum(out), 1), "wall/iter us", round((time.perf_counter() - t0) / 10 * 1e6, 1))
 
 if what == "train":
-    from giga_amd.training import loss_fn, select
+    from giga_amd.training import giga_loss
     net.train()
     x = torch.from_numpy(synth.tsdf_batch(0, B)).to(dev); pos = torch.from_numpy(synth.query_points(0, B, 1, stream=2)).to(dev)
     pos_occ = torch.from_numpy(synth.query_points(0, B, 2048, stream=3)).to(dev)
@@ -80,6 +80,6 @@ if what == "train":
     opt = torch.optim.Adam(net.parameters(), lr=2e-4, fused=True)
     def step():
         opt.zero_grad(set_to_none=True)
-        loss, _ = loss_fn(select(net(x, pos, p_tsdf=pos_occ)), y)
+        loss, _ = giga_loss(net(x, pos, p_tsdf=pos_occ), y)
         loss.backward(); opt.step()
     run(step)
