@@ -276,25 +276,51 @@ def _planes_to_nhwc(c_plane, precision):
 
 
 # ---- the fixed inference lattice (detection_implicit.py:28-31) -------------------------------------
-# `giga_amd.detection.query_lattice()` registers the tensors it builds here; when such a tensor is
-# passed as the query points, the decoder takes the lattice fast path (giga_decoder_forward_lattice).
-_LATTICES = {}          # id(tensor) -> (weakref(tensor), lin (R,) fp32 on the same device, R)
+# A query tensor of shape (1, R^3, 3) that is meshgrid(lin, lin, lin, 'ij') with z fastest is shared by all scenes and
+# takes the lattice fast path (giga_decoder_forward_lattice).  `giga_amd.detection.query_lattice()` registers the tensors
+# it builds; any other tensor of that shape -- e.g. the reference's own `VGNImplicit.pos`, built by its own constructor and
+# handed in through the one-line network switch of INTEGRATION.md -- is recognised FROM ITS DATA, once per tensor object
+# and version (one small comparison kernel + a host sync, then cached; negative results are cached too).
+_LATTICES = {}          # id(tensor) -> (weakref(tensor), version, (lin (R,) fp32 on the same device, R) or None)
 _LATTICE_WS = {}
+LATTICE_STATS = {"fast": 0, "generic": 0, "detected": 0}     # decode_heads launches per path (tests, diagnostics)
+
+
+def _remember_lattice(points, result):
+    import weakref
+    key = id(points)
+    _LATTICES[key] = (weakref.ref(points, lambda _r, k=key: _LATTICES.pop(k, None)), points._version, result)
 
 
 def register_lattice(points, lin):
-    import weakref
-    key = id(points)
-    _LATTICES[key] = (weakref.ref(points, lambda _r, k=key: _LATTICES.pop(k, None)),
-                      lin.to(points.device, torch.float32).contiguous(), int(lin.numel()))
+    _remember_lattice(points, (lin.to(points.device, torch.float32).contiguous(), int(lin.numel())))
     return points
 
 
-def _lattice_of(p):
-    ent = _LATTICES.get(id(p))
-    if ent is None or ent[0]() is not p or not p.is_cuda:
+def _detect_lattice(p):
+    """(lin, R) if p (1, R^3, 3) is exactly meshgrid(lin, lin, lin, indexing='ij') flattened with z fastest, else None."""
+    n = p.shape[1]
+    R = round(n ** (1.0 / 3.0))
+    if p.shape[0] != 1 or R < 8 or R > 64 or R * R * R != n or p.dtype != torch.float32 or not p.is_contiguous():
         return None
-    return ent[1], ent[2]
+    g = p[0].view(R, R, R, 3)
+    lin = g[:, 0, 0, 0]
+    ok = (g[..., 0] == lin[:, None, None]) & (g[..., 1] == lin[None, :, None]) & (g[..., 2] == lin[None, None, :])
+    if not bool(ok.all()):                                   # host sync: once per tensor object and version
+        return None
+    LATTICE_STATS["detected"] += 1
+    return lin.clone().contiguous(), R
+
+
+def _lattice_of(p):
+    if not p.is_cuda or p.dim() != 3 or p.shape[0] != 1:
+        return None
+    ent = _LATTICES.get(id(p))
+    if ent is not None and ent[0]() is p and ent[1] == p._version:
+        return ent[2]
+    res = _detect_lattice(p)
+    _remember_lattice(p, res)
+    return res
 
 
 def decode_heads(nhwc, p, blob, head_mask, precision, post, probe=None, folded=False):
@@ -321,6 +347,7 @@ def decode_heads(nhwc, p, blob, head_mask, precision, post, probe=None, folded=F
     if head_mask & 8:
         out["decoder_tsdf"] = torch.empty((B, N), device=dev)
     ev0, ev1 = probe if probe is not None else (None, None)
+    LATTICE_STATS["fast" if lat is not None else "generic"] += 1
     if lat is not None:
         lin, R = lat
         prec = _capi.PRECISION[precision]

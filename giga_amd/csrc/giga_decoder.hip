@@ -13,6 +13,9 @@
 // operand of the next layer for a permuted contraction order that is baked into the packed weights,
 // so the whole 11-layer chain runs without any cross-lane traffic.  The fp32 residual stream lives
 // in the accumulator (C-in = stream), biases ride in a constant-one k-slot or in the C operand.
+#include <cstdlib>
+#include <type_traits>
+
 #include "giga_dev.h"
 #include "giga_args.h"
 
@@ -302,21 +305,28 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16_kernel(DecArgs a) {
 // costs a few percent of the 162-MFMA chain.  8 waves of T = 2 tiles.
 constexpr int DEC16S_CHUNKS = (int)(DEC16S_BYTES / FRAG);    // 111
 
-template <int T, bool LATTICE, int NW>
+// SPLIT = false runs the same head-resident structure with single f16 operands (the plain f16 image of 59 KiB, f16 planes):
+// it serves small launches of the fp16 mode, where decoder_f16_kernel's shared-feature rounds leave most CUs idle.
+template <int T, bool LATTICE, int NW, bool SPLIT>
 __global__ __launch_bounds__(NW * 64) void decoder_f16s_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int NCH = SPLIT ? DEC16S_CHUNKS : DEC16_CHUNKS;
+    constexpr int NFR = SPLIT ? DEC16S_FRAGS : DEC16_FRAGS;
+    constexpr int BLK = SPLIT ? DEC16S_BLK : 11;               // fragments per block
+    constexpr int PR = SPLIT ? 2 : 1;                          // fragments per weight chunk ([hi, lo] pair or single)
+    constexpr int F_AUX = 6 * PR, F_FC0 = F_AUX + 1, F_FC1 = F_FC0 + 2 * PR, F_TAIL = NBLK * BLK, F_OUT = F_TAIL + 1;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, hi = lane >> 5;
     const int hsel = blockIdx.x % a.nheads, slot = blockIdx.x / a.nheads, slots = gridDim.x / a.nheads;
-    dma_head_image<NW, DEC16S_CHUNKS>(a.blob + a.head_off[hsel], smem, wave, lane);
+    dma_head_image<NW, NCH>(a.blob + a.head_off[hsel], smem, wave, lane);
 
     const long long tiles_total = (a.P + 31) / 32;
     const long long tile_lo = tiles_total * slot / slots;
     const long long tile_hi = tiles_total * (slot + 1) / slots;
     const half8* W = reinterpret_cast<const half8*>(smem);
-    const float* ctab = reinterpret_cast<const float*>(smem + (size_t)DEC16S_FRAGS * FRAG);
-    const size_t plane_stride = LATTICE ? (size_t)a.B * a.R * a.R * CD : (size_t)a.B * RES * RES * CD;   // elements (4 B each)
+    const float* ctab = reinterpret_cast<const float*>(smem + (size_t)NFR * FRAG);
+    const size_t plane_stride = LATTICE ? (size_t)a.B * a.R * a.R * CD : (size_t)a.B * RES * RES * CD;   // in features
 
     half8 cfh[T][6], cfl[T][6], ax[T];
     long long gidx[T];
@@ -339,18 +349,28 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16s_kernel(DecArgs a) {
                     const int ix = div_magic(rs[t], a.mR2), rz = rs[t] - ix * R2;
                     const int iy = div_magic(rz, a.mR), iz = rz - iy * R;
                     pxs[t] = a.lin[ix]; pys[t] = a.lin[iy]; pzs[t] = a.lin[iz];
-                    // split planes: pixel = 4 groups of 8 channels x [8 hi halfs | 8 lo halfs]; chunk c = 2*pl + hf of lane
-                    // half `hi` is group 2*hf + hi of plane pl  ->  one 32-byte read per chunk
-                    const half_t* base = reinterpret_cast<const half_t*>(a.planes) + 2 * ((size_t)bs[t] * R2 * CD) + 16 * hi;
                     const int off[3] = {iz * R + ix, iy * R + ix, iz * R + iy};   // (H,W): xz->(z,x) xy->(y,x) yz->(z,y)
+                    if constexpr (SPLIT) {
+                        // split planes: pixel = 4 groups of 8 channels x [8 hi halfs | 8 lo halfs]; chunk c = 2*pl + hf of lane
+                        // half `hi` is group 2*hf + hi of plane pl  ->  one 32-byte read per chunk
+                        const half_t* base = reinterpret_cast<const half_t*>(a.planes) + 2 * ((size_t)bs[t] * R2 * CD) + 16 * hi;
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                        for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                        for (int hf = 0; hf < 2; ++hf) {
-                            const half_t* q = base + 2 * (pl * plane_stride + (size_t)off[pl] * CD) + 32 * hf;
-                            cfh[t][2 * pl + hf] = *reinterpret_cast<const half8*>(q);
-                            cfl[t][2 * pl + hf] = *reinterpret_cast<const half8*>(q + 8);
-                        }
+                            for (int hf = 0; hf < 2; ++hf) {
+                                const half_t* q = base + 2 * (pl * plane_stride + (size_t)off[pl] * CD) + 32 * hf;
+                                cfh[t][2 * pl + hf] = *reinterpret_cast<const half8*>(q);
+                                cfl[t][2 * pl + hf] = *reinterpret_cast<const half8*>(q + 8);
+                            }
+                    } else {
+                        const half_t* base = reinterpret_cast<const half_t*>(a.planes) + (size_t)bs[t] * R2 * CD + 8 * hi;
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                            for (int hf = 0; hf < 2; ++hf)
+                                cfh[t][2 * pl + hf] = *reinterpret_cast<const half8*>(base + pl * plane_stride +
+                                                                                      (size_t)off[pl] * CD + 16 * hf);
+                    }
                 } else {
                     pxs[t] = a.p[3 * g + 0]; pys[t] = a.p[3 * g + 1]; pzs[t] = a.p[3 * g + 2];
                 }
@@ -369,12 +389,12 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16s_kernel(DecArgs a) {
                 ax[t] = av;
             }
             if constexpr (!LATTICE) {
-                // ---------------- generic gather on fp32 planes: per (tile, plane, channel half) the lane's 8 channels of the
-                // 4 bilinear taps (8 x 16 B), interpolated in fp32 in aten's tap order, then split.  Software pipeline of
-                // depth 3 groups (24 loads in flight per lane).
-                const float* planes = reinterpret_cast<const float*>(a.planes);
+                // ---------------- generic gather: per (tile, plane, channel half) the lane's 8 channels of the 4 bilinear
+                // taps, interpolated in fp32 in aten's tap order, then split (or rounded).  Software pipeline of DEPTH groups.
+                typedef typename std::conditional<SPLIT, float, half_t>::type PT;
+                const PT* planes = reinterpret_cast<const PT*>(a.planes);
                 Bilin bl[T][3];
-                const float* pbase[T];
+                const PT* pbase[T];
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     const float nx = norm_coord(pxs[t]), ny = norm_coord(pys[t]), nz = norm_coord(pzs[t]);
@@ -383,17 +403,18 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16s_kernel(DecArgs a) {
                     bl[t][2] = bilin_setup(ny, nz);
                     pbase[t] = planes + (size_t)bs[t] * RES * RES * CD + 8 * hi;
                 }
-                constexpr int NG = T * 6, DEPTH = 3;
-                float4 raw[NG][4][2];
+                constexpr int NG = T * 6, DEPTH = SPLIT ? 3 : 6;
+                constexpr int VPT = SPLIT ? 2 : 1;            // 16-byte vectors per tap
+                uint4 raw[NG][4][VPT];
                 auto issue = [&](int k) {
                     const int t = k / 6, pl = (k % 6) / 2, hf = k % 2;
-                    const float* base = pbase[t] + pl * plane_stride + 16 * hf;
+                    const PT* base = pbase[t] + pl * plane_stride + 16 * hf;
                     const int o[4] = {bl[t][pl].o00, bl[t][pl].o01, bl[t][pl].o10, bl[t][pl].o11};
 #pragma unroll
-                    for (int tp = 0; tp < 4; ++tp) {
-                        raw[k][tp][0] = *reinterpret_cast<const float4*>(base + (size_t)o[tp] * CD);
-                        raw[k][tp][1] = *reinterpret_cast<const float4*>(base + (size_t)o[tp] * CD + 4);
-                    }
+                    for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+                        for (int q = 0; q < VPT; ++q)
+                            raw[k][tp][q] = *reinterpret_cast<const uint4*>(base + (size_t)o[tp] * CD + q * (16 / sizeof(PT)));
                 };
 #pragma unroll
                 for (int k = 0; k < DEPTH; ++k) issue(k);
@@ -403,15 +424,30 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16s_kernel(DecArgs a) {
                     const int t = k / 6, pl = (k % 6) / 2;
                     const Bilin& B4 = bl[t][pl];
                     float v[8];
+                    if constexpr (SPLIT) {
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const float4 v00 = raw[k][0][q], v01 = raw[k][1][q], v10 = raw[k][2][q], v11 = raw[k][3][q];
-                        v[4 * q + 0] = fmaf(v11.x, B4.w11, fmaf(v10.x, B4.w10, fmaf(v01.x, B4.w01, v00.x * B4.w00)));
-                        v[4 * q + 1] = fmaf(v11.y, B4.w11, fmaf(v10.y, B4.w10, fmaf(v01.y, B4.w01, v00.y * B4.w00)));
-                        v[4 * q + 2] = fmaf(v11.z, B4.w11, fmaf(v10.z, B4.w10, fmaf(v01.z, B4.w01, v00.z * B4.w00)));
-                        v[4 * q + 3] = fmaf(v11.w, B4.w11, fmaf(v10.w, B4.w10, fmaf(v01.w, B4.w01, v00.w * B4.w00)));
+                        for (int q = 0; q < 2; ++q) {
+                            const f32x4 v00 = __builtin_bit_cast(f32x4, raw[k][0][q]), v01 = __builtin_bit_cast(f32x4, raw[k][1][q]);
+                            const f32x4 v10 = __builtin_bit_cast(f32x4, raw[k][2][q]), v11 = __builtin_bit_cast(f32x4, raw[k][3][q]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                v[4 * q + e] = fmaf(v11[e], B4.w11, fmaf(v10[e], B4.w10, fmaf(v01[e], B4.w01, v00[e] * B4.w00)));
+                        }
+                        split8(v, cfh[t][k % 6], cfl[t][k % 6]);
+                    } else {
+                        const half8 h00 = __builtin_bit_cast(half8, raw[k][0][0]), h01 = __builtin_bit_cast(half8, raw[k][1][0]);
+                        const half8 h10 = __builtin_bit_cast(half8, raw[k][2][0]), h11 = __builtin_bit_cast(half8, raw[k][3][0]);
+                        half8 r;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            float acc = (float)h00[j] * B4.w00;
+                            acc = fmaf((float)h01[j], B4.w01, acc);
+                            acc = fmaf((float)h10[j], B4.w10, acc);
+                            acc = fmaf((float)h11[j], B4.w11, acc);
+                            r[j] = (half_t)acc;
+                        }
+                        cfh[t][k % 6] = r;
                     }
-                    split8(v, cfh[t][k % 6], cfl[t][k % 6]);
                     if (k + DEPTH < NG) issue(k + DEPTH);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -422,25 +458,38 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16s_kernel(DecArgs a) {
             __syncthreads();                                  // everyone's share (all waves run iteration 0)
         }
         if (!has) break;
-        // ---------------- the chain: fragment indices per block b: fc_c 21b + 2c (+1 = lo), aux 21b + 12,
-        // fc_0 21b + 13 + 2c, fc_1 21b + 17 + 2c; tail aux 105, fc_out 106 + 2c
+        // ---------------- the chain.  Fragment indices per block b (PR = fragments per chunk): fc_c BLK*b + PR*c, aux
+        // BLK*b + 6*PR, fc_0 .. + 1 + PR*c, fc_1 .. + 1 + 2*PR + PR*c; tail aux NBLK*BLK, fc_out + 1 + PR*c
         f32x16 net[T], hh[T];
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) net[t][r] = 0.f;
+        // acc[t] += W(frag) * X[t]  for one k-chunk: three MFMAs on [hi, lo] pairs, one on single operands
+        auto mm = [&](int frag, const half8 (&xh)[T], const half8 (&xl)[T], f32x16 (&acc)[T]) {
+            const half8 Ah = W[frag * 64 + lane];
+            if constexpr (SPLIT) {
+                const half8 Al = W[(frag + 1) * 64 + lane];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    acc[t] = mfma16(Al, xh[t], acc[t]);
+                    acc[t] = mfma16(Ah, xl[t], acc[t]);
+                    acc[t] = mfma16(Ah, xh[t], acc[t]);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < T; ++t) acc[t] = mfma16(Ah, xh[t], acc[t]);
+            }
+        };
         auto fc_c = [&](int blk) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                const half8 Ah = W[(DEC16S_BLK * blk + 2 * c) * 64 + lane], Al = W[(DEC16S_BLK * blk + 2 * c + 1) * 64 + lane];
+                half8 xh[T], xl[T];
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    net[t] = mfma16(Al, cfh[t][c], net[t]);
-                    net[t] = mfma16(Ah, cfl[t][c], net[t]);
-                    net[t] = mfma16(Ah, cfh[t][c], net[t]);
-                }
+                for (int t = 0; t < T; ++t) { xh[t] = cfh[t][c]; xl[t] = cfl[t][c]; }
+                mm(BLK * blk + PR * c, xh, xl, net);
             }
-            const half8 A = W[(DEC16S_BLK * blk + 12) * 64 + lane];
+            const half8 A = W[(BLK * blk + F_AUX) * 64 + lane];
 #pragma unroll
             for (int t = 0; t < T; ++t) net[t] = mfma16(A, ax[t], net[t]);
         };
@@ -453,23 +502,18 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16s_kernel(DecArgs a) {
             }
             return c0;
         };
-        // dst[t] += Wpair(frag0 + 2c) * split(relu(src[t]))
+        // dst[t] += W(frag0 + PR*c) * relu(src[t])
         auto dense = [&](int frag0, const f32x16 (&src)[T], f32x16 (&dst)[T]) {
-            half8 xh[T][2], xl[T][2];
+            half8 xh[2][T], xl[2][T];
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) split_relu8(src[t], c, xh[t][c], xl[t][c]);
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const half8 Ah = W[(frag0 + 2 * c) * 64 + lane], Al = W[(frag0 + 2 * c + 1) * 64 + lane];
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    dst[t] = mfma16(Al, xh[t][c], dst[t]);
-                    dst[t] = mfma16(Ah, xl[t][c], dst[t]);
-                    dst[t] = mfma16(Ah, xh[t][c], dst[t]);
+                for (int c = 0; c < 2; ++c) {
+                    if constexpr (SPLIT) split_relu8(src[t], c, xh[c][t], xl[c][t]);
+                    else xh[c][t] = pack_relu8(src[t], c);
                 }
-            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) mm(frag0 + PR * c, xh[c], xl[c], dst);
         };
         fc_c(0);
 #pragma unroll
@@ -477,23 +521,23 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16s_kernel(DecArgs a) {
             const f32x16 c0 = ctab_regs(blk);
 #pragma unroll
             for (int t = 0; t < T; ++t) hh[t] = c0;
-            dense(DEC16S_BLK * blk + 13, net, hh);            // hh = fc_0(relu(net)) + b0
+            dense(BLK * blk + F_FC0, net, hh);                // hh = fc_0(relu(net)) + b0
             // every term of the residual stream is an accumulation, so the next block's fc_c (+ folded biases) is issued
-            // here, where it covers the split of hh
+            // here, where it covers the conversion of hh
             if (blk + 1 < NBLK) fc_c(blk + 1);
             else {
-                const half8 A = W[(DEC16S_BLK * NBLK) * 64 + lane];       // tail aux: fc_1 bias of the last block
+                const half8 A = W[F_TAIL * 64 + lane];       // tail aux: fc_1 bias of the last block
 #pragma unroll
                 for (int t = 0; t < T; ++t) net[t] = mfma16(A, ax[t], net[t]);
             }
-            dense(DEC16S_BLK * blk + 17, hh, net);            // net += fc_1(relu(hh))
+            dense(BLK * blk + F_FC1, hh, net);                // net += fc_1(relu(hh))
         }
         {
             const f32x16 c0 = ctab_regs(NBLK);
             f32x16 o[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) o[t] = c0;
-            dense(DEC16S_BLK * NBLK + 1, net, o);             // fc_out(relu(net))
+            dense(F_OUT, net, o);                             // fc_out(relu(net))
 #pragma unroll
             for (int t = 0; t < T; ++t)
                 if (hi == 0 && valid[t]) store_head(a, hsel, gidx[t], o[t][0], o[t][1], o[t][2], o[t][3]);
@@ -827,22 +871,36 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
         a.mR = (unsigned)((0x100000000ULL + a.R - 1) / a.R);
         a.mR2 = (unsigned)((0x100000000ULL + (unsigned long long)a.R * a.R - 1) / ((unsigned long long)a.R * a.R));
     }
-    if (precision == 2) {
-        // f16x3 split: head-resident workgroups, grid = slots x nheads <= 256 (one per CU).  Two tiles per wave (the weight
-        // fragments of an MFMA triple are read from LDS once per two tiles) when every workgroup gets at least two such
-        // rounds; smaller problems take one tile per wave so that twice as many CUs share the work.
-        constexpr int NW = 8;
+    // Head-resident kernel: always for the f16x3 split mode; for plain f16 when the launch is small (the shared-feature
+    // kernel below walks rounds of NW*T tiles per workgroup with all heads on the same CU: a single scene's 2000 tiles then
+    // keep only 84 CUs busy: 31.6 -> 16.3 us for the three grasp heads of one scene's 64 000 lattice points; from ~8 scenes
+    // up the shared-feature kernel is the faster one, 297 vs 323 us at 32 scenes).  grid = slots x nheads <= 256 (one workgroup per CU).  Two tiles per wave (the weight fragments
+    // are read from LDS once per two tiles) when every workgroup gets at least two such rounds, else one tile per wave.
+    // (tuning knob, read once: GIGA_DEC16_RESIDENT=0/1 forces the choice for plain f16; measurements in DESIGN.md)
+    static const int force_resident = [] { const char* e = getenv("GIGA_DEC16_RESIDENT"); return e ? atoi(e) : -1; }();
+    const bool resident = precision == 2 ||
+                          (precision == 1 && (force_resident >= 0 ? force_resident != 0 : tiles * a.nheads < (lat ? 16000 : 6000)));
+    if (resident) {
         const int cap = 256 / a.nheads;
-        const bool two = tiles >= 2LL * cap * NW * 2;
-        const int per_round = NW * (two ? 2 : 1);
-        int slots = (int)((tiles + per_round - 1) / per_round);
-        if (slots > cap) slots = cap;
-        a.nbatch = slots;
-        auto kern = two ? (lat ? decoder_f16s_kernel<2, true, NW> : decoder_f16s_kernel<2, false, NW>)
-                        : (lat ? decoder_f16s_kernel<1, true, NW> : decoder_f16s_kernel<1, false, NW>);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)DEC16S_BYTES);
-        hipLaunchKernelGGL(kern, dim3(slots * a.nheads), dim3(NW * 64), DEC16S_BYTES, s, a);
+        auto go = [&](auto kern, int NW, int T, size_t lds) {
+            const int per_round = NW * T;
+            int slots = (int)((tiles + per_round - 1) / per_round);
+            if (slots > cap) slots = cap;
+            a.nbatch = slots;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(slots * a.nheads), dim3(NW * 64), lds, s, a);
+        };
+        if (precision == 2) {
+            constexpr int NW = 8;
+            const bool two = tiles >= 2LL * cap * NW * 2;
+            if (two) { if (lat) go(decoder_f16s_kernel<2, true, NW, true>, NW, 2, DEC16S_BYTES); else go(decoder_f16s_kernel<2, false, NW, true>, NW, 2, DEC16S_BYTES); }
+            else { if (lat) go(decoder_f16s_kernel<1, true, NW, true>, NW, 1, DEC16S_BYTES); else go(decoder_f16s_kernel<1, false, NW, true>, NW, 1, DEC16S_BYTES); }
+        } else {
+            // plain f16: 112-142 VGPRs with one tile per wave (12 waves), 2 tiles need the 256-register budget (8 waves)
+            const bool two = tiles >= 2LL * cap * 8 * 2;
+            if (two) { if (lat) go(decoder_f16s_kernel<2, true, 8, false>, 8, 2, DEC16_BYTES); else go(decoder_f16s_kernel<2, false, 8, false>, 8, 2, DEC16_BYTES); }
+            else { if (lat) go(decoder_f16s_kernel<1, true, 12, false>, 12, 1, DEC16_BYTES); else go(decoder_f16s_kernel<1, false, 12, false>, 12, 1, DEC16_BYTES); }
+        }
     } else if (precision == 1 && lat) {
         // lattice variant: 155 VGPRs -> 12 waves (3 per SIMD, phases 0/1/2 over the heads)
         constexpr int T = 2, NW = 12;

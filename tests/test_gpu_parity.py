@@ -124,6 +124,38 @@ def test_lattice_fast_path_equals_generic_path(net, dev, sd7, prec, tol):
     net.set_precision("fp32")
 
 
+def test_unregistered_reference_lattice_is_detected_from_data(net, dev, sd7):
+    """The reference's own VGNImplicit builds its query lattice itself (detection_implicit.py:28-31) and hands it to the
+    network; that tensor was never registered with giga_amd, yet it must take the lattice fast path (recognised from its
+    data, once per tensor), while a tensor of the same shape that is NOT a lattice takes the generic gather."""
+    from giga_amd import convonet
+    net.set_precision("fp32")
+    R = 40
+    lin = torch.linspace(start=-0.5, end=0.5 - 1.0 / R, steps=R)              # detection_implicit.py:28-31, verbatim recipe
+    x_, y_, z_ = torch.meshgrid(lin, lin, lin, indexing="ij")
+    pos = torch.stack((x_, y_, z_), dim=-1).float().unsqueeze(0).to(dev).view(1, R * R * R, 3)
+    x = torch.from_numpy(synth.tsdf_batch(11, 1)).to(dev)
+    before = dict(convonet.LATTICE_STATS)
+    with torch.no_grad():
+        fast = net(x, pos)
+        again = net(x, pos)                                  # cached: no second detection
+        bent = pos.clone(); bent[0, 12345, 1] += 1e-3        # same shape, not a lattice
+        slow = net(x, bent)
+        ref = O.model_forward(sd7, x.cpu(), pos.cpu())
+    after = convonet.LATTICE_STATS
+    assert after["fast"] - before["fast"] == 2 and after["detected"] - before["detected"] == 1
+    assert after["generic"] - before["generic"] == 1
+    for a, b, c, r in zip(fast, again, slow, ref):
+        assert torch.equal(a, b)
+        assert maxerr(a, r) < 1e-4
+        keep = torch.ones(R ** 3, dtype=torch.bool); keep[12345] = False
+        assert maxerr(a[0][keep.to(dev)], c[0][keep.to(dev)].cpu()) < 2e-5
+    pos[0, 7, 0] += 0.25                                     # an in-place edit bumps the version: re-checked, now generic
+    with torch.no_grad():
+        net(x, pos)
+    assert convonet.LATTICE_STATS["generic"] - before["generic"] == 2
+
+
 @pytest.mark.parametrize("prec", ["fp32", "fp16x3"])
 def test_edge_cases_g5(net, dev, sd7, golden, prec):
     net.set_precision(prec)
