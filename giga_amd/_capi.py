@@ -54,6 +54,11 @@ _SIGNATURES = {
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "giga_host_register": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t]),
+    "giga_host_unregister": (ctypes.c_int, [ctypes.c_void_p]),
+    "giga_tsdf_scatter_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "giga_tsdf_scatter": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "giga_train_loss": (ctypes.c_int, [ctypes.c_void_p] * 8 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                                                ctypes.c_void_p]),
     "giga_train_loss_backward": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5),

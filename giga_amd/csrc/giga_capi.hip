@@ -30,6 +30,9 @@ int launch_train_loss_backward(const float* qual, const float* rot, const float*
                                const float* label, const float* rot_t, const float* width_t, const float* occ_t,
                                const float* gout, int B, int M, float* dqual, float* drot, float* dwidth, float* docc,
                                hipStream_t s);
+// giga_tsdf.hip
+int launch_tsdf_scatter(const int* index, const float* value, const int* offsets, int B, int R, int n, float* grid,
+                        int* winner, hipStream_t s);
 // giga_encoder.hip
 struct EncWs { size_t P0, A0, S0, Q0, A1, S1, Q1, A2, S2, U0, A3, A4, U1, A5, A6, YZ, XZ, total; };
 EncWs enc_workspace(int B, int precision);
@@ -309,6 +312,32 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
     rc |= launch_encoder_backward(tsdf, blob, bblob, static_cast<const uint8_t*>(enc_workspace_fwd), gplanes, gws,
                                   grads, head_present, B, s);
     return rc;
+}
+
+/* page-lock (and map for DMA) a host range the caller owns, e.g. a shared-memory batch ring written by reader processes */
+int giga_host_register(void* ptr, size_t bytes) {
+    if (!ptr || bytes == 0) return -1;
+    return hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess ? 0 : -10;
+}
+int giga_host_unregister(void* ptr) {
+    if (!ptr) return -1;
+    return hipHostUnregister(ptr) == hipSuccess ? 0 : -10;
+}
+
+size_t giga_tsdf_scatter_workspace_bytes(int B, int R) {
+    if (B <= 0 || R <= 0) return 0;
+    return (size_t)B * R * R * R * sizeof(int32_t);
+}
+
+int giga_tsdf_scatter(const int32_t* voxel_index, const float* voxel_value, const int32_t* scene_offsets, int B, int R,
+                      int n_voxels, float* grid, void* workspace, size_t workspace_bytes, void* stream) {
+    if (B < 0 || R <= 0 || R > 1024 || n_voxels < 0) return -1;
+    if (B == 0) return 0;
+    if (!grid || !scene_offsets) return -1;
+    if (n_voxels > 0 && (!voxel_index || !voxel_value || !workspace)) return -1;
+    if (n_voxels > 0 && workspace_bytes < giga_tsdf_scatter_workspace_bytes(B, R)) return -4;
+    return launch_tsdf_scatter(voxel_index, voxel_value, scene_offsets, B, R, n_voxels, grid, static_cast<int*>(workspace),
+                               static_cast<hipStream_t>(stream));
 }
 
 int giga_train_loss(const float* qual, const float* rot, const float* width, const float* occ_logits, const float* label,

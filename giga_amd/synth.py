@@ -4,6 +4,9 @@ TSDF grids are U[0,1) float32 (Open3D's TSDF export range, reference perception.
 an optional "realistic" variant zeroes ~60 % of the voxels (0 = unobserved).  Query points are
 U[-0.5,0.5)^3 (optionally widened to exercise both clamps of normalize_coordinate).
 """
+import json
+import os
+
 import numpy as np
 
 RES = 40
@@ -85,3 +88,35 @@ def post_volumes(seed, R=RES):
     rot /= np.linalg.norm(rot, axis=-1, keepdims=True)
     width = rng.uniform(0.0, 0.3, (R, R, R)).astype(np.float32)
     return tsdf, qual, rot, width
+
+
+# ---- a synthetic training set in the reference's on-disk layout ---------------------------------------------------
+# scenes/<id>.npz ("grid"), grasps.csv, setup.json, occ/<id>/*.npz ("points", "occ"): the files vgn.io.write_voxel_grid
+# (io.py:88-90), write_grasp (:56-69), write_setup (:11-17) and the occupancy generator produce.  Read back by
+# giga_amd.dataset.GraspOccDataset (and by the reference's DatasetVoxelOccFile in the parity tests).
+def write_training_set(root, raw_root, n_scenes=6, grasps_per_scene=5, occ_files=(1, 3), n_occ_points=300, seed=0, size=0.3):
+    rng = np.random.default_rng([606, seed])
+    os.makedirs(os.path.join(root, "scenes"), exist_ok=True)
+    os.makedirs(raw_root, exist_ok=True)
+    rows = []
+    for s in range(n_scenes):
+        sid = f"scene{seed:02d}_{s:04d}"
+        np.savez_compressed(os.path.join(root, "scenes", sid + ".npz"), grid=tsdf_scene(1000 * seed + s, realistic=True)[None])
+        d = os.path.join(raw_root, "occ", sid)
+        os.makedirs(d, exist_ok=True)
+        for f in range(int(rng.integers(occ_files[0], occ_files[1] + 1))):
+            pts = (rng.random((n_occ_points, 3)) * size).astype(np.float32)
+            np.savez(os.path.join(d, f"{f:04d}.npz"), points=pts, occ=rng.random(n_occ_points) < 0.3)
+        for _ in range(grasps_per_scene):
+            q = rng.normal(size=4); q /= np.linalg.norm(q)
+            rows.append((sid, *q, *(rng.random(3) * size), rng.uniform(0.02, 0.08), int(rng.random() < 0.5)))
+    order = rng.permutation(len(rows))
+    with open(os.path.join(raw_root, "grasps.csv"), "w") as f:
+        f.write("scene_id,qx,qy,qz,qw,x,y,z,width,label\n")
+        for i in order:
+            r = rows[i]
+            f.write(",".join([r[0]] + [repr(float(v)) for v in r[1:9]] + [str(r[9])]) + "\n")
+    with open(os.path.join(raw_root, "setup.json"), "w") as f:
+        json.dump({"size": size, "intrinsic": {"width": 640, "height": 480, "K": [540.0, 0.0, 320.0, 0.0, 540.0, 240.0, 0.0, 0.0, 1.0]},
+                   "max_opening_width": 0.08, "finger_depth": 0.05}, f)
+    return len(rows)

@@ -149,6 +149,22 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
                   const float* const* douts, float* grads, size_t n_params, int head_present, int B, int N, int M,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- input side: page-locking of caller-owned host memory (hipHostRegister / hipHostUnregister), so that batches which
+ * reader processes assemble in a shared-memory ring are DMA-ed to the device without a staging copy
+ * (giga_amd/feed.py; replaces the pageable `.to(device)` of train_giga.py:141-151). */
+int giga_host_register(void* ptr, size_t bytes);
+int giga_host_unregister(void* ptr);
+
+/* ---- input side: dense export of a sparse TSDF (src/vgn/perception.py:107-115, TSDFVolume.get_grid) -----
+ * voxel_index [n][3] int32 (grid_index i, j, k) and voxel_value [n] float32 (voxel.color[0]) list the observed voxels of B
+ * scenes back to back; scene b owns voxels scene_offsets[b] .. scene_offsets[b+1]-1 (scene_offsets [B+1], device).
+ * grid [B][R][R][R] float32 receives 0 for unobserved cells and the value of the LAST voxel of the list that targets a
+ * cell (the Python loop's semantics; Open3D's lists have unique indices).  Indices outside [0, R) are ignored.
+ * workspace: giga_tsdf_scatter_workspace_bytes(B, R) bytes of device scratch. */
+size_t giga_tsdf_scatter_workspace_bytes(int B, int R);
+int giga_tsdf_scatter(const int32_t* voxel_index, const float* voxel_value, const int32_t* scene_offsets, int B, int R,
+                      int n_voxels, float* grid, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- fused training loss (scripts/train_giga.py:154-195: `select` + `loss_fn`, literal call shape N = 1) -----
  * Inputs are the head outputs of the model's forward for one grasp query per scene -- qual [B] (post sigmoid), rot [B][4]
  * (unit), width [B], occ_logits [B][M] (raw; the sigmoid of `select` is part of this function) -- and the labels of

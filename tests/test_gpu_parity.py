@@ -297,16 +297,50 @@ def test_generation_eval_points_and_grid(sd7, golden):
 
 @pytest.mark.gpu
 def test_tsdf_feed_pinned_double_buffer(sd7):
-    """the pinned, double-buffered H->D feed delivers every batch intact and in order."""
+    """the pinned, ring-buffered H->D feed delivers every batch intact and in order, also when the ring laps
+    several times, when the consumer keeps the GPU busy between batches, and with a short last batch."""
     from giga_amd.feed import TSDFFeed
     dev = torch.device("cuda:0")
-    host = [(synth.tsdf_batch(10 * i, 3)[:, None], torch.from_numpy(synth.query_points(10 * i, 3, 5))) for i in range(5)]
-    seen = 0
+    host = [(synth.tsdf_batch(10 * i, 3 if i < 10 else 2)[:, None], torch.from_numpy(synth.query_points(10 * i, 3 if i < 10 else 2, 5)))
+            for i in range(11)]
+    seen, sums = 0, []
+    busy = torch.randn(2048, 2048, device=dev)
     for i, (xb, pb) in enumerate(TSDFFeed(host, dev)):
-        assert xb.is_cuda and pb.is_cuda and xb.shape == (3, 1, 40, 40, 40)
+        assert xb.is_cuda and pb.is_cuda and xb.shape == host[i][0].shape
+        for _ in range(3):
+            busy = busy @ busy * 1e-3                         # asynchronous consumer work that reads the batch afterwards
+        sums.append((xb.double().sum() + busy[0, 0].double() * 0).item() if i % 2 else xb.double().sum())
         assert torch.equal(xb.cpu(), torch.from_numpy(host[i][0])) and torch.equal(pb.cpu(), host[i][1])
         seen += 1
-    assert seen == 5
+    assert seen == 11
+    for i, v in enumerate(sums):
+        assert abs(float(v) - float(host[i][0].astype(np.float64).sum())) < 1e-6
+
+
+@pytest.mark.gpu
+def test_shared_ring_feed_end_to_end(tmp_path):
+    """Reader processes -> page-locked shared-memory ring -> DMA into the device ring (TSDFFeed over GraspOccRing): every
+    batch arrives intact and in order over two epochs, and matches the plain GraspOccBatches path."""
+    from giga_amd import dataset
+    from giga_amd.feed import TSDFFeed
+    dev = torch.device("cuda:0")
+    root, raw = str(tmp_path / "data"), str(tmp_path / "raw")
+    synth.write_training_set(root, raw, n_scenes=6, grasps_per_scene=7, seed=3)
+    ds = dataset.GraspOccDataset(root, raw, num_point_occ=64, workers=2)
+    ring = dataset.GraspOccRing(ds, 8, workers=3, shuffle=True, seed=5)
+    ref = dataset.GraspOccBatches(ds, 8, shuffle=True, seed=5, workers=2)
+    try:
+        for _ in range(2):
+            want = [(b[0], *b[1], b[2], b[3], b[4]) for b in ref]
+            k = 0
+            for x, (lab, rot, wid), pos, op, occ in TSDFFeed(ring, dev):
+                for a, b in zip((x, lab, rot, wid, pos, op, occ), want[k]):
+                    assert a.is_cuda and a.dtype == b.dtype and torch.equal(a.cpu(), b)
+                k += 1
+            assert k == len(want)
+        assert ring._pinned is True
+    finally:
+        ring.close()
 
 
 @pytest.mark.gpu
