@@ -51,7 +51,7 @@ template <int KIND, int H, int W>
 constexpr bool conv_lin() { return H == 10 && W == 10 && KIND != DOWN; }
 // waves per workgroup: 12 unless the resident weights + the wave-private patches would not fit the 160 KiB LDS
 template <typename T, int KIND, int C0, int C1, int H, int W, int NB>
-constexpr int conv_nw() {
+constexpr int conv_nw() {       // (SPLIT instantiations have T = float and exactly the fp32 LDS footprint)
     constexpr int ES = (int)sizeof(T), PS = 32 * ES + 16, HALO = KIND == CONV3 ? 1 : 0;
     constexpr int TAPS = KIND == CONV3 ? 9 : KIND == DOWN ? 4 : 1;
     constexpr int NPIX = conv_lin<KIND, H, W>() ? (W + 2 * HALO) * (3 + 2 * HALO) : KIND == DOWN ? 64 : (4 + 2 * HALO) * (4 + 2 * HALO);
@@ -62,8 +62,14 @@ constexpr int conv_nw() {
 }
 
 // H, W are the OUTPUT-grid dimensions for DOWN (its input is 2H x 2W) and the input dimensions otherwise.
-template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL, bool RELU = (KIND == CONV3)>
+// SPLIT (T = float only): f16x3 split-operand arithmetic.  Activations stay fp32 in HBM; the staging step converts every
+// value v to the pair hi = f16(v), lo = f16(v - hi) (patch pixel = 4 groups of 8 channels x [8 hi | 8 lo] halfs, 128 B as for
+// fp32), the resident weights are [hi, lo] fragment pairs, and every (tap, 32-channel chunk) is three v_mfma_f32_16x16x32_f16
+// (W_lo*x_hi + W_hi*x_lo + W_hi*x_hi) instead of eight v_mfma_f32_16x16x4_f32: fp32-grade results at 5x less MFMA time.
+template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL, bool RELU = (KIND == CONV3),
+          bool SPLIT = false>
 __global__ __launch_bounds__((conv_nw<T, KIND, C0, C1, H, W, NB>() * 64)) void conv16_kernel(ConvArgs a) {
+    static_assert(!SPLIT || sizeof(T) == 4, "split mode reads and writes fp32 activations");
     constexpr int CIN = C0 + C1;
     constexpr int TAPS = KIND == CONV3 ? 9 : KIND == DOWN ? 4 : 1;
     constexpr int HALO = KIND == CONV3 ? 1 : 0;
@@ -86,9 +92,11 @@ __global__ __launch_bounds__((conv_nw<T, KIND, C0, C1, H, W, NB>() * 64)) void c
     constexpr int NBT = COUT / 16;                    // 16-channel blocks per sub-output
     constexpr int CG = NBT / NB;                      // channel groups per sub-output
     constexpr int NGRP = NSUB * CG;                   // weight groups (one per workgroup)
-    constexpr int KGC = ES == 4 ? 2 : 1;              // k-groups per 32-channel chunk (16 / 32 channels)
+    constexpr bool F16MATH = ES == 2 || SPLIT;        // 16x16x32 f16 MFMA (one k-group per 32-channel chunk)
+    constexpr int KGC = F16MATH ? 1 : 2;              // k-groups per 32-channel chunk (16 / 32 channels)
+    constexpr int WPF = SPLIT ? 2 : 1;                // LDS fragments per weight k-group ([hi, lo] pair)
     constexpr int KGT = CIN / 32 * KGC;
-    constexpr int WFRAGS = NB * TAPS * KGT;           // weight fragments resident in LDS
+    constexpr int WFRAGS = NB * TAPS * KGT * WPF;     // weight fragments resident in LDS
     static_assert(NBT % NB == 0, "cout grouping");
 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -103,7 +111,7 @@ __global__ __launch_bounds__((conv_nw<T, KIND, C0, C1, H, W, NB>() * 64)) void c
     const int sub = grp / CG, nb0 = (grp % CG) * NB;
     {
         // fragments of (sub, nb0 .. nb0+NB-1) are contiguous in the packed blob: [sub][nb][tap][kg]
-        const uint8_t* wsrc = a.w + (size_t)(sub * NBT + nb0) * TAPS * KGT * FRAG;
+        const uint8_t* wsrc = a.w + (size_t)(sub * NBT + nb0) * TAPS * KGT * WPF * FRAG;
         for (int c = wave; c < WFRAGS; c += NWV)
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(wsrc + (size_t)c * FRAG + lane * 16),
@@ -117,7 +125,8 @@ __global__ __launch_bounds__((conv_nw<T, KIND, C0, C1, H, W, NB>() * 64)) void c
 
     // A geometry: row i = lane&15 : quad = i>>2 (qy = quad>>1, qx = quad&1), pos = i&3 (dy = pos>>1, dx = pos&1)
     const int ay = 2 * (j >> 3) + ((j >> 1) & 1), ax = 2 * ((j >> 2) & 1) + (j & 1);
-    int a_off = (KIND == DOWN ? (2 * ay * LW + 2 * ax) : (ay * LW + ax)) * PS + g * 16;      // LIN: set per unit below
+    constexpr int AG = SPLIT ? 32 : 16;               // byte offset of k-group g inside a patch pixel
+    int a_off = (KIND == DOWN ? (2 * ay * LW + 2 * ax) : (ay * LW + ax)) * PS + g * AG;      // LIN: set per unit below
 
     // staging geometry of this lane's NLD vectors (fixed for the whole kernel)
     int st_lds[NLD], st_ly[NLD], st_lx[NLD], st_v[NLD];
@@ -178,12 +187,29 @@ __global__ __launch_bounds__((conv_nw<T, KIND, C0, C1, H, W, NB>() * 64)) void c
             const int t16 = 16 * (u % TX);
             int p = t16 + j;
             p = p < H * W ? p : H * W - 1;
-            a_off = ((p / W - t16 / W) * LW + p % W) * PS + g * 16;
+            a_off = ((p / W - t16 / W) * LW + p % W) * PS + g * AG;
         }
         // ---- registers -> wave-private LDS patch (DS ops of one wave execute in order) -----------
 #pragma unroll
         for (int q = 0; q < NLD; ++q)
-            if (st_lds[q] >= 0) *reinterpret_cast<uint4*>(region + st_lds[q]) = stg[q];
+            if (st_lds[q] >= 0) {
+                if constexpr (SPLIT) {
+                    // vector v = channels 4v..4v+3 of the pixel: hi halfs at group (v>>1), slot 4*(v&1); lo 16 bytes further
+                    const f32x4v x = __builtin_bit_cast(f32x4v, stg[q]);
+                    half4 hi4, lo4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const half_t h = (half_t)x[e];
+                        hi4[e] = h;
+                        lo4[e] = (half_t)__builtin_fmaf((float)h, -1.0f, x[e]);
+                    }
+                    uint8_t* dst = region + (st_lds[q] - st_v[q] * 16) + (st_v[q] >> 1) * 32 + (st_v[q] & 1) * 8;
+                    *reinterpret_cast<half4*>(dst) = hi4;
+                    *reinterpret_cast<half4*>(dst + 16) = lo4;
+                } else {
+                    *reinterpret_cast<uint4*>(region + st_lds[q]) = stg[q];
+                }
+            }
         CONV_T(tcount); ++tcount;          // patch chunk in LDS (includes the wait for its global loads)
         // ---- prefetch the next chunk / next unit ---------------------------------------------------
         int un = u, ccn = cc + 1;
@@ -195,35 +221,48 @@ __global__ __launch_bounds__((conv_nw<T, KIND, C0, C1, H, W, NB>() * 64)) void c
         // wave keeps the MFMA pipe fed on its own instead of relying on its two SIMD siblings to cover the
         // LDS round trip (they are gone in the ragged last round).
         constexpr int NIT = TAPS * KGC;
-        auto read_ops = [&](int it, uint4& av, uint4 (&bw)[NB]) {
+        auto read_ops = [&](int it, uint4 (&av)[WPF], uint4 (&bw)[NB][WPF]) {
             const int tap = it / KGC, kg = it % KGC;
             const int toff = (KIND == DOWN ? ((tap >> 1) * LW + (tap & 1)) : ((tap / 3) * LW + (tap % 3))) * PS;
-            av = *reinterpret_cast<const uint4*>(region + a_off + toff + kg * 64);
 #pragma unroll
-            for (int n = 0; n < NB; ++n) bw[n] = wl[((n * TAPS + tap) * KGT + cc * KGC + kg) * 64 + lane];
+            for (int w = 0; w < WPF; ++w) av[w] = *reinterpret_cast<const uint4*>(region + a_off + toff + kg * 64 + w * 16);
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int w = 0; w < WPF; ++w) bw[n][w] = wl[(((n * TAPS + tap) * KGT + cc * KGC + kg) * WPF + w) * 64 + lane];
         };
         // ring of PD operand sets: the LDS round trip of a 1 KiB ds_read_b128 is ~300 cycles, i.e. more than two
         // groups of four 32-cycle MFMAs
         constexpr int PD = NIT < 3 ? NIT : 3;
-        uint4 av_q[PD], bw_q[PD][NB];
+        uint4 av_q[PD][WPF], bw_q[PD][NB][WPF];
 #pragma unroll
         for (int it = 0; it < PD; ++it) read_ops(it, av_q[it], bw_q[it]);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int kg = it % KGC, sl = it % PD;
-            if constexpr (ES == 2) {
+            if constexpr (SPLIT) {
+                const half8 Ah = __builtin_bit_cast(half8, av_q[sl][0]), Al = __builtin_bit_cast(half8, av_q[sl][1]);
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    const half8 Bh = __builtin_bit_cast(half8, bw_q[sl][n][0]), Bl = __builtin_bit_cast(half8, bw_q[sl][n][1]);
+                    f32x4v& c = acc[n][it & (NACC - 1)];
+                    c = mfma16_16(Ah, Bl, c);
+                    c = mfma16_16(Al, Bh, c);
+                    c = mfma16_16(Ah, Bh, c);
+                }
+            } else if constexpr (ES == 2) {
 #pragma unroll
                 for (int n = 0; n < NB; ++n)
-                    acc[n][kg & (NACC - 1)] = mfma16_16(__builtin_bit_cast(half8, av_q[sl]),
-                                                        __builtin_bit_cast(half8, bw_q[sl][n]), acc[n][kg & (NACC - 1)]);
+                    acc[n][kg & (NACC - 1)] = mfma16_16(__builtin_bit_cast(half8, av_q[sl][0]),
+                                                        __builtin_bit_cast(half8, bw_q[sl][n][0]), acc[n][kg & (NACC - 1)]);
             } else {
                 // 16x16x4 f32: 32-cycle issue, 40-cycle dependent latency -> alternate accumulators
-                const f32x4v A = __builtin_bit_cast(f32x4v, av_q[sl]);
+                const f32x4v A = __builtin_bit_cast(f32x4v, av_q[sl][0]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int n = 0; n < NB; ++n)
-                        acc[n][e & (NACC - 1)] = mfma32_16(A[e], __builtin_bit_cast(f32x4v, bw_q[sl][n])[e], acc[n][e & (NACC - 1)]);
+                        acc[n][e & (NACC - 1)] = mfma32_16(A[e], __builtin_bit_cast(f32x4v, bw_q[sl][n][0])[e], acc[n][e & (NACC - 1)]);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (it + PD < NIT) read_ops(it + PD, av_q[sl], bw_q[sl]);
@@ -279,7 +318,8 @@ __global__ __launch_bounds__((conv_nw<T, KIND, C0, C1, H, W, NB>() * 64)) void c
     CONV_T(63);
 }
 
-template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL, bool RELU = (KIND == CONV3)>
+template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL, bool RELU = (KIND == CONV3),
+          bool SPLIT = false>
 inline int launch_conv(const ConvArgs& a, hipStream_t s) {
     constexpr int HALO = KIND == CONV3 ? 1 : 0;
     constexpr int TAPS = KIND == CONV3 ? 9 : KIND == DOWN ? 4 : 1;
@@ -291,15 +331,15 @@ inline int launch_conv(const ConvArgs& a, hipStream_t s) {
     constexpr int REGION = (NPIX * PS + 15) / 16 * 16;
     constexpr int NSUB = KIND == UPCONV ? 4 : 1;
     constexpr int NGRP = NSUB * (COUT / 16 / NB);
-    constexpr int KGT = (C0 + C1) / 32 * (ES == 4 ? 2 : 1);
-    constexpr size_t lds = (size_t)NB * TAPS * KGT * FRAG + NWV * REGION;
+    constexpr int KGT = (C0 + C1) / 32 * ((ES == 4 && !SPLIT) ? 2 : 1);
+    constexpr size_t lds = (size_t)NB * TAPS * KGT * (SPLIT ? 2 : 1) * FRAG + NWV * REGION;
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert(!(LIN && POOL), "the in-lane 2x2 max-pool needs the quad tiling");
     static_assert(256 % NGRP == 0, "weight groups must divide the CU count");
     const int units = a.nimg * (LIN ? (H * W + 15) / 16 : ((H + 3) / 4) * ((W + 3) / 4));   // per weight group
     int wgs = (units + NWV - 1) / NWV;                                // workgroups per weight group
     if (wgs > 256 / NGRP) wgs = 256 / NGRP;                           // one persistent workgroup per CU
-    auto kern = conv16_kernel<T, KIND, C0, C1, COUT, H, W, NB, POOL, RELU>;
+    auto kern = conv16_kernel<T, KIND, C0, C1, COUT, H, W, NB, POOL, RELU, SPLIT>;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(wgs * NGRP), dim3(NWV * 64), lds, s, a);

@@ -254,7 +254,7 @@ EncWs enc_workspace(int B, int precision) {
 // (k = 0 conv_in+project, 1 plane_finalize, 2..14 = U-Net layers 0..12).
 struct Probe { int stage; hipEvent_t ev0, ev1; };
 
-template <typename T>
+template <typename T, bool SPLIT = false>
 static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc, float* planes_nchw, int B,
                        uint8_t* ws, hipStream_t s, const Probe& pr, bool fold_final) {
     int stage_no = 0;
@@ -292,7 +292,7 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     if (hipGetLastError() != hipSuccess) return -10;
 
     const int nimg = 3 * B;
-    auto W_ = [&](int l) { return blob + (precision == 1 ? ko.conv[l].w16 : ko.conv[l].w32); };
+    auto W_ = [&](int l) { return blob + (SPLIT ? ko.conv[l].w16s : precision == 1 ? ko.conv[l].w16 : ko.conv[l].w32); };
     auto Bi = [&](int l) { return reinterpret_cast<const float*>(blob + ko.conv[l].bias); };
     auto args = [&](int l, const void* i0, const void* i1, void* o, void* op) {
         ConvArgs a{};
@@ -304,27 +304,27 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     uint8_t* b = ws;
     int rc = 0;
     // template params: <T, KIND, C0, C1, COUT, H, W, NB (16-channel blocks per unit), POOL>
-    pre(); rc |= launch_conv<T, CONV3, 32, 0, 32, 40, 40, 2, false>(args(0, b + w.P0, nullptr, b + w.A0, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 32, 0, 32, 40, 40, 2, true>(args(1, b + w.A0, nullptr, b + w.S0, b + w.Q0), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 32, 0, 64, 20, 20, 1, false>(args(2, b + w.Q0, nullptr, b + w.A1, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 64, 0, 64, 20, 20, 1, true>(args(3, b + w.A1, nullptr, b + w.S1, b + w.Q1), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 64, 0, 128, 10, 10, 1, false>(args(4, b + w.Q1, nullptr, b + w.A2, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 128, 0, 128, 10, 10, 1, false>(args(5, b + w.A2, nullptr, b + w.S2, nullptr), s); post();
-    pre(); rc |= launch_conv<T, UPCONV, 128, 0, 64, 10, 10, 2, false>(args(6, b + w.S2, nullptr, b + w.U0, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 64, 64, 64, 20, 20, 1, false>(args(7, b + w.U0, b + w.S1, b + w.A3, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 64, 0, 64, 20, 20, 1, false>(args(8, b + w.A3, nullptr, b + w.A4, nullptr), s); post();
-    pre(); rc |= launch_conv<T, UPCONV, 64, 0, 32, 20, 20, 2, false>(args(9, b + w.A4, nullptr, b + w.U1, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 32, 32, 32, 40, 40, 2, false>(args(10, b + w.U1, b + w.S0, b + w.A5, nullptr), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 32, 0, 32, 40, 40, 2, false, true, SPLIT>(args(0, b + w.P0, nullptr, b + w.A0, nullptr), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 32, 0, 32, 40, 40, 2, true, true, SPLIT>(args(1, b + w.A0, nullptr, b + w.S0, b + w.Q0), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 32, 0, 64, 20, 20, 1, false, true, SPLIT>(args(2, b + w.Q0, nullptr, b + w.A1, nullptr), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 64, 0, 64, 20, 20, 1, true, true, SPLIT>(args(3, b + w.A1, nullptr, b + w.S1, b + w.Q1), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 64, 0, 128, 10, 10, 1, false, true, SPLIT>(args(4, b + w.Q1, nullptr, b + w.A2, nullptr), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 128, 0, 128, 10, 10, 1, false, true, SPLIT>(args(5, b + w.A2, nullptr, b + w.S2, nullptr), s); post();
+    pre(); rc |= launch_conv<T, UPCONV, 128, 0, 64, 10, 10, 2, false, false, SPLIT>(args(6, b + w.S2, nullptr, b + w.U0, nullptr), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 64, 64, 64, 20, 20, 1, false, true, SPLIT>(args(7, b + w.U0, b + w.S1, b + w.A3, nullptr), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 64, 0, 64, 20, 20, 1, false, true, SPLIT>(args(8, b + w.A3, nullptr, b + w.A4, nullptr), s); post();
+    pre(); rc |= launch_conv<T, UPCONV, 64, 0, 32, 20, 20, 2, false, false, SPLIT>(args(9, b + w.A4, nullptr, b + w.U1, nullptr), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 32, 32, 32, 40, 40, 2, false, true, SPLIT>(args(10, b + w.U1, b + w.S0, b + w.A5, nullptr), s); post();
     // GIGA_FOLD_FINAL: the caller's decoder carries conv_final inside its fc_c weights, so up1.conv2 writes straight
     // into the output planes and the last layer is not launched (its probe stage then brackets nothing)
     void* a6 = fold_final ? planes_nhwc : static_cast<void*>(b + w.A6);
-    pre(); rc |= launch_conv<T, CONV3, 32, 0, 32, 40, 40, 2, false>(args(11, b + w.A5, nullptr, a6, nullptr), s); post();
+    pre(); rc |= launch_conv<T, CONV3, 32, 0, 32, 40, 40, 2, false, true, SPLIT>(args(11, b + w.A5, nullptr, a6, nullptr), s); post();
     if (fold_final) {
         pre(); post();
     } else {
         ConvArgs a = args(12, b + w.A6, nullptr, planes_nhwc, nullptr);
         a.out_nchw = planes_nchw;
-        pre(); rc |= launch_conv<T, CONV1, 32, 0, 32, 40, 40, 2, false>(a, s); post();
+        pre(); rc |= launch_conv<T, CONV1, 32, 0, 32, 40, 40, 2, false, false, SPLIT>(a, s); post();
     }
     return rc;
 }
@@ -334,8 +334,10 @@ int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, fl
     if (B <= 0) return 0;
     Probe pr{ev0 && ev1 ? probe_stage : -1, static_cast<hipEvent_t>(ev0), static_cast<hipEvent_t>(ev1)};
     const bool fold = (precision & GIGA_FOLD_FINAL) != 0;
-    return (precision & 1) ? encoder_run<half_t>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold)
-                           : encoder_run<float>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold);
+    const int prec = precision & ~GIGA_FOLD_FINAL;
+    if (prec == 2) return encoder_run<float, true>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold);
+    return prec == 1 ? encoder_run<half_t>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold)
+                     : encoder_run<float>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold);
 }
 
 }  // namespace giga

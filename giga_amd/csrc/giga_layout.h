@@ -117,7 +117,7 @@ constexpr size_t DEC16S_BYTES = (DEC16S_FRAGS + 1) * FRAG;                // 111
 constexpr int DEC32_FRAGS = NBLK * (12 + 1 + 4 + 4) + 1 + 4;              // 110
 constexpr size_t DEC32_BYTES = (DEC32_FRAGS + 1) * FRAG;                  // 111 KiB: fragments + C table chunk (LDS-DMA image)
 
-struct ConvPackOff { size_t w16, w32, bias; int nfrag16, nfrag32; };
+struct ConvPackOff { size_t w16, w32, bias, w16s; int nfrag16, nfrag32; };   // w16s: f16x3 split [hi, lo] fragment pairs (2 * nfrag16)
 struct PackOff {
     size_t convin_w;        // fp32 [2][7][64]  B operands (channel half, K-step of 4 taps; tap 27 = 0)
     size_t convin_b;        // fp32 [32]
@@ -125,6 +125,7 @@ struct PackOff {
     size_t dec16[NHEADS], dec32[NHEADS];
     size_t dec16f[NHEADS], dec32f[NHEADS];   // the same heads with the encoder's final 1x1 conv folded into fc_c (see giga_pack.cpp)
     size_t dec16s[NHEADS], dec16sf[NHEADS];  // f16x3 split images (plain, folded)
+    size_t convin_ws;       // f16x3 split conv_in B operands: [2 channel halves][hi, lo] fragments of v_mfma_f32_16x16x32_f16
     size_t total;
 };
 
@@ -157,6 +158,8 @@ inline PackOff pack_offsets() {
         o.dec16s[h] = at; at += align_up(DEC16S_BYTES, 256);
         o.dec16sf[h] = at; at += align_up(DEC16S_BYTES, 256);
     }
+    for (int l = 0; l < NCONV; ++l) { o.conv[l].w16s = at; at += (size_t)2 * o.conv[l].nfrag16 * FRAG; }
+    o.convin_ws = at; at += 4 * FRAG;
     o.total = at;
     return o;
 }

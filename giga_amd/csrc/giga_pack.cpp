@@ -197,6 +197,7 @@ static void pack_conv(const float* P, const ParamOff& po, const PackOff& ko, int
     const float* W = P + po.conv_w[l];
     const int cin = d.cin0 + d.cin1, taps = conv_taps(d), nsub = conv_nsub(d), nb16 = d.cout / 16;
     half_t* f16 = reinterpret_cast<half_t*>(blob + ko.conv[l].w16);
+    half_t* f16s = reinterpret_cast<half_t*>(blob + ko.conv[l].w16s);      // split: fragment pair (2*i16, 2*i16 + 1) = (hi, lo)
     float* f32 = reinterpret_cast<float*>(blob + ko.conv[l].w32);
     size_t i16 = 0, i32 = 0;
     for (int sub = 0; sub < nsub; ++sub)
@@ -206,9 +207,13 @@ static void pack_conv(const float* P, const ParamOff& po, const PackOff& ko, int
                 for (int kg = 0; kg < cin / 32; ++kg, ++i16)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int j = lane & 15, g = lane >> 4;
-                        for (int e = 0; e < 8; ++e)
-                            f16[i16 * 512 + lane * 8 + e] =
-                                f2h(conv_w_at(W, d, nb * 16 + j, kg * 32 + 8 * g + e, wtap));
+                        for (int e = 0; e < 8; ++e) {
+                            const float w = conv_w_at(W, d, nb * 16 + j, kg * 32 + 8 * g + e, wtap);
+                            const half_t h = f2h(w);
+                            f16[i16 * 512 + lane * 8 + e] = h;
+                            f16s[(2 * i16) * 512 + lane * 8 + e] = h;
+                            f16s[(2 * i16 + 1) * 512 + lane * 8 + e] = f2h(w - (float)h);
+                        }
                     }
                 for (int kg = 0; kg < cin / 16; ++kg, ++i32)
                     for (int lane = 0; lane < 64; ++lane) {
@@ -240,6 +245,20 @@ int pack_weights_host(const float* P, size_t n_params, int head_present, uint8_t
                 int n = 16 * h + (lane & 15), tap = 4 * s + (lane >> 4);
                 cw[(h * 7 + s) * 64 + lane] = tap < 27 ? P[po.conv_in_w + n * 27 + tap] : 0.f;
             }
+    // f16x3 split conv_in: B operand of ONE v_mfma_f32_16x16x32_f16 per channel half (K = 27 taps padded to 32):
+    //   [h][hi|lo][lane]: lane (j = lane&15 -> channel 16h + j, g = lane>>4), half e -> tap 8g + e (taps >= 27 are zero)
+    {
+        half_t* cs = reinterpret_cast<half_t*>(blob + ko.convin_ws);
+        for (int h = 0; h < 2; ++h)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int n = 16 * h + (lane & 15), tap = 8 * (lane >> 4) + e;
+                    const float w = tap < 27 ? P[po.conv_in_w + n * 27 + tap] : 0.f;
+                    const half_t hi = f2h(w);
+                    cs[((2 * h) * 64 + lane) * 8 + e] = hi;
+                    cs[((2 * h + 1) * 64 + lane) * 8 + e] = f2h(w - (float)hi);
+                }
+    }
     float* cb = reinterpret_cast<float*>(blob + ko.convin_b);
     for (int n = 0; n < 32; ++n) cb[n] = P[po.conv_in_b + n];
     for (int l = 0; l < NCONV; ++l) pack_conv(P, po, ko, l, blob);

@@ -22,11 +22,14 @@ def _blob_and_offsets(sd):
     conv = [(0, 32, 0, 32), (0, 32, 0, 32), (0, 32, 0, 64), (0, 64, 0, 64), (0, 64, 0, 128), (0, 128, 0, 128),
             (1, 128, 0, 64), (0, 64, 64, 64), (0, 64, 0, 64), (1, 64, 0, 32), (0, 32, 32, 32), (0, 32, 0, 32),
             (2, 32, 0, 32)]
+    tail = 0
     for kind, c0, c1, co in conv:
         cin = c0 + c1
         nblk = co // 32 * (4 if kind == 1 else 1)
         taps = 9 if kind == 0 else 1
         at += nblk * taps * (cin // 16) * 1024 + nblk * taps * (cin // 8) * 1024 + up(co * 4)
+        tail += 2 * nblk * taps * (cin // 16) * 1024          # f16x3 split conv fragments ([hi, lo] pairs), appended
+    tail += 4 * 1024                                           # f16x3 split conv_in fragments
     dec16, dec32 = [], []
     for _ in range(4):
         dec16.append(at); at += up(59 * 1024)          # 58 fragments + C table in a 59th 1 KiB chunk
@@ -38,6 +41,7 @@ def _blob_and_offsets(sd):
     dec16s = []                                        # f16x3 split images (plain, folded), appended
     for _ in range(4):
         dec16s.append(at); at += 2 * up(111 * 1024)
+    at += tail
     assert at == blob.size
     _blob_and_offsets.dec16s = dec16s
     return blob, dec16, dec32
