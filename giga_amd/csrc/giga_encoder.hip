@@ -38,10 +38,14 @@ constexpr size_t ci_lds_bytes(int sxw) {
     return stage > red ? stage : red;
 }
 
-template <typename TOut, int SXW>
+// SPLIT: f16x3 split-operand arithmetic for the 27-tap contraction.  The sub-volume is staged as one 32-bit word per voxel
+// holding the pair (hi = f16(v), lo = f16(v - hi)); the 27 taps (+5 zero weights) are ONE K = 32 step, i.e. three
+// v_mfma_f32_16x16x32_f16 per unit (W_lo*x_hi + W_hi*x_lo + W_hi*x_hi, bias in the C operand) instead of seven
+// v_mfma_f32_16x16x4_f32; a lane gathers its 8 tap words and separates them into the hi and lo operand with 8 byte-permutes.
+template <typename TOut, int SXW, bool SPLIT = false>
 __global__ __launch_bounds__(512) void convin_project_kernel(
     const float* __restrict__ tsdf,        // [B][40][40][40]
-    const float* __restrict__ wpk,         // [2][7][64] packed B operands
+    const float* __restrict__ wpk,         // [2][7][64] packed B operands (SPLIT: [2][hi|lo][64] x 8 halfs)
     const float* __restrict__ bias,        // [32]
     TOut* __restrict__ planes,             // [3][B][40][40][32] NHWC (xy written here)
     float* __restrict__ xz_partial,        // [4 iy-groups][B][40(iz)][40(ix)][32] sums over the group's 10 iy
@@ -64,13 +68,31 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
         if (ix >= 0 && ix < RES && iy >= 0 && iy < RES)
             val = *reinterpret_cast<const float4*>(vol + ((size_t)ix * RES + iy) * RES + 4 * q);
         float* dst = lds + row * CV_RS + 1 + 4 * q;
-        dst[0] = val.x; dst[1] = val.y; dst[2] = val.z; dst[3] = val.w;
+        if constexpr (SPLIT) {                     // word = hi | lo << 16
+            const float v4[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const half_t h = (half_t)v4[e];
+                const half_t l = (half_t)__builtin_fmaf((float)h, -1.0f, v4[e]);
+                const unsigned w = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+                dst[e] = __builtin_bit_cast(float, w);
+            }
+        } else {
+            dst[0] = val.x; dst[1] = val.y; dst[2] = val.z; dst[3] = val.w;
+        }
         if (q == 0) dst[-1] = 0.f;
         if (q == 9) dst[4] = 0.f;
     }
     float wreg[7];
+    half8 wsh = {0, 0, 0, 0, 0, 0, 0, 0}, wsl = wsh;
+    if constexpr (SPLIT) {
+        const half8* wsp = reinterpret_cast<const half8*>(wpk);
+        wsh = wsp[(2 * chh) * 64 + lane];
+        wsl = wsp[(2 * chh + 1) * 64 + lane];
+    } else {
 #pragma unroll
-    for (int s = 0; s < 7; ++s) wreg[s] = wpk[(chh * 7 + s) * 64 + lane];
+        for (int s = 0; s < 7; ++s) wreg[s] = wpk[(chh * 7 + s) * 64 + lane];
+    }
     const int ch = 16 * chh + j;
     const float bn = bias[ch];
     // A operand: row i = lane&15 is voxel (iy_l = i>>3, iz_l = 4*((i>>2)&1) + (i&3)); k-slot g supplies tap 4s+g
@@ -81,6 +103,14 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
         int t = 4 * s + g;
         t = t > 26 ? 26 : t;
         abase[s] = ((t / 9) * CV_ROWS + (j >> 3) + (t / 3) % 3) * CV_RS + 4 * ((j >> 2) & 1) + (j & 3) + t % 3;
+    }
+    // SPLIT: k-slot g of the single K = 32 step supplies taps 8g .. 8g+7 (taps > 26 have zero weight and read tap 26's voxel)
+    int sbase[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int t = 8 * g + e;
+        t = t > 26 ? 26 : t;
+        sbase[e] = ((t / 9) * CV_ROWS + (j >> 3) + (t / 3) % 3) * CV_RS + 4 * ((j >> 2) & 1) + (j & 3) + t % 3;
     }
     f32x4v acc_yz[5][5];
 #pragma unroll
@@ -111,13 +141,48 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
         // uninterrupted burst (an extra issue slot between MFMAs costs far more than the slot itself); the ReLU /
         // axis-sum epilogue is paid in full: fp32 MFMA shares the VALU with it.
         float P[3][5], Q[4][5];
+        const unsigned* ldw = reinterpret_cast<const unsigned*>(lds);
+        if constexpr (SPLIT) {
+        } else {
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+            for (int s = 0; s < 3; ++s)
 #pragma unroll
-            for (int ip = 0; ip < 5; ++ip) P[s][ip] = lds[addr[s] + 2 * ip * CV_RS];
+                for (int ip = 0; ip < 5; ++ip) P[s][ip] = lds[addr[s] + 2 * ip * CV_RS];
+        }
 #pragma unroll
         for (int zg = 0; zg < 5; ++zg) {
             f32x4v d[5];
+            if constexpr (SPLIT) {
+                // two batches (3 + 2 units) keep the operand registers low: the 100 yz accumulators stay resident
+#pragma unroll
+                for (int b0 = 0; b0 < 5; b0 += 3) {
+                    constexpr int NBATCH = 3;
+                    half8 ah[NBATCH], al[NBATCH];
+#pragma unroll
+                    for (int u = 0; u < NBATCH; ++u) {
+                        const int ip = b0 + u;
+                        if (ip < 5) {
+                            unsigned w8[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) w8[e] = ldw[sbase[e] + ixl * CV_ROWS * CV_RS + 2 * ip * CV_RS + 8 * zg];
+                            unsigned hw[4], lw[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {   // bytes [w0.b0 w0.b1 w1.b0 w1.b1] = two hi halfs, [w0.b2 w0.b3 w1.b2 w1.b3] = two lo halfs
+                                hw[q] = __builtin_amdgcn_perm(w8[2 * q + 1], w8[2 * q], 0x05040100u);
+                                lw[q] = __builtin_amdgcn_perm(w8[2 * q + 1], w8[2 * q], 0x07060302u);
+                            }
+                            ah[u] = __builtin_bit_cast(half8, uint4{hw[0], hw[1], hw[2], hw[3]});
+                            al[u] = __builtin_bit_cast(half8, uint4{lw[0], lw[1], lw[2], lw[3]});
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < NBATCH; ++u) if (b0 + u < 5) d[b0 + u] = mfma16_16(ah[u], wsl, bias4);
+#pragma unroll
+                    for (int u = 0; u < NBATCH; ++u) if (b0 + u < 5) d[b0 + u] = mfma16_16(al[u], wsh, d[b0 + u]);
+#pragma unroll
+                    for (int u = 0; u < NBATCH; ++u) if (b0 + u < 5) d[b0 + u] = mfma16_16(ah[u], wsh, d[b0 + u]);
+                }
+            } else {
 #pragma unroll
             for (int s = 3; s < 7; ++s)
 #pragma unroll
@@ -140,6 +205,7 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
 #pragma unroll
                 for (int ip = 0; ip < 5; ++ip) d[ip] = mfma32_16(Q[s - 3][ip], wreg[s], d[ip]);
             __builtin_amdgcn_sched_barrier(0);
+            }
             f32x4v part_y = zero4;            // per r: sum over the 5 iy-pairs of this group
 #pragma unroll
             for (int ip = 0; ip < 5; ++ip) {
@@ -268,16 +334,16 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     float* XZP = reinterpret_cast<float*>(ws + w.YZ);
     float* YZP = XZP + 4 * per;
     const int nxp = enc_nxp(B);
-    const float* cw = reinterpret_cast<const float*>(blob + ko.convin_w);
+    const float* cw = reinterpret_cast<const float*>(blob + (SPLIT ? ko.convin_ws : ko.convin_w));
     const float* cb = reinterpret_cast<const float*>(blob + ko.convin_b);
     pre();
     if (nxp == 1) {
-        auto kern = convin_project_kernel<T, 5>;
+        auto kern = convin_project_kernel<T, 5, SPLIT>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)ci_lds_bytes(5));
         hipLaunchKernelGGL(kern, dim3(1, 8, B), dim3(512), ci_lds_bytes(5), s, tsdf, cw, cb, P0, XZP, YZP, B);
     } else {
-        auto kern = convin_project_kernel<T, 1>;
+        auto kern = convin_project_kernel<T, 1, SPLIT>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)ci_lds_bytes(1));
         hipLaunchKernelGGL(kern, dim3(5, 8, B), dim3(512), ci_lds_bytes(1), s, tsdf, cw, cb, P0, XZP, YZP, B);
