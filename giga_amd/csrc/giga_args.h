@@ -26,4 +26,10 @@ struct DecArgs {
     unsigned mR, mR2;        // ceil(2^32 / R), ceil(2^32 / R^2)   (lattice mode)
 };
 
+// Byte offsets of the encoder's activations inside its caller-allocated workspace (giga_encoder.hip::enc_workspace).
+struct EncWs {
+    size_t P0, A0, S0, Q0, A1, S1, Q1, A2, S2, U0, A3, A4, U1, A5, A6, YZ, XZ, total;   // XZ unused (kept for the ABI)
+    size_t SYNC;               // barrier counter + timeout flag of the persistent U-Net kernel
+};
+
 }  // namespace giga

@@ -34,7 +34,6 @@ int launch_train_loss_backward(const float* qual, const float* rot, const float*
 int launch_tsdf_scatter(const int* index, const float* value, const int* offsets, int B, int R, int n, float* grid,
                         int* winner, hipStream_t s);
 // giga_encoder.hip
-struct EncWs { size_t P0, A0, S0, Q0, A1, S1, Q1, A2, S2, U0, A3, A4, U1, A5, A6, YZ, XZ, total; };
 EncWs enc_workspace(int B, int precision);
 int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, float* planes_nchw, int B,
                    int precision, uint8_t* ws, hipStream_t s, int probe_stage, void* ev0, void* ev1);

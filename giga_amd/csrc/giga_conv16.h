@@ -66,9 +66,33 @@ constexpr int conv_nw() {       // (SPLIT instantiations have T = float and exac
 // value v to the pair hi = f16(v), lo = f16(v - hi) (patch pixel = 4 groups of 8 channels x [8 hi | 8 lo] halfs, 128 B as for
 // fp32), the resident weights are [hi, lo] fragment pairs, and every (tap, 32-channel chunk) is three v_mfma_f32_16x16x32_f16
 // (W_lo*x_hi + W_hi*x_lo + W_hi*x_hi) instead of eight v_mfma_f32_16x16x4_f32: fp32-grade results at 5x less MFMA time.
-template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL, bool RELU = (KIND == CONV3),
-          bool SPLIT = false>
-__global__ __launch_bounds__((conv_nw<T, KIND, C0, C1, H, W, NB>() * 64)) void conv16_kernel(ConvArgs a) {
+// The layer is written as two device functions so that it can run either as its own kernel (conv16_kernel) or as one
+// stage of the persistent U-Net kernel (unet_mega_kernel, giga_encoder.hip):
+//   conv16_fill : issue the LDS-DMA of this workgroup's weight group (all launched waves take part)
+//   conv16_run  : wait for it, then walk the units.  `block` / `nblocks` replace blockIdx.x / gridDim.x; waves beyond the
+//                 layer's own wave count (launched because another stage needs them) only take part in the barrier.
+template <typename T, int KIND, int C0, int C1, int COUT, int NB, bool SPLIT>
+__device__ __forceinline__ void conv16_fill(const ConvArgs& a, uint8_t* smem, int block) {
+    constexpr int TAPS = KIND == CONV3 ? 9 : KIND == DOWN ? 4 : 1;
+    constexpr int KGT = (C0 + C1) / 32 * ((sizeof(T) == 2 || SPLIT) ? 1 : 2);
+    constexpr int WPF = SPLIT ? 2 : 1;
+    constexpr int NSUB = KIND == UPCONV ? 4 : 1, NBT = COUT / 16, CG = NBT / NB, NGRP = NSUB * CG;
+    constexpr int WFRAGS = NB * TAPS * KGT * WPF;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwl = blockDim.x >> 6;
+    const int grp = block % NGRP;
+    const int sub = grp / CG, nb0 = (grp % CG) * NB;
+    // fragments of (sub, nb0 .. nb0+NB-1) are contiguous in the packed blob: [sub][nb][tap][kg]
+    const uint8_t* wsrc = a.w + (size_t)(sub * NBT + nb0) * TAPS * KGT * WPF * FRAG;
+    for (int c = wave; c < WFRAGS; c += nwl)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(wsrc + (size_t)c * FRAG + lane * 16),
+            (__attribute__((address_space(3))) void*)(smem + c * FRAG), 16, 0, 0);
+}
+
+template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL, bool RELU, bool SPLIT>
+__device__ __forceinline__ void conv16_run(const ConvArgs& a, uint8_t* smem, int block, int nblocks) {
     static_assert(!SPLIT || sizeof(T) == 4, "split mode reads and writes fp32 activations");
     constexpr int CIN = C0 + C1;
     constexpr int TAPS = KIND == CONV3 ? 9 : KIND == DOWN ? 4 : 1;
@@ -99,24 +123,16 @@ __global__ __launch_bounds__((conv_nw<T, KIND, C0, C1, H, W, NB>() * 64)) void c
     constexpr int WFRAGS = NB * TAPS * KGT * WPF;     // weight fragments resident in LDS
     static_assert(NBT % NB == 0, "cout grouping");
 
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
-    uint8_t* region = smem + (size_t)WFRAGS * FRAG + wave * REGION;
+    const bool active = wave < NWV;                    // (the persistent kernel launches 12 waves for every stage)
+    uint8_t* region = smem + (size_t)WFRAGS * FRAG + (active ? wave : 0) * REGION;
     CONV_T(0);
 
-    // ---- this workgroup's weight group -> LDS, once (LDS-DMA, 1 KiB per wave-instruction) ----------
-    const int grp = blockIdx.x % NGRP, wg_in_grp = blockIdx.x / NGRP, wgs_per_grp = gridDim.x / NGRP;
+    // this workgroup's weight group (filled by conv16_fill)
+    const int grp = block % NGRP, wg_in_grp = block / NGRP, wgs_per_grp = nblocks / NGRP;
     const int sub = grp / CG, nb0 = (grp % CG) * NB;
-    {
-        // fragments of (sub, nb0 .. nb0+NB-1) are contiguous in the packed blob: [sub][nb][tap][kg]
-        const uint8_t* wsrc = a.w + (size_t)(sub * NBT + nb0) * TAPS * KGT * WPF * FRAG;
-        for (int c = wave; c < WFRAGS; c += NWV)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(wsrc + (size_t)c * FRAG + lane * 16),
-                (__attribute__((address_space(3))) void*)(smem + c * FRAG), 16, 0, 0);
-    }
     const uint4* wl = reinterpret_cast<const uint4*>(smem);
     int tcount = 2;
 
@@ -165,15 +181,16 @@ __global__ __launch_bounds__((conv_nw<T, KIND, C0, C1, H, W, NB>() * 64)) void c
 
     // global wave index = wave * (#workgroups) + workgroup: remainder units spread over all CUs/SIMDs
     int u = wave * wgs_per_grp + wg_in_grp;
+    const bool work = active && u < units;
     // the first patch and the biases are requested while the weight fill is still in flight
-    if (u < units) issue_loads(u, 0);
+    if (work) issue_loads(u, 0);
     float bias_r[NB];
 #pragma unroll
     for (int n = 0; n < NB; ++n) bias_r[n] = a.bias ? a.bias[(nb0 + n) * 16 + j] : 0.f;
     __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): weights (LDS-DMA), patch and biases landed
     __syncthreads();
     CONV_T(1);
-    if (u >= units) return;
+    if (!work) return;                                 // (no workgroup barrier below this point)
     int cc = 0;
     constexpr int NACC = NB == 1 ? 2 : 1;          // independent accumulator chains per channel block
     f32x4v acc[NB][NACC];
@@ -316,6 +333,29 @@ __global__ __launch_bounds__((conv_nw<T, KIND, C0, C1, H, W, NB>() * 64)) void c
         u = un; cc = ccn;
     }
     CONV_T(63);
+}
+
+template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL, bool RELU = (KIND == CONV3),
+          bool SPLIT = false>
+__global__ __launch_bounds__((conv_nw<T, KIND, C0, C1, H, W, NB>() * 64)) void conv16_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    conv16_fill<T, KIND, C0, C1, COUT, NB, SPLIT>(a, smem, (int)blockIdx.x);
+    conv16_run<T, KIND, C0, C1, COUT, H, W, NB, POOL, RELU, SPLIT>(a, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// LDS bytes of one layer (weights resident + wave-private patches)
+template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool SPLIT>
+constexpr size_t conv_lds_bytes() {
+    constexpr int HALO = KIND == CONV3 ? 1 : 0;
+    constexpr int TAPS = KIND == CONV3 ? 9 : KIND == DOWN ? 4 : 1;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int PS = 32 * ES + 16;
+    constexpr bool LIN = conv_lin<KIND, H, W>();
+    constexpr int NWV = conv_nw<T, KIND, C0, C1, H, W, NB>();
+    constexpr int NPIX = LIN ? (W + 2 * HALO) * (3 + 2 * HALO) : KIND == DOWN ? 64 : (4 + 2 * HALO) * (4 + 2 * HALO);
+    constexpr int REGION = (NPIX * PS + 15) / 16 * 16;
+    constexpr int KGT = (C0 + C1) / 32 * ((ES == 4 && !SPLIT) ? 2 : 1);
+    return (size_t)NB * TAPS * KGT * (SPLIT ? 2 : 1) * FRAG + NWV * REGION;
 }
 
 template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL, bool RELU = (KIND == CONV3),

@@ -6,9 +6,12 @@
 // Kernel 1 (convin_project_kernel) fuses the 3-D conv, the ReLU and the three axis means, so the
 // 32x40^3 feature volume (8.2 MB/scene in the reference) is never written to memory.  Kernel 2
 // (conv16_kernel) is one LDS-staged implicit-GEMM convolution used for every U-Net layer.
+#include <cstdlib>
+
 #include "../../include/giga_hip.h"
 #include "giga_dev.h"
 #include "giga_conv16.h"
+#include "giga_args.h"
 
 namespace giga {
 
@@ -293,9 +296,6 @@ __global__ void plane_finalize_kernel(const float* __restrict__ xz_partial, cons
 //   P0 planes_in [3B,40,40,32] | A0 | S0 (skip 0) | Q0 [3B,20,20,32] | A1 [..,20,20,64] | S1 | Q1 [..,10,10,64]
 //   | A2 [..,10,10,128] | S2 | U0 [..,20,20,64] | A3 | A4 | U1 [..,40,40,32] | A5 | A6 | YZ partials fp32
 // ----------------------------------------------------------------------------------------------------
-struct EncWs {
-    size_t P0, A0, S0, Q0, A1, S1, Q1, A2, S2, U0, A3, A4, U1, A5, A6, YZ, XZ, total;   // XZ unused (kept for the ABI)
-};
 // x-parts of conv_in+project: 1 (8*B workgroups, five slices per wave) from 32 scenes up, else 5 (40*B workgroups)
 int enc_nxp(int B) { return B >= 32 ? 1 : 5; }
 
@@ -312,9 +312,126 @@ EncWs enc_workspace(int B, int precision) {
     w.U1 = take(n * 1600 * 32, es); w.A5 = take(n * 1600 * 32, es); w.A6 = take(n * 1600 * 32, es);
     w.YZ = take((size_t)(4 + enc_nxp(B)) * B * 1600 * 32, 4);   // 4 xz partials (iy-groups) + NXP yz partials (x-parts)
     w.XZ = w.YZ;
+    w.SYNC = take(64, 4);
     w.total = at;
     return w;
 }
+
+
+// ====================================================================================================
+// Persistent U-Net kernel: all 12 (13) layers of UNet.forward (encoder/unet.py:225-239) in ONE launch.
+//   At 32 scenes a U-Net layer is 10-55 us of which ~7 us is per-launch floor (dispatch gap, the weight fill into LDS, the
+//   first patch round trip, the tail) -- 13 launches, i.e. ~90 us of a 200-420 us encoder that no per-layer tuning removes.
+//   EXPERIMENT, NOT THE PRODUCT PATH: measured 573 vs 423 us (fp32, 32 scenes) -- see the profile note.  The idea:
+//   one workgroup per CU stays resident and walks the layers; between two layers there is a device-wide barrier (an
+//   agent-scope release -> atomic counter -> acquire, so that the other XCDs' L2 see the layer's output), and the NEXT
+//   layer's weight group is already streaming into LDS (LDS-DMA) while the workgroup waits at that barrier.
+//   The layer bodies are the conv16 stages (giga_conv16.h), unchanged: same arithmetic, same results as per-layer launches.
+//   Co-residency of the 256 workgroups is what the barrier needs; the spin is bounded (no hang if another kernel holds CUs:
+//   the flag word behind the counter is set and the host falls back to per-layer launches).
+// ====================================================================================================
+#define GIGA_UNET_LAYERS(X)                              \
+    X(0, CONV3, 32, 0, 32, 40, 40, 2, false)             \
+    X(1, CONV3, 32, 0, 32, 40, 40, 2, true)              \
+    X(2, CONV3, 32, 0, 64, 20, 20, 1, false)             \
+    X(3, CONV3, 64, 0, 64, 20, 20, 1, true)              \
+    X(4, CONV3, 64, 0, 128, 10, 10, 1, false)            \
+    X(5, CONV3, 128, 0, 128, 10, 10, 1, false)           \
+    X(6, UPCONV, 128, 0, 64, 10, 10, 2, false)           \
+    X(7, CONV3, 64, 64, 64, 20, 20, 1, false)            \
+    X(8, CONV3, 64, 0, 64, 20, 20, 1, false)             \
+    X(9, UPCONV, 64, 0, 32, 20, 20, 2, false)            \
+    X(10, CONV3, 32, 32, 32, 40, 40, 2, false)           \
+    X(11, CONV3, 32, 0, 32, 40, 40, 2, false)            \
+    X(12, CONV1, 32, 0, 32, 40, 40, 2, false)
+
+#ifdef GIGA_MEGA_EXPERIMENT   // measured slower than per-layer launches (profiles/r02e_persistent_unet_experiment.txt)
+struct MegaArgs {
+    ConvArgs layer[NCONV];
+    unsigned* sync;            // [0] arrival counter (zeroed before the launch), [1] set if a barrier timed out
+    int nlayers;               // 12 (conv_final folded into the decoder) or 13
+    int dbg;                   // experiment bits (GIGA_MEGA_DBG): 1 no fences, 2 no device barrier at all, 4 no sleep in the spin
+};
+constexpr int MEGA_NW = CONV_NW;                  // waves per workgroup of the persistent kernel
+
+template <typename T, bool SPLIT>
+constexpr size_t mega_lds_bytes() {
+    size_t m = 0;
+#define X(l, KIND, C0, C1, COUT, H, W, NB, POOL) \
+    { constexpr size_t v = conv_lds_bytes<T, KIND, C0, C1, COUT, H, W, NB, SPLIT>(); m = v > m ? v : m; }
+    GIGA_UNET_LAYERS(X)
+#undef X
+    return m;
+}
+
+__device__ __forceinline__ void grid_barrier(unsigned* sync, unsigned target, int dbg = 0) {
+    __syncthreads();                                          // the whole workgroup is done with the layer
+    if (dbg & 2) return;
+    if (threadIdx.x == 0) {
+        if (!(dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");    // this XCD's L2 writes back what the layer produced
+        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (!(dbg & 4)) __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 22)) {                       // seconds: never hang the device
+                __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        if (!(dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // drop stale lines before reading the other CUs' output
+    }
+    __syncthreads();
+}
+
+template <typename T, bool SPLIT>
+__global__ __launch_bounds__(MEGA_NW * 64) void unet_mega_kernel(MegaArgs m) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int block = (int)blockIdx.x, nblocks = (int)gridDim.x;
+    unsigned epoch = 0;
+#define X(l, KIND, C0, C1, COUT, H, W, NB, POOL)                                                                        \
+    if (l < m.nlayers) {                                                                                                \
+        if (l == 0) conv16_fill<T, KIND, C0, C1, COUT, NB, SPLIT>(m.layer[l], smem, block);                             \
+        conv16_run<T, KIND, C0, C1, COUT, H, W, NB, POOL, KIND == CONV3, SPLIT>(m.layer[l], smem, block, nblocks);      \
+    }
+#define FILL(l, KIND, C0, C1, COUT, H, W, NB, POOL)                                                                     \
+    if (l < m.nlayers) conv16_fill<T, KIND, C0, C1, COUT, NB, SPLIT>(m.layer[l], smem, block);
+    // layer l, then: everyone in the workgroup leaves its LDS -> request layer l+1's weights -> device barrier
+#define STEP(lcur, lnext_args)                                                                                           \
+    __syncthreads();                                                                                                    \
+    FILL lnext_args                                                                                                     \
+    grid_barrier(m.sync, ++epoch * (unsigned)nblocks, m.dbg);
+    X(0, CONV3, 32, 0, 32, 40, 40, 2, false)
+    STEP(0, (1, CONV3, 32, 0, 32, 40, 40, 2, true))
+    X(1, CONV3, 32, 0, 32, 40, 40, 2, true)
+    STEP(1, (2, CONV3, 32, 0, 64, 20, 20, 1, false))
+    X(2, CONV3, 32, 0, 64, 20, 20, 1, false)
+    STEP(2, (3, CONV3, 64, 0, 64, 20, 20, 1, true))
+    X(3, CONV3, 64, 0, 64, 20, 20, 1, true)
+    STEP(3, (4, CONV3, 64, 0, 128, 10, 10, 1, false))
+    X(4, CONV3, 64, 0, 128, 10, 10, 1, false)
+    STEP(4, (5, CONV3, 128, 0, 128, 10, 10, 1, false))
+    X(5, CONV3, 128, 0, 128, 10, 10, 1, false)
+    STEP(5, (6, UPCONV, 128, 0, 64, 10, 10, 2, false))
+    X(6, UPCONV, 128, 0, 64, 10, 10, 2, false)
+    STEP(6, (7, CONV3, 64, 64, 64, 20, 20, 1, false))
+    X(7, CONV3, 64, 64, 64, 20, 20, 1, false)
+    STEP(7, (8, CONV3, 64, 0, 64, 20, 20, 1, false))
+    X(8, CONV3, 64, 0, 64, 20, 20, 1, false)
+    STEP(8, (9, UPCONV, 64, 0, 32, 20, 20, 2, false))
+    X(9, UPCONV, 64, 0, 32, 20, 20, 2, false)
+    STEP(9, (10, CONV3, 32, 32, 32, 40, 40, 2, false))
+    X(10, CONV3, 32, 32, 32, 40, 40, 2, false)
+    STEP(10, (11, CONV3, 32, 0, 32, 40, 40, 2, false))
+    X(11, CONV3, 32, 0, 32, 40, 40, 2, false)
+    if (m.nlayers > 12) {
+        STEP(11, (12, CONV1, 32, 0, 32, 40, 40, 2, false))
+        X(12, CONV1, 32, 0, 32, 40, 40, 2, false)
+    }
+#undef STEP
+#undef FILL
+#undef X
+}
+#endif  // GIGA_MEGA_EXPERIMENT
 
 // probe: if probe_stage == k, ev0/ev1 (hipEvent_t) are recorded right before / after launch k
 // (k = 0 conv_in+project, 1 plane_finalize, 2..14 = U-Net layers 0..12).
@@ -369,29 +486,57 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     };
     uint8_t* b = ws;
     int rc = 0;
-    // template params: <T, KIND, C0, C1, COUT, H, W, NB (16-channel blocks per unit), POOL>
-    pre(); rc |= launch_conv<T, CONV3, 32, 0, 32, 40, 40, 2, false, true, SPLIT>(args(0, b + w.P0, nullptr, b + w.A0, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 32, 0, 32, 40, 40, 2, true, true, SPLIT>(args(1, b + w.A0, nullptr, b + w.S0, b + w.Q0), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 32, 0, 64, 20, 20, 1, false, true, SPLIT>(args(2, b + w.Q0, nullptr, b + w.A1, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 64, 0, 64, 20, 20, 1, true, true, SPLIT>(args(3, b + w.A1, nullptr, b + w.S1, b + w.Q1), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 64, 0, 128, 10, 10, 1, false, true, SPLIT>(args(4, b + w.Q1, nullptr, b + w.A2, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 128, 0, 128, 10, 10, 1, false, true, SPLIT>(args(5, b + w.A2, nullptr, b + w.S2, nullptr), s); post();
-    pre(); rc |= launch_conv<T, UPCONV, 128, 0, 64, 10, 10, 2, false, false, SPLIT>(args(6, b + w.S2, nullptr, b + w.U0, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 64, 64, 64, 20, 20, 1, false, true, SPLIT>(args(7, b + w.U0, b + w.S1, b + w.A3, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 64, 0, 64, 20, 20, 1, false, true, SPLIT>(args(8, b + w.A3, nullptr, b + w.A4, nullptr), s); post();
-    pre(); rc |= launch_conv<T, UPCONV, 64, 0, 32, 20, 20, 2, false, false, SPLIT>(args(9, b + w.A4, nullptr, b + w.U1, nullptr), s); post();
-    pre(); rc |= launch_conv<T, CONV3, 32, 32, 32, 40, 40, 2, false, true, SPLIT>(args(10, b + w.U1, b + w.S0, b + w.A5, nullptr), s); post();
     // GIGA_FOLD_FINAL: the caller's decoder carries conv_final inside its fc_c weights, so up1.conv2 writes straight
     // into the output planes and the last layer is not launched (its probe stage then brackets nothing)
     void* a6 = fold_final ? planes_nhwc : static_cast<void*>(b + w.A6);
-    pre(); rc |= launch_conv<T, CONV3, 32, 0, 32, 40, 40, 2, false, true, SPLIT>(args(11, b + w.A5, nullptr, a6, nullptr), s); post();
-    if (fold_final) {
-        pre(); post();
-    } else {
-        ConvArgs a = args(12, b + w.A6, nullptr, planes_nhwc, nullptr);
-        a.out_nchw = planes_nchw;
-        pre(); rc |= launch_conv<T, CONV1, 32, 0, 32, 40, 40, 2, false, false, SPLIT>(a, s); post();
+    ConvArgs L[NCONV] = {
+        args(0, b + w.P0, nullptr, b + w.A0, nullptr),  args(1, b + w.A0, nullptr, b + w.S0, b + w.Q0),
+        args(2, b + w.Q0, nullptr, b + w.A1, nullptr),  args(3, b + w.A1, nullptr, b + w.S1, b + w.Q1),
+        args(4, b + w.Q1, nullptr, b + w.A2, nullptr),  args(5, b + w.A2, nullptr, b + w.S2, nullptr),
+        args(6, b + w.S2, nullptr, b + w.U0, nullptr),  args(7, b + w.U0, b + w.S1, b + w.A3, nullptr),
+        args(8, b + w.A3, nullptr, b + w.A4, nullptr),  args(9, b + w.A4, nullptr, b + w.U1, nullptr),
+        args(10, b + w.U1, b + w.S0, b + w.A5, nullptr), args(11, b + w.A5, nullptr, a6, nullptr),
+        args(12, b + w.A6, nullptr, planes_nhwc, nullptr)};
+    L[12].out_nchw = planes_nchw;
+    const int nlayers = fold_final ? 12 : 13;
+#ifdef GIGA_MEGA_EXPERIMENT
+    // One persistent launch for the whole U-Net unless a single layer is being probed (stages 2..14) or the device cannot
+    // hold one workgroup per CU for 256 workgroups (GIGA_UNET_MEGA=0 forces per-layer launches: diagnostics).
+    static const bool mega_ok = [] {
+        const char* e = getenv("GIGA_UNET_MEGA");
+        if (e && atoi(e) == 0) return false;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+        return cus >= 256;
+    }();
+    const bool probe_layer = pr.stage >= 2 && pr.stage <= 14;
+    if (mega_ok && !probe_layer) {
+        MegaArgs m{};
+        for (int l = 0; l < NCONV; ++l) m.layer[l] = L[l];
+        m.sync = reinterpret_cast<unsigned*>(b + w.SYNC);
+        m.nlayers = nlayers;
+        static const int dbg = [] { const char* e = getenv("GIGA_MEGA_DBG"); return e ? atoi(e) : 0; }();
+        m.dbg = dbg;
+        if (hipMemsetAsync(m.sync, 0, 8, s) != hipSuccess) return -10;
+        auto kern = unet_mega_kernel<T, SPLIT>;
+        constexpr size_t lds = mega_lds_bytes<T, SPLIT>();
+        static_assert(lds <= 160 * 1024, "LDS budget of the persistent U-Net kernel");
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        stage_no = 15;                                        // probe stage 15 = the whole U-Net
+        pre();
+        hipLaunchKernelGGL(kern, dim3(256), dim3(MEGA_NW * 64), lds, s, m);
+        post();
+        return hipGetLastError() == hipSuccess ? 0 : -10;
     }
+#endif
+    if (pr.stage == 15) (void)hipEventRecord(pr.ev0, s);
+#define X(l, KIND, C0, C1, COUT, H, W, NB, POOL)                                                                          \
+    if (l < nlayers) { pre(); rc |= launch_conv<T, KIND, C0, C1, COUT, H, W, NB, POOL, KIND == CONV3, SPLIT>(L[l], s); post(); } \
+    else { pre(); post(); }
+    GIGA_UNET_LAYERS(X)
+#undef X
+    if (pr.stage == 15) (void)hipEventRecord(pr.ev1, s);
     return rc;
 }
 

@@ -10,6 +10,7 @@
 // Weight/bias gradients are ACCUMULATED into the flat fp32 gradient buffer (reference state-dict order) with
 // fp32 atomics (summation order is not fixed, as with PyTorch's own CUDA/HIP backward kernels).
 #include "giga_conv16.h"
+#include "giga_args.h"
 
 namespace giga {
 
@@ -604,7 +605,6 @@ BwdWs enc_bwd_workspace(int B) {
     return w;
 }
 
-struct EncWs { size_t P0, A0, S0, Q0, A1, S1, Q1, A2, S2, U0, A3, A4, U1, A5, A6, YZ, XZ, total; };
 EncWs enc_workspace(int B, int precision);
 int enc_nxp(int B);
 
