@@ -106,6 +106,27 @@ class UNet(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
 
+class _ScratchCache:
+    """Scratch device buffers keyed by (shape key, device, STREAM): a handful of entries in LRU order, so alternating batch
+    sizes (a planner at B = 1 next to an evaluation at B = 32) do not reallocate every call, and two streams never share
+    a workspace (the library is re-entrant per (stream, workspace): INTEGRATION.md section 4)."""
+
+    def __init__(self, entries=6):
+        from collections import OrderedDict
+        self._d, self._n = OrderedDict(), entries
+
+    def get(self, key, device, nbytes_fn):
+        k = key + (str(device), torch.cuda.current_stream(device).cuda_stream)
+        t = self._d.get(k)
+        if t is None:
+            t = self._d[k] = torch.empty(max(int(nbytes_fn()), 16), dtype=torch.uint8, device=device)
+            while len(self._d) > self._n:
+                self._d.popitem(last=False)
+        else:
+            self._d.move_to_end(k)
+        return t
+
+
 class PlaneDict(dict):
     """The reference's {'xz','xy','yz': (B,32,40,40)} dict, plus the NHWC image the HIP decoder
     reads (`nhwc`, `precision`).  Behaves as a plain dict for any reference-style consumer."""
@@ -201,7 +222,7 @@ class LocalVoxelEncoder(nn.Module):
         self.plane_type, self.padding = plane_type, padding
         self.precision = _DEFAULT_PRECISION
         self._packed = _PackedWeights()
-        self._ws = {}
+        self._ws = _ScratchCache()
 
     # -- HIP path ---------------------------------------------------------------------------------
     def _blob(self, device, blob=None):
@@ -225,12 +246,7 @@ class LocalVoxelEncoder(nn.Module):
         blob = self._blob(x.device, blob)
         nhwc = torch.empty((3, B, RES, RES, C_DIM), device=x.device, dtype=_capi.PLANE_DTYPE[prec])
         nchw = torch.empty((3, B, C_DIM, RES, RES), device=x.device, dtype=torch.float32) if want_nchw else None
-        key = (B, prec, str(x.device))
-        ws = self._ws.get(key)
-        if ws is None:
-            self._ws.clear()
-            ws = torch.empty(max(L.giga_encoder_workspace_bytes(B, prec), 16), dtype=torch.uint8, device=x.device)
-            self._ws[key] = ws
+        ws = self._ws.get((B, prec), x.device, lambda: L.giga_encoder_workspace_bytes(B, prec))
         stage, ev0, ev1 = probe if probe is not None else (-1, None, None)
         if fold_final and want_nchw:
             raise ValueError("fold_final planes are an internal representation; the reference layout needs the final planes")
@@ -282,7 +298,7 @@ def _planes_to_nhwc(c_plane, precision):
 # handed in through the one-line network switch of INTEGRATION.md -- is recognised FROM ITS DATA, once per tensor object
 # and version (one small comparison kernel + a host sync, then cached; negative results are cached too).
 _LATTICES = {}          # id(tensor) -> (weakref(tensor), version, (lin (R,) fp32 on the same device, R) or None)
-_LATTICE_WS = {}
+_LATTICE_WS = _ScratchCache()
 LATTICE_STATS = {"fast": 0, "generic": 0, "detected": 0}     # decode_heads launches per path (tests, diagnostics)
 
 
@@ -353,12 +369,7 @@ def decode_heads(nhwc, p, blob, head_mask, precision, post, probe=None, folded=F
         prec = _capi.PRECISION[precision]
         fold = _capi.FOLD_FINAL if folded else 0
         L = _capi.lib()
-        key = (B, R, prec, str(dev))
-        ws = _LATTICE_WS.get(key)
-        if ws is None:
-            _LATTICE_WS.clear()
-            ws = torch.empty(L.giga_lattice_workspace_bytes(B, R, prec), dtype=torch.uint8, device=dev)
-            _LATTICE_WS[key] = ws
+        ws = _LATTICE_WS.get((B, R, prec), dev, lambda: L.giga_lattice_workspace_bytes(B, R, prec))
         with torch.cuda.device(dev):
             _capi.check(L.giga_decoder_forward_lattice(
                 _capi.ptr(nhwc), _capi.ptr(lin), _capi.ptr(blob), head_mask,

@@ -4,8 +4,9 @@ section 8f-2.
 
 The reference splits the query set into `points_batch_size` chunks, moves each chunk to the device, calls
 `model.decode_occ(pi, c).logits` and copies every chunk back.  Here the planes stay cached on the device in the
-layout the decoder reads (`PlaneDict.nhwc`, produced once by `encode_inputs`), the fused decoder takes the whole
-query set in ONE launch (there is no activation tensor whose size would call for chunking), and a regular grid of
+layout the decoder reads (`PlaneDict.nhwc`, produced once by `encode_inputs`), the fused decoder takes a whole
+chunk in ONE launch (there is no activation tensor whose size would call for chunking: `points_batch_size` only bounds
+the device copy of a HOST-resident query set, one chunk in flight at a time), and a regular grid of
 queries takes the lattice path (each plane sampled once per lattice coordinate pair).  Mesh extraction
 (`extract_mesh`, marching cubes via libmcubes) is host code outside the hot path and not part of this package."""
 import torch
@@ -17,15 +18,15 @@ from .convonet import register_lattice
 class Generator3D:
     """generation.py:22-75 (the arguments that matter for the voxel-input GIGA models)."""
 
-    def __init__(self, model, points_batch_size=100000, threshold=0.5, device=None, resolution0=16,
-                 upsampling_steps=3, padding=0.1, **unused):
+    def __init__(self, model, points_batch_size=100000, threshold=0.5, device=None, resolution0=16, **mesh_options):
+        """`threshold`, `upsampling_steps`, `padding`, ... of generation.py:36-58 steer the host-side mesh extraction
+        (marching cubes / MISE), which is outside this package: they are accepted and kept in `mesh_options` untouched."""
         self.model = model
-        self.points_batch_size = points_batch_size
+        self.points_batch_size = int(points_batch_size)
         self.threshold = threshold
         self.device = device if device is not None else torch.device("cuda")
         self.resolution0 = resolution0
-        self.upsampling_steps = upsampling_steps
-        self.padding = padding
+        self.mesh_options = dict(mesh_options)
         self._grids = {}
 
     def encode(self, inputs):
@@ -38,9 +39,14 @@ class Generator3D:
         unit cube, on any device; returns the occupancy logits on the device, (N,) or (B,N).  One launch; the
         reference's chunk loop and per-chunk D->H copy disappear (use `.cpu()` for its return type)."""
         squeeze = p.dim() == 2
-        pts = (p.unsqueeze(0) if squeeze else p).to(self.device, torch.float32)
+        pts = p.unsqueeze(0) if squeeze else p
         with torch.no_grad():
-            logits = self.model.decode_occ(pts, c, **kwargs).logits
+            if pts.is_cuda or pts.shape[1] <= self.points_batch_size:
+                logits = self.model.decode_occ(pts.to(self.device, torch.float32), c, **kwargs).logits
+            else:                                             # host-resident queries: bounded device footprint (generation.py:337)
+                parts = [self.model.decode_occ(ch.to(self.device, torch.float32), c, **kwargs).logits
+                         for ch in torch.split(pts, self.points_batch_size, dim=1)]
+                logits = torch.cat(parts, dim=1)
         return logits.squeeze(0) if squeeze else logits
 
     def grid_points(self, resolution, lo=-0.5, hi=0.5):

@@ -284,6 +284,8 @@ def test_generation_eval_points_and_grid(sd7, golden):
         got = gen.eval_points(p, c).cpu()
         assert got.shape == ref.shape
         assert (got - ref).abs().max().item() < 1e-4
+    chunked = Generator3D(net, points_batch_size=1000, device=dev, threshold=0.3, upsampling_steps=2)   # host queries in 5 chunks
+    assert torch.equal(chunked.eval_points(p, c), got.to(dev)) and chunked.mesh_options["upsampling_steps"] == 2
     one = gen.eval_points(p[0], {k: v[:1] for k, v in c.items()}).cpu()      # (N,3) form, reference-style dict
     assert (one - ref[0]).abs().max().item() < 1e-4
     g7 = golden("g7_generation.npz")                        # the reference's own Generator3D.eval_points on scene 70
