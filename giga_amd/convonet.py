@@ -126,6 +126,10 @@ class _ScratchCache:
             self._d.move_to_end(k)
         return t
 
+    def snapshot(self):
+        """The cached buffers (a hipGraph that baked their addresses in keeps them alive with this list)."""
+        return list(self._d.values())
+
 
 class PlaneDict(dict):
     """The reference's {'xz','xy','yz': (B,32,40,40)} dict, plus the NHWC image the HIP decoder

@@ -248,13 +248,13 @@ class VGNImplicit:
                 for _ in range(2):
                     run()
             torch.cuda.current_stream(self.device).wait_stream(side)
-            # the graph bakes in the encoder / lattice workspaces the warm-up left in their one-entry caches; those
-            # caches drop their entry when another batch size comes along, so the graph keeps its own references
             from . import convonet
-            keep = (dict(self.net.encoder._ws), dict(convonet._LATTICE_WS))
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 run()
+            # the graph bakes in the encoder / lattice workspaces it used (the scratch caches are keyed by stream, so the
+            # capture got its own entries); the caches evict in LRU order, so the graph keeps its own references
+            keep = (self.net.encoder._ws.snapshot(), convonet._LATTICE_WS.snapshot())
             ent = self._graphs[key] = (graph, static_in, static_proc, buf, (prm, keep))
         graph, static_in, static_proc, buf, _ = ent
         static_in.copy_(tsdf)
