@@ -229,30 +229,78 @@ def main():
     T = float(t_elapsed.item())
     scenes_per_s = total_scenes / T
 
-    # -------- N > 1 legs (every rank takes part; outside the timed region) ---------------------------------
+    def finish():                          # every rank leaves together: no rank tears the communicator down early
+        if dist is not None:
+            import threading
+            t = threading.Timer(60.0, lambda: os._exit(0))   # (a rank that died must not keep the others here for ever)
+            t.daemon = True
+            t.start()
+            dist.barrier()
+            dist.destroy_process_group()
+            t.cancel()
+
+    # The contract line is assembled BEFORE the multi-GPU extras run, and a watchdog prints it if they hang: a collective
+    # that one rank never enters (an exception elsewhere, a wedged RCCL ring) must not cost the scaling run its numbers.
+    out = core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, dec_occ_ms, dom, dom_ms, step_ms) if rank == 0 else None
+    extra = dict(multi)
     if dist is not None and not args.no_extra:
+        import threading
+
+        def bail():
+            if rank == 0:
+                extra["multi_gpu_extras"] = "timed out after 240 s (a collective did not complete); core numbers are unaffected"
+                out["extra"] = extra
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(240.0, bail)
+        dog.daemon = True
+        dog.start()
         try:
-            multi["c3_gather"] = bench_c3_gather(net, x, pos, pos_occ, sharding, dist, rccl, rank, world, B, dev)
+            extra["c3_gather"] = bench_c3_gather(net, x, pos, pos_occ, sharding, dist, rccl, rank, world, B, dev)
         except Exception as e:  # noqa: BLE001
-            multi["c3_gather"] = {"error": f"{type(e).__name__}: {e}"}
+            extra["c3_gather"] = {"error": f"{type(e).__name__}: {e}"}
         try:
             net.enable_data_parallel(group=rccl)
-            multi["c5_train_step_fp32_data_parallel"] = bench_train(net, dev, synth, B, M, rank=rank, world=world, sync=barrier)
+            extra["c5_train_step_fp32_data_parallel"] = bench_train(net, dev, synth, B, M, rank=rank, world=world, sync=barrier)
         except Exception as e:  # noqa: BLE001
-            multi["c5_train_step_fp32_data_parallel"] = {"error": f"{type(e).__name__}: {e}"}
+            extra["c5_train_step_fp32_data_parallel"] = {"error": f"{type(e).__name__}: {e}"}
         finally:
             net.enable_data_parallel(enabled=False)
             net.eval().set_precision("fp32")
-
-    def finish():                          # every rank leaves together: no rank tears the communicator down early
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        dog.cancel()
 
     if rank != 0:
         finish()
         return
 
+    single = world == 1 and dist is None
+    if single and not args.no_extra:
+        legs = (("c4", lambda: bench_c4_all(net, dev, L, _capi, synth, decode_heads)),
+                ("c2_ii", lambda: bench_c2_ii(net, dev, synth, B)),
+                ("c2_fp16x3", lambda: bench_c2_mode(net, x, pos, pos_occ, "fp16x3")),
+                ("c5_train_step_fp32", lambda: bench_train(net, dev, synth, B, M)))
+        for key, fn in legs:
+            try:
+                r = fn()
+                if key == "c4":
+                    extra.update(r)
+                else:
+                    extra[key] = r
+            except Exception as e:  # noqa: BLE001
+                extra[key + "_error"] = f"{type(e).__name__}: {e}"
+    if extra:
+        out["extra"] = extra
+
+    # -------- CPU baseline: the oracle (port of the reference path) on the host cores -------------------
+    if single and not args.no_cpu_baseline:               # rank 0 at N = 1 only
+        out["cpu_baseline"] = cpu_baseline(sd, synth, M)
+    print(json.dumps(out), flush=True)
+    finish()
+
+
+def core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, dec_occ_ms, dom, dom_ms, step_ms):
+    """The contract keys + roofline of the timed region (rank 0)."""
     # HBM bytes per launch: PMC counters cannot be collected from inside this process, so they come from the committed
     # rocprofv3 PMC table of the same workload (tools/gpu_traffic.sh -> profiles/*traffic_c2.json), stamped with the commit
     # and kernel it was measured on; null when the table has no entry for this kernel / batch size.
@@ -314,30 +362,7 @@ def main():
         "stage_note": "unet.conv_final is not launched in this call: the 1x1 convolution is folded into the heads' fc_c weights "
                       "(GIGA_FOLD_FINAL); its entry is the empty event bracket",
     }
-    extra = dict(multi)
-    single = world == 1 and dist is None
-    if single and not args.no_extra:
-        legs = (("c4", lambda: bench_c4_all(net, dev, L, _capi, synth, decode_heads)),
-                ("c2_ii", lambda: bench_c2_ii(net, dev, synth, B)),
-                ("c2_fp16x3", lambda: bench_c2_mode(net, x, pos, pos_occ, "fp16x3")),
-                ("c5_train_step_fp32", lambda: bench_train(net, dev, synth, B, M)))
-        for key, fn in legs:
-            try:
-                r = fn()
-                if key == "c4":
-                    extra.update(r)
-                else:
-                    extra[key] = r
-            except Exception as e:  # noqa: BLE001
-                extra[key + "_error"] = f"{type(e).__name__}: {e}"
-    if extra:
-        out["extra"] = extra
-
-    # -------- CPU baseline: the oracle (port of the reference path) on the host cores -------------------
-    if single and not args.no_cpu_baseline:               # rank 0 at N = 1 only
-        out["cpu_baseline"] = cpu_baseline(sd, synth, M)
-    print(json.dumps(out), flush=True)
-    finish()
+    return out
 
 
 def bench_c3_gather(net, x, pos, pos_occ, sharding, dist, rccl, rank, world, B, dev):
