@@ -60,6 +60,29 @@ STAGE_NAMES = ["convin_project", "plane_finalize"] + [
 HEADLINE_STAGE = 0                      # convin_project: the kernel VERDICT r01 names; see pick_headline()
 
 
+# kernel-name fragments (rocprofv3 names) of the stages whose HBM traffic bench.py quotes from the committed PMC tables
+TRAFFIC_KERNEL = {"convin_project": "convin_project_kernel<float, 5, false>",
+                  "unet.up0.conv1": "conv16_kernel<float, 0, 64, 64, 64, 20, 20, 1, false, true, false>",
+                  "unet.up1.conv1": "conv16_kernel<float, 0, 32, 32, 32, 40, 40, 2, false, true, false>"}
+
+
+def traffic_lookup(workload, fragment):
+    """HBM bytes per launch of the kernel whose name contains `fragment`, from profiles/r02_traffic_<workload>.json (two
+    rocprofv3 PMC passes, tools/gpu_traffic.sh): PMC counters cannot be collected from inside this process.  Returns
+    (bytes or None, provenance or None)."""
+    if not fragment:
+        return None, None
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", f"r02_traffic_{workload}.json")))
+    except (OSError, ValueError):
+        return None, None
+    for name, ent in tab.get("kernels", {}).items():
+        if fragment in name:
+            return ent["bytes"], {"table": f"profiles/r02_traffic_{workload}.json", "commit": tab.get("commit"), "kernel": name,
+                                  "fetch_kib": ent["fetch_kib"], "write_kib": ent["write_kib"]}
+    return None, None
+
+
 def stage_flops(stage, B):
     """Algorithmic FLOPs of one launch of encoder stage `stage` for B scenes."""
     if stage == 0:
@@ -304,17 +327,7 @@ def core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, d
     # HBM bytes per launch: PMC counters cannot be collected from inside this process, so they come from the committed
     # rocprofv3 PMC table of the same workload (tools/gpu_traffic.sh -> profiles/*traffic_c2.json), stamped with the commit
     # and kernel it was measured on; null when the table has no entry for this kernel / batch size.
-    traffic, traffic_src = None, None
-    for name in ("r02_traffic_c2.json", "r01_traffic_c2.json"):
-        try:
-            tab = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if B == 32 and STAGE_NAMES[dom] in tab["stages"]:
-                traffic = tab["stages"][STAGE_NAMES[dom]]["bytes"]
-                traffic_src = {"table": "profiles/" + name, "commit": tab.get("commit"),
-                               "kernel": tab["stages"][STAGE_NAMES[dom]].get("kernel")}
-                break
-        except (OSError, ValueError, KeyError):
-            pass
+    traffic, traffic_src = traffic_lookup("c2", TRAFFIC_KERNEL.get(STAGE_NAMES[dom])) if B == 32 else (None, None)
     dom_avg_ms = float(np.mean(dom_ms))
     dom_flops = stage_flops(dom, B)
     achieved = dom_flops / (dom_avg_ms * 1e-3) / 1e12
@@ -442,8 +455,10 @@ def bench_c4(net, dev, L, _capi, synth, decode_heads, prec, Bc=32, steps=10):
     ach = flops / (dec_ms * 1e-3) / 1e12
     net.set_precision("fp32")
     split = prec == "fp16x3"
+    tr, tr_src = traffic_lookup("c4step_x3" if split else "c4step", "decoder_f16s_kernel<2, true, 8, true>" if split else
+                                "decoder_f16_kernel<2, true, 12>") if Bc == 32 else (None, None)
     roof = {"kernel": "decoder_f16s_kernel" if split else "decoder_f16_kernel", "bound": "mfma", "achieved": ach,
-            "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+            "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": tr, "traffic_source": tr_src,
             "frac_of_measured_peak": ach / MEASURED_F16_MFMA_TFLOPS, "avg_launch_ms": dec_ms, "flops_per_launch": flops}
     if split:
         roof["issued_mfma_tflops"] = ach * SPLIT_MFMA_PER_PLAIN

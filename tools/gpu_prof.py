@@ -36,6 +36,23 @@ with torch.no_grad():
         nhwc, _ = net.encoder.encode_nhwc(x, blob=blob, precision="fp16")
         lat = query_lattice(40, dev)
         run(lambda: decode_heads(nhwc, lat, blob, 7, "fp16", True))
+    elif what in ("c4step", "c4step_x3"):                  # the whole c4 step: encoder + lattice resample + fused decoder
+        from giga_amd.detection import query_lattice
+        prec = "fp16x3" if what.endswith("x3") else "fp16"
+        net.set_precision(prec); blob = net.packed_blob(dev)
+        x = torch.from_numpy(synth.tsdf_batch(0, B)).to(dev)
+        lat = query_lattice(40, dev)
+
+        def c4():
+            nhwc, _ = net.encoder.encode_nhwc(x, blob=blob, precision=prec, fold_final=True)
+            return decode_heads(nhwc, lat, blob, 7, prec, True, folded=True)
+        run(c4)
+    elif what == "c2_x3":
+        net.set_precision("fp16x3")
+        x = torch.from_numpy(synth.tsdf_batch(0, B)).to(dev)
+        pos = torch.from_numpy(synth.query_points(0, B, 1, stream=2)).to(dev)
+        occ = torch.from_numpy(synth.query_points(0, B, 2048, stream=3)).to(dev)
+        run(lambda: net(x, pos, p_tsdf=occ))
     elif what == "c4dec":
         net.set_precision("fp16"); blob = net.packed_blob(dev)
         x = torch.from_numpy(synth.tsdf_batch(0, B)).to(dev)

@@ -1,42 +1,31 @@
-"""profiles/r01_traffic_c2.json from the table printed by tools/gpu_traffic.sh (gpurun_out/final/traffic.txt)."""
+"""Per-kernel HBM traffic table from the two rocprofv3 PMC passes of tools/gpu_traffic.sh:
+    python tools/make_traffic_table.py gpurun_out/traffic/<workload> out.json <workload>
+bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024: FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide
+coalesced read stream); that correction is calibrated for 16 B/lane streams, so the read side is an upper bound for kernels
+with narrower loads.  bench.py looks kernels up by name fragment (roofline.traffic)."""
+import collections
+import csv
+import glob
 import json
-import re
+import os
 import sys
 
-STAGE_OF = {   # kernel-name fragment -> stage names of bench.py that run this instantiation
-    "convin_project_kernel<float,": ["convin_project"],
-    "plane_finalize_kernel<float>": ["plane_finalize"],
-    "conv16_kernel<float, 0, 32, 0, 32, 40, 40, 2, false, true>": ["unet.down0.conv1", "unet.up1.conv2"],
-    "conv16_kernel<float, 0, 32, 0, 32, 40, 40, 2, true, true>": ["unet.down0.conv2+pool"],
-    "conv16_kernel<float, 0, 32, 0, 64, 20, 20, 1, false, true>": ["unet.down1.conv1"],
-    "conv16_kernel<float, 0, 64, 0, 64, 20, 20, 1, true, true>": ["unet.down1.conv2+pool"],
-    "conv16_kernel<float, 0, 64, 0, 128, 10, 10, 1, false, true>": ["unet.down2.conv1"],
-    "conv16_kernel<float, 0, 128, 0, 128, 10, 10, 1, false, true>": ["unet.down2.conv2"],
-    "conv16_kernel<float, 1, 128, 0, 64, 10, 10, 2, false, false>": ["unet.up0.upconv"],
-    "conv16_kernel<float, 0, 64, 64, 64, 20, 20, 1, false, true>": ["unet.up0.conv1"],
-    "conv16_kernel<float, 0, 64, 0, 64, 20, 20, 1, false, true>": ["unet.up0.conv2"],
-    "conv16_kernel<float, 1, 64, 0, 32, 20, 20, 2, false, false>": ["unet.up1.upconv"],
-    "conv16_kernel<float, 0, 32, 32, 32, 40, 40, 2, false, true>": ["unet.up1.conv1"],
-    "conv16_kernel<float, 2, 32, 0, 32, 40, 40, 2, false, false>": ["unet.conv_final"],
-    "decoder_f32_kernel<2, false>": ["decoder_occ"],
-}
-
-src, dst = sys.argv[1], sys.argv[2]
-stages = {}
-for line in open(src):
-    m = re.match(r"^(void giga::.*?)\s+([\d.]+)\s+(\d+)\s+([\d.]+)\s+(\d+)\s*$", line)
-    if not m:
+src, dst, workload = sys.argv[1], sys.argv[2], sys.argv[3]
+tot = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        t = tot[r["Kernel_Name"]][r["Counter_Name"]]
+        t[0] += float(r["Counter_Value"]); t[1] += 1
+kernels = {}
+print(f"== {workload}")
+print(f"{'kernel':100s} {'FETCH_SIZE(KiB)':>16s} {'WRITE_SIZE(KiB)':>16s} {'bytes':>14s}")
+for k, cs in sorted(tot.items()):
+    if "giga" not in k:
         continue
-    name, fk, _, wk, _ = m.groups()
-    for frag, names in STAGE_OF.items():
-        if frag in name:
-            for st in names:
-                stages[st] = {"kernel": name.strip(), "fetch_kib": float(fk), "write_kib": float(wk),
-                              "bytes": int((2 * float(fk) + float(wk)) * 1024)}
-out = {"_about": "HBM traffic per launch of the c2 step (B=32, fp32) from rocprofv3 PMC, FETCH_SIZE and WRITE_SIZE in separate "
-                 "--pmc passes (tools/gpu_traffic.sh). Units KiB. bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE is "
-                 "doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read stream); that correction is "
-                 "calibrated for 16 B/lane streams only, so the read side is an upper bound for kernels with narrower loads.",
-       "stages": stages}
-json.dump(out, open(dst, "w"), indent=1)
-print(len(stages), "stages")
+    fs = cs["FETCH_SIZE"][0] / max(cs["FETCH_SIZE"][1], 1)
+    wsz = cs["WRITE_SIZE"][0] / max(cs["WRITE_SIZE"][1], 1)
+    kernels[k] = {"fetch_kib": round(fs, 1), "write_kib": round(wsz, 1), "bytes": int((2 * fs + wsz) * 1024),
+                  "launches_sampled": cs["FETCH_SIZE"][1]}
+    print(f"{k[:100]:100s} {fs:16.1f} {wsz:16.1f} {kernels[k]['bytes']:14d}")
+json.dump({"_about": __doc__.strip(), "workload": workload + " (tools/gpu_prof.py), 32 scenes", "commit": os.environ.get("GIGA_COMMIT"),
+           "kernels": kernels}, open(dst, "w"), indent=1)
