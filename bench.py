@@ -285,9 +285,11 @@ def main():
             extra["c3_gather"] = {"error": f"{type(e).__name__}: {e}"}
         try:
             net.enable_data_parallel(group=rccl)
-            extra["c5_train_step_fp32_data_parallel"] = bench_train(net, dev, synth, B, M, rank=rank, world=world, sync=barrier)
+            for prec in ("bf16", "fp32"):                    # BASELINE c5 names bf16; the fp32 step beside it
+                extra[f"c5_train_step_{prec}_data_parallel"] = bench_train(net, dev, synth, B, M, rank=rank, world=world,
+                                                                              sync=barrier, precision=prec)
         except Exception as e:  # noqa: BLE001
-            extra["c5_train_step_fp32_data_parallel"] = {"error": f"{type(e).__name__}: {e}"}
+            extra["c5_train_step_data_parallel_error"] = f"{type(e).__name__}: {e}"
         finally:
             net.enable_data_parallel(enabled=False)
             net.eval().set_precision("fp32")
@@ -302,7 +304,9 @@ def main():
         legs = (("c4", lambda: bench_c4_all(net, dev, L, _capi, synth, decode_heads)),
                 ("c2_ii", lambda: bench_c2_ii(net, dev, synth, B)),
                 ("c2_fp16x3", lambda: bench_c2_mode(net, x, pos, pos_occ, "fp16x3")),
-                ("c5_train_step_fp32", lambda: bench_train(net, dev, synth, B, M)))
+                ("c5_train_step_fp32_param_list", lambda: bench_train(net, dev, synth, B, M, flat=False)),
+                ("c5_train_step_fp32", lambda: bench_train(net, dev, synth, B, M)),
+                ("c5_train_step_bf16", lambda: bench_train(net, dev, synth, B, M, precision="bf16")))
         for key, fn in legs:
             try:
                 r = fn()
@@ -519,20 +523,21 @@ def bench_c2_mode(net, x, pos, pos_occ, prec, steps=30):
             "ms_per_step": el * 1e3, "step_ms_median": float(np.median(per)), "scenes_per_sec": B / el}
 
 
-def bench_train(net, dev, synth, B, M, steps=50, rank=0, world=1, sync=None):
+def bench_train(net, dev, synth, B, M, steps=50, rank=0, world=1, sync=None, precision="fp32", flat=True):
     """One optimisation step of scripts/train_giga.py:198-211 on this rank's scenes: forward, the fused joint loss
     (giga_amd.training.giga_loss = select + loss_fn of the reference), HIP backward, fused Adam.  world > 1: the backward
     all-reduces (means) the flat gradient bucket over RCCL (net.enable_data_parallel), BASELINE config c5."""
     from giga_amd.training import giga_loss
-    net.set_precision("fp32").train()
+    net.set_precision("fp32").train().set_train_precision(precision)
     first = 2000 + rank * B
     x = torch.from_numpy(synth.tsdf_batch(first, B)).to(dev)
     pos = torch.from_numpy(synth.query_points(first, B, 1, stream=2)).to(dev)
     pos_occ = torch.from_numpy(synth.query_points(first, B, M, stream=3)).to(dev)
     y = tuple(torch.from_numpy(a).to(dev) for a in synth.train_labels(first, B, M))
-    # the reference's optimiser (train_giga.py:49: Adam, lr 2e-4) in torch's single-launch form; the default
-    # per-tensor foreach path costs 6 ms of host time per step for the 164 parameter tensors
-    opt = torch.optim.Adam(net.parameters(), lr=2e-4, fused=True)
+    # the reference's optimiser (train_giga.py:49: Adam, lr 2e-4) in torch's fused form (the default per-tensor foreach path
+    # costs 6 ms of host time per step for the 164 parameter tensors); flat: over the module's single flat parameter
+    # (net.flatten_parameters(): one Adam launch instead of five, no per-step flattening copy, one gradient for autograd)
+    opt = torch.optim.Adam(net.flatten_parameters() if flat else [q for q in net.parameters() if q.requires_grad], lr=2e-4, fused=True)
     last = {}
 
     def step():
@@ -549,9 +554,12 @@ def bench_train(net, dev, synth, B, M, steps=50, rank=0, world=1, sync=None):
     el, per = _time_steps(step, steps, 0)
     if sync is not None:
         sync()
-    net.eval()
+    net.eval().set_train_precision("fp32")
+    arith = ("bf16 MFMA operands / fp32 accumulate in the U-Net's forward and data-gradient convolutions, fp32 elsewhere (weight "
+             "gradients, decoders, conv_in, master weights)") if precision == "bf16" else "fp32"
     return {"workload": f"joint GIGA training step (train_giga.py:198-211): B={B} scenes/GPU, 1 grasp query + {M} "
-                        f"occupancy queries, forward + fused loss + HIP backward + fused Adam, fp32, {world} GPU"
+                        f"occupancy queries, forward + fused loss + HIP backward + fused Adam"
+                        f"{' over one flat parameter' if flat else ' over the 164 parameter tensors'}, {arith}, {world} GPU"
                         + (", one RCCL all-reduce of the flat gradient bucket per step" if world > 1 else ""),
             "steps": steps, "ms_per_step": el * 1e3, "step_ms_median": float(np.median(per)), "step_ms_max": float(np.max(per)),
             "step_ms_p90": float(np.percentile(per, 90)), "scenes_per_sec": world * B / el,

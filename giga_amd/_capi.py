@@ -15,10 +15,13 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgiga_hip.so")
 
 HEAD_QUAL, HEAD_ROT, HEAD_WIDTH, HEAD_TSDF = 1, 2, 4, 8
 DETACH_OCC = 16          # GIGA_DETACH_OCC: flag for giga_backward's head_present
+BF16_CONVS = 32          # GIGA_BF16_CONVS: dgrad convolutions on bf16 MFMA (giga_backward's head_present)
+ENC_BF16 = 3             # encoder `precision` 3: bf16 U-Net convolutions, fp32 activations in memory
 FOLD_FINAL = 16          # GIGA_FOLD_FINAL: OR-ed into `precision` of an encoder call and of the decoder calls on its planes
 HEAD_BITS = {"decoder_qual": 1, "decoder_rot": 2, "decoder_width": 4, "decoder_tsdf": 8}
-PRECISION = {"fp32": 0, "fp16": 1, "fp16x3": 2}     # include/giga_hip.h `precision`
-PLANE_DTYPE = {0: torch.float32, 1: torch.float16, 2: torch.float32}   # element type of the NHWC planes per precision
+PRECISION = {"fp32": 0, "fp16": 1, "fp16x3": 2, "bf16": 3}     # include/giga_hip.h `precision` (3: encoder only)
+PLANE_DTYPE = {0: torch.float32, 1: torch.float16, 2: torch.float32, 3: torch.float32}   # element type of the NHWC planes
+DECODER_PRECISION = {0: 0, 1: 1, 2: 2, 3: 0}         # "bf16" = bf16 U-Net convolutions; the decoders run their fp32 kernels
 
 _lib = None
 
@@ -45,6 +48,7 @@ _SIGNATURES = {
                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "giga_derive_bf16_fragments": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "giga_bwd_packed_bytes": (ctypes.c_size_t, []),
     "giga_pack_bwd_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
                                              ctypes.c_size_t]),

@@ -286,7 +286,7 @@ def _planes_to_nhwc(c_plane, precision):
     for t in xs:
         if tuple(t.shape) != (B, C_DIM, RES, RES):
             raise ValueError(f"expected (B,{C_DIM},{RES},{RES}) planes, got {tuple(t.shape)}")
-    prec = _capi.PRECISION[precision]
+    prec = _capi.DECODER_PRECISION[_capi.PRECISION[precision]]
     nhwc = torch.empty((3, B, RES, RES, C_DIM), device=xs[0].device, dtype=_capi.PLANE_DTYPE[prec])
     with torch.cuda.device(_capi.device_of(*xs)):
         _capi.check(_capi.lib().giga_planes_pack(_capi.ptr(xs[0]), _capi.ptr(xs[1]), _capi.ptr(xs[2]),
@@ -370,7 +370,7 @@ def decode_heads(nhwc, p, blob, head_mask, precision, post, probe=None, folded=F
     LATTICE_STATS["fast" if lat is not None else "generic"] += 1
     if lat is not None:
         lin, R = lat
-        prec = _capi.PRECISION[precision]
+        prec = _capi.DECODER_PRECISION[_capi.PRECISION[precision]]
         fold = _capi.FOLD_FINAL if folded else 0
         L = _capi.lib()
         ws = _LATTICE_WS.get((B, R, prec), dev, lambda: L.giga_lattice_workspace_bytes(B, R, prec))
@@ -387,7 +387,7 @@ def decode_heads(nhwc, p, blob, head_mask, precision, post, probe=None, folded=F
             _capi.ptr(nhwc), _capi.ptr(p), _capi.ptr(blob), head_mask,
             _capi.ptr(out.get("decoder_qual")), _capi.ptr(out.get("decoder_rot")),
             _capi.ptr(out.get("decoder_width")), _capi.ptr(out.get("decoder_tsdf")),
-            B, N, _capi.PRECISION[precision] | (_capi.FOLD_FINAL if folded else 0), 1 if post else 0,
+            B, N, _capi.DECODER_PRECISION[_capi.PRECISION[precision]] | (_capi.FOLD_FINAL if folded else 0), 1 if post else 0,
             _capi.stream_ptr(dev), ev0, ev1),
             "giga_decoder_forward")
     return out
@@ -467,6 +467,9 @@ class _ParamListCache:
 
     def _apply(self, fn, *args, **kwargs):
         self.invalidate_packed()
+        if self.__dict__.pop("_flat_param", None) is not None:     # torch is about to replace the storages: un-flatten
+            for q in self.parameters():
+                q.requires_grad_(True)
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
@@ -497,7 +500,8 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
     # -- weights ----------------------------------------------------------------------------------
     def set_precision(self, precision):
         """'fp32' (exact fp32 MFMA, default), 'fp16' (f16 operands, fp32 accumulate: 2-5e-3 on raw logits) or 'fp16x3'
-        (f16 MFMA on split hi/lo operands: fp32-grade results, <= 1e-5, at ~5x the fp32-MFMA rate; fp32 encoder)."""
+        (f16 MFMA on split hi/lo operands in encoder and decoders: fp32-grade results, <= 1e-5, at ~5x the fp32-MFMA rate);
+        'bf16' = the training step's forward arithmetic (bf16 U-Net convolutions, everything else fp32), ~1e-2."""
         if precision not in _capi.PRECISION:
             raise ValueError(precision)
         self.precision = precision
@@ -523,7 +527,8 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
         qual (B,N) [sigmoid], rot (B,N,4) [unit], width (B,N) [, tsdf (B,M) raw logits].
         (`_probe`: bench.py's HIP-event bracket around one encoder kernel; not part of the API.)"""
         _capi.require_device(inputs, p, p_tsdf)
-        if torch.is_grad_enabled() and any(q.requires_grad for q in self._ordered_params()):
+        fp = self.__dict__.get("_flat_param")
+        if torch.is_grad_enabled() and (fp.requires_grad if fp is not None else any(q.requires_grad for q in self._ordered_params())):
             return self._forward_train(inputs, p, p_tsdf)
         blob = self.packed_blob(inputs.device)
         # encoder and decoders are called back to back here, so conv_final is folded into the heads' fc_c weights and
@@ -543,6 +548,45 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
                 params += _head_param_list(getattr(self, h))
         return params + _encoder_param_list(self.encoder)
 
+    def flatten_parameters(self):
+        """Optional fast path for training loops: every parameter becomes a VIEW of one flat fp32 tensor in state-dict order,
+        and that tensor is the single trainable leaf:
+
+            opt = torch.optim.Adam(net.flatten_parameters(), lr=2e-4, fused=True)
+
+        The optimizer then updates all 581 863 weights in one launch (the 164-tensor fused Adam takes five launches of 31 us),
+        the per-step flattening copy disappears and autograd handles one gradient instead of 164.  `state_dict()`,
+        `load_state_dict()` and `named_parameters()` keep their reference keys and shapes (they are the views); the individual
+        Parameters stop requiring grad, so build the optimizer from the returned list, not from `net.parameters()`.
+        `.to()` / `.float()` undo the flattening (torch replaces the storages).  Returns [flat_parameter]."""
+        fp = self.__dict__.get("_flat_param")
+        if fp is not None:
+            return [fp]
+        params = self._ordered_params()
+        flat = torch.cat([q.detach().reshape(-1).float() for q in params])
+        at = 0
+        for q in params:
+            n = q.numel()
+            q.data = flat[at:at + n].view(q.shape)
+            q.requires_grad_(False)
+            at += n
+        fp = self.__dict__["_flat_param"] = torch.nn.Parameter(flat)
+        self.invalidate_packed()
+        self.__dict__["_flat_param"] = fp                    # (invalidate_packed keeps it; _apply drops it)
+        return [fp]
+
+    def set_train_precision(self, precision):
+        """Arithmetic of the differentiable forward/backward (giga_amd/training.py): "fp32" (default) or "bf16" (bf16 MFMA
+        operands in the U-Net's forward and data-gradient convolutions, fp32 everywhere else; BASELINE config c5)."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(precision)
+        self._train_bf16 = precision == "bf16"
+        st = getattr(self, "_train_state", None)
+        if st is not None:
+            st.bf16 = self._train_bf16
+            st._wkey = None
+        return self
+
     def enable_data_parallel(self, group=None, enabled=True):
         """Scene-sharded data-parallel training: every rank runs the same step on its own scenes and the
         backward all-reduces (means) the flat gradient bucket once (giga_amd.training.allreduce_mean_)."""
@@ -560,7 +604,11 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
         if st is None or st.blob.device != inputs.device:
             st = self._train_state = _TrainState(self._head_present(), inputs.device, detach_occ=self.detach_tsdf)
             st.data_parallel, st.group = getattr(self, "_dp", (False, None))
+            st.bf16 = getattr(self, "_train_bf16", False)
         self.__dict__["_stale_after_training"] = True
+        fp = self.__dict__.get("_flat_param")
+        if fp is not None:
+            return GigaFunction.apply(st, inputs, p, p_tsdf, fp)
         return GigaFunction.apply(st, inputs, p, p_tsdf, *self._ordered_params())
 
     def infer_geo(self, inputs, p_tsdf, **kwargs):

@@ -17,7 +17,7 @@ int pack_bwd_map_host(int head_present, int32_t* map, size_t nwords);
 struct BwdWs { size_t gA6, gA5, gC1, gA4, gA3, gC0, gS2, gA2, gQ1, gS1, gA1, gQ0, gS0, gA0, gP0, WG, total; };
 BwdWs enc_bwd_workspace(int B);
 int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws,
-                            float* gplanes, uint8_t* gws, float* grads, int head_present, int B, hipStream_t s);
+                            float* gplanes, uint8_t* gws, float* grads, int head_present, int B, hipStream_t s, bool bf16_convs);
 size_t dec_bwd_scratch_floats(long long P, int nheads);
 int launch_decoder_backward(const float* planes, const float* p, const uint8_t* blob, const uint8_t* bwd_blob,
                             int head_mask, const float* const* outs, const float* const* douts, float* gplanes,
@@ -63,7 +63,43 @@ __global__ void repack_kernel(const float* __restrict__ params, const int32_t* _
     else if (m == -1) words[i] = 0.f;
 }
 
+// bf16 fragment images (f16 fragment layout: lane (j, g) holds channels 8g..8g+7 of k-group kg32) from the fp32 fragments
+// (lane (j, g') holds channels 4g'..4g'+3 of k-group kg16 = 2*kg32 + h): one workgroup per bf16 fragment.
+struct BfRegions { size_t src[2 * NCONV], dst[2 * NCONV]; int first[2 * NCONV + 1]; int n; };
+__global__ void derive_bf16_kernel(uint8_t* fwd, uint8_t* bwd, BfRegions r) {
+    int reg = 0;
+    while (reg + 1 < r.n && (int)blockIdx.x >= r.first[reg + 1]) ++reg;
+    const int i16 = (int)blockIdx.x - r.first[reg], lane = threadIdx.x;
+    uint8_t* base = reg < NCONV ? fwd : bwd;
+    if (!base) return;
+    const float* f32 = reinterpret_cast<const float*>(base + r.src[reg]);
+    __bf16* out = reinterpret_cast<__bf16*>(base + r.dst[reg]) + ((size_t)i16 * 64 + lane) * 8;
+    const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = 8 * g + e;
+        out[e] = (__bf16)f32[((size_t)(2 * i16 + c / 16) * 64 + ((c % 16) / 4) * 16 + j) * 4 + c % 4];
+    }
+}
+
 extern "C" {
+
+int giga_derive_bf16_fragments(void* packed_dev, void* bwd_packed_dev, void* stream) {
+    if (!packed_dev && !bwd_packed_dev) return -1;
+    const PackOff ko = pack_offsets();
+    const BwdPackOff bo = bwd_pack_offsets();
+    BfRegions r{};
+    int at = 0;
+    for (int l = 0; l < NCONV; ++l) { r.src[l] = ko.conv[l].w32; r.dst[l] = ko.conv[l].wbf; r.first[l] = at; at += ko.conv[l].nfrag16; }
+    for (int l = 0; l < NCONV; ++l) {
+        r.src[NCONV + l] = bo.conv[l]; r.dst[NCONV + l] = bo.convbf[l]; r.first[NCONV + l] = at; at += bo.nfrag[l] / 2;
+    }
+    r.first[2 * NCONV] = at;
+    r.n = 2 * NCONV;
+    hipLaunchKernelGGL(derive_bf16_kernel, dim3(at), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       static_cast<uint8_t*>(packed_dev), static_cast<uint8_t*>(bwd_packed_dev), r);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
 
 int giga_abi_version(void) { return GIGA_ABI_VERSION; }
 
@@ -115,7 +151,7 @@ size_t giga_encoder_workspace_bytes(int B, int precision) {
 int giga_encoder_workspace_layout(int B, int precision, size_t* offsets) {
     if (B <= 0 || !offsets) return -1;
     precision &= ~GIGA_FOLD_FINAL;
-    if (precision < 0 || precision > 2) return -5;
+    if (precision < 0 || precision > 3) return -5;
     const EncWs w = enc_workspace(B, precision);
     const size_t v[17] = {w.P0, w.A0, w.S0, w.Q0, w.A1, w.S1, w.Q1, w.A2, w.S2, w.U0, w.A3, w.A4, w.U1, w.A5, w.A6,
                           w.YZ, w.XZ};
@@ -129,7 +165,7 @@ int giga_encoder_forward_probe(const float* tsdf, const void* packed, void* plan
     if (B < 0 || (B > 0 && (!tsdf || !packed || !planes_nhwc || !workspace))) return -1;
     const bool fold = (precision & GIGA_FOLD_FINAL) != 0;     // stop before conv_final (folded decoder images)
     precision &= ~GIGA_FOLD_FINAL;
-    if (precision < 0 || precision > 2) return -5;
+    if (precision < 0 || precision > 3) return -5;
     if (fold && planes_nchw) return -1;                       // the reference-layout copy is the FINAL planes only
     if (workspace_bytes < giga_encoder_workspace_bytes(B, precision)) return -4;
     return launch_encoder(tsdf, static_cast<const uint8_t*>(packed), planes_nhwc, planes_nchw, B,
@@ -280,6 +316,7 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
         !workspace)
         return -1;
     const bool detach_occ = (head_present & GIGA_DETACH_OCC) != 0;     // detach_tsdf, models/__init__.py:61-63
+    const bool bf16_convs = (head_present & GIGA_BF16_CONVS) != 0;     // data-gradient convolutions on bf16 MFMA
     head_present &= 15;
     if (N < 0 || M < 0) return -1;
     if (n_params != param_offsets(head_present).total) return -2;
@@ -309,7 +346,7 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
                                       detach_occ ? nullptr : gplanes, grads, head_present, scratch, B, M, s);
     }
     rc |= launch_encoder_backward(tsdf, blob, bblob, static_cast<const uint8_t*>(enc_workspace_fwd), gplanes, gws,
-                                  grads, head_present, B, s);
+                                  grads, head_present, B, s, bf16_convs);
     return rc;
 }
 

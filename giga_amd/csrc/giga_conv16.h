@@ -35,6 +35,13 @@ struct ConvArgs {
     int trace_id;                        // layer index (diagnostic builds)
 };
 
+constexpr int MATH_NATIVE = 0, MATH_SPLIT = 1, MATH_BF16 = 2;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v mfma16_16_bf(bf16x8 a, bf16x8 b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
 constexpr int CONV_NW = 12;       // waves per workgroup (3 per SIMD; VGPR use is < 80)
 
 #ifdef GIGA_TRACE   // diagnostic build: issue timeline (s_memtime) of workgroup 0 of the layer selected at run time
@@ -62,7 +69,14 @@ constexpr int conv_nw() {       // (SPLIT instantiations have T = float and exac
 }
 
 // H, W are the OUTPUT-grid dimensions for DOWN (its input is 2H x 2W) and the input dimensions otherwise.
-// SPLIT (T = float only): f16x3 split-operand arithmetic.  Activations stay fp32 in HBM; the staging step converts every
+// MATH selects the arithmetic for T = float activations (T = _Float16 is always native f16):
+//   MATH_NATIVE  fp32 MFMA on fp32 operands (or f16 MFMA when T is _Float16)
+//   MATH_SPLIT   f16x3 split-operand arithmetic (below)
+//   MATH_BF16    bf16 operands / fp32 accumulate: activations stay fp32 in HBM (so the fp32 weight-gradient and elementwise
+//                backward kernels of the training path read them unchanged) and are rounded to bf16 when a patch is staged;
+//                weights are bf16 fragments derived on the device from the fp32 ones; one v_mfma_f32_16x16x32_bf16 per tap
+//                and 32-channel chunk.  The training step's forward and data-gradient convolutions (BASELINE config c5).
+// MATH_SPLIT (T = float only): f16x3 split-operand arithmetic.  Activations stay fp32 in HBM; the staging step converts every
 // value v to the pair hi = f16(v), lo = f16(v - hi) (patch pixel = 4 groups of 8 channels x [8 hi | 8 lo] halfs, 128 B as for
 // fp32), the resident weights are [hi, lo] fragment pairs, and every (tap, 32-channel chunk) is three v_mfma_f32_16x16x32_f16
 // (W_lo*x_hi + W_hi*x_lo + W_hi*x_hi) instead of eight v_mfma_f32_16x16x4_f32: fp32-grade results at 5x less MFMA time.
@@ -71,10 +85,11 @@ constexpr int conv_nw() {       // (SPLIT instantiations have T = float and exac
 //   conv16_fill : issue the LDS-DMA of this workgroup's weight group (all launched waves take part)
 //   conv16_run  : wait for it, then walk the units.  `block` / `nblocks` replace blockIdx.x / gridDim.x; waves beyond the
 //                 layer's own wave count (launched because another stage needs them) only take part in the barrier.
-template <typename T, int KIND, int C0, int C1, int COUT, int NB, bool SPLIT>
+template <typename T, int KIND, int C0, int C1, int COUT, int NB, int MATH>
 __device__ __forceinline__ void conv16_fill(const ConvArgs& a, uint8_t* smem, int block) {
+    constexpr bool SPLIT = MATH == MATH_SPLIT;
     constexpr int TAPS = KIND == CONV3 ? 9 : KIND == DOWN ? 4 : 1;
-    constexpr int KGT = (C0 + C1) / 32 * ((sizeof(T) == 2 || SPLIT) ? 1 : 2);
+    constexpr int KGT = (C0 + C1) / 32 * ((sizeof(T) == 2 || MATH != MATH_NATIVE) ? 1 : 2);
     constexpr int WPF = SPLIT ? 2 : 1;
     constexpr int NSUB = KIND == UPCONV ? 4 : 1, NBT = COUT / 16, CG = NBT / NB, NGRP = NSUB * CG;
     constexpr int WFRAGS = NB * TAPS * KGT * WPF;
@@ -91,15 +106,16 @@ __device__ __forceinline__ void conv16_fill(const ConvArgs& a, uint8_t* smem, in
             (__attribute__((address_space(3))) void*)(smem + c * FRAG), 16, 0, 0);
 }
 
-template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL, bool RELU, bool SPLIT>
+template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL, bool RELU, int MATH>
 __device__ __forceinline__ void conv16_run(const ConvArgs& a, uint8_t* smem, int block, int nblocks) {
-    static_assert(!SPLIT || sizeof(T) == 4, "split mode reads and writes fp32 activations");
+    constexpr bool SPLIT = MATH == MATH_SPLIT, BF = MATH == MATH_BF16;
+    static_assert(MATH == MATH_NATIVE || sizeof(T) == 4, "split / bf16 modes read and write fp32 activations");
     constexpr int CIN = C0 + C1;
     constexpr int TAPS = KIND == CONV3 ? 9 : KIND == DOWN ? 4 : 1;
     constexpr int HALO = KIND == CONV3 ? 1 : 0;
     constexpr int NCHUNK = CIN / 32;
     constexpr int ES = (int)sizeof(T);
-    constexpr int PS = 32 * ES + 16;                  // LDS pixel stride in bytes
+    constexpr int PS = BF ? 32 * 2 + 16 : 32 * ES + 16;   // LDS pixel stride in bytes (bf16 patches: 64 B of channels)
     // LIN (the 10x10 layers): a 4x4 tiling covers 144 pixel slots for 100 pixels; instead a unit is 16 CONSECUTIVE
     // pixels of an image in row-major order (7 units per image), staged as the haloed band of rows they touch.
     constexpr bool LIN = conv_lin<KIND, H, W>();
@@ -116,7 +132,7 @@ __device__ __forceinline__ void conv16_run(const ConvArgs& a, uint8_t* smem, int
     constexpr int NBT = COUT / 16;                    // 16-channel blocks per sub-output
     constexpr int CG = NBT / NB;                      // channel groups per sub-output
     constexpr int NGRP = NSUB * CG;                   // weight groups (one per workgroup)
-    constexpr bool F16MATH = ES == 2 || SPLIT;        // 16x16x32 f16 MFMA (one k-group per 32-channel chunk)
+    constexpr bool F16MATH = ES == 2 || SPLIT || BF;  // 16x16x32 f16 / bf16 MFMA (one k-group per 32-channel chunk)
     constexpr int KGC = F16MATH ? 1 : 2;              // k-groups per 32-channel chunk (16 / 32 channels)
     constexpr int WPF = SPLIT ? 2 : 1;                // LDS fragments per weight k-group ([hi, lo] pair)
     constexpr int KGT = CIN / 32 * KGC;
@@ -210,7 +226,11 @@ __device__ __forceinline__ void conv16_run(const ConvArgs& a, uint8_t* smem, int
 #pragma unroll
         for (int q = 0; q < NLD; ++q)
             if (st_lds[q] >= 0) {
-                if constexpr (SPLIT) {
+                if constexpr (BF) {                       // channels 4v..4v+3 -> four bf16 (round to nearest even), 8 bytes
+                    const f32x4v x = __builtin_bit_cast(f32x4v, stg[q]);
+                    const bf16x4 b4 = {(__bf16)x[0], (__bf16)x[1], (__bf16)x[2], (__bf16)x[3]};
+                    *reinterpret_cast<bf16x4*>(region + (st_lds[q] - st_v[q] * 16) + st_v[q] * 8) = b4;
+                } else if constexpr (SPLIT) {
                     // vector v = channels 4v..4v+3 of the pixel: hi halfs at group (v>>1), slot 4*(v&1); lo 16 bytes further
                     const f32x4v x = __builtin_bit_cast(f32x4v, stg[q]);
                     half4 hi4, lo4;
@@ -267,6 +287,11 @@ __device__ __forceinline__ void conv16_run(const ConvArgs& a, uint8_t* smem, int
                     c = mfma16_16(Al, Bh, c);
                     c = mfma16_16(Ah, Bh, c);
                 }
+            } else if constexpr (BF) {
+#pragma unroll
+                for (int n = 0; n < NB; ++n)
+                    acc[n][it & (NACC - 1)] = mfma16_16_bf(__builtin_bit_cast(bf16x8, av_q[sl][0]),
+                                                           __builtin_bit_cast(bf16x8, bw_q[sl][n][0]), acc[n][it & (NACC - 1)]);
             } else if constexpr (ES == 2) {
 #pragma unroll
                 for (int n = 0; n < NB; ++n)
@@ -336,16 +361,17 @@ __device__ __forceinline__ void conv16_run(const ConvArgs& a, uint8_t* smem, int
 }
 
 template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL, bool RELU = (KIND == CONV3),
-          bool SPLIT = false>
+          int MATH = MATH_NATIVE>
 __global__ __launch_bounds__((conv_nw<T, KIND, C0, C1, H, W, NB>() * 64)) void conv16_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    conv16_fill<T, KIND, C0, C1, COUT, NB, SPLIT>(a, smem, (int)blockIdx.x);
-    conv16_run<T, KIND, C0, C1, COUT, H, W, NB, POOL, RELU, SPLIT>(a, smem, (int)blockIdx.x, (int)gridDim.x);
+    conv16_fill<T, KIND, C0, C1, COUT, NB, MATH>(a, smem, (int)blockIdx.x);
+    conv16_run<T, KIND, C0, C1, COUT, H, W, NB, POOL, RELU, MATH>(a, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // LDS bytes of one layer (weights resident + wave-private patches)
-template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool SPLIT>
-constexpr size_t conv_lds_bytes() {
+template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, int MATH>
+constexpr size_t conv_lds_bytes() {       // (sized for the fp32 / split footprint; the bf16 mode needs less)
+    constexpr bool SPLIT = MATH == MATH_SPLIT;
     constexpr int HALO = KIND == CONV3 ? 1 : 0;
     constexpr int TAPS = KIND == CONV3 ? 9 : KIND == DOWN ? 4 : 1;
     constexpr int ES = (int)sizeof(T);
@@ -359,8 +385,9 @@ constexpr size_t conv_lds_bytes() {
 }
 
 template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL, bool RELU = (KIND == CONV3),
-          bool SPLIT = false>
+          int MATH = MATH_NATIVE>
 inline int launch_conv(const ConvArgs& a, hipStream_t s) {
+    constexpr bool SPLIT = MATH == MATH_SPLIT;
     constexpr int HALO = KIND == CONV3 ? 1 : 0;
     constexpr int TAPS = KIND == CONV3 ? 9 : KIND == DOWN ? 4 : 1;
     constexpr int ES = (int)sizeof(T);
@@ -379,7 +406,7 @@ inline int launch_conv(const ConvArgs& a, hipStream_t s) {
     const int units = a.nimg * (LIN ? (H * W + 15) / 16 : ((H + 3) / 4) * ((W + 3) / 4));   // per weight group
     int wgs = (units + NWV - 1) / NWV;                                // workgroups per weight group
     if (wgs > 256 / NGRP) wgs = 256 / NGRP;                           // one persistent workgroup per CU
-    auto kern = conv16_kernel<T, KIND, C0, C1, COUT, H, W, NB, POOL, RELU, SPLIT>;
+    auto kern = conv16_kernel<T, KIND, C0, C1, COUT, H, W, NB, POOL, RELU, MATH>;
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(wgs * NGRP), dim3(NWV * 64), lds, s, a);

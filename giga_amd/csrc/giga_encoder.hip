@@ -437,9 +437,10 @@ __global__ __launch_bounds__(MEGA_NW * 64) void unet_mega_kernel(MegaArgs m) {
 // (k = 0 conv_in+project, 1 plane_finalize, 2..14 = U-Net layers 0..12).
 struct Probe { int stage; hipEvent_t ev0, ev1; };
 
-template <typename T, bool SPLIT = false>
+template <typename T, int MATH = MATH_NATIVE>
 static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc, float* planes_nchw, int B,
                        uint8_t* ws, hipStream_t s, const Probe& pr, bool fold_final) {
+    constexpr bool SPLIT = MATH == MATH_SPLIT;
     int stage_no = 0;
     auto pre = [&]() { if (pr.stage == stage_no) (void)hipEventRecord(pr.ev0, s); };
     auto post = [&]() { if (pr.stage == stage_no) (void)hipEventRecord(pr.ev1, s); ++stage_no; };
@@ -475,7 +476,9 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     if (hipGetLastError() != hipSuccess) return -10;
 
     const int nimg = 3 * B;
-    auto W_ = [&](int l) { return blob + (SPLIT ? ko.conv[l].w16s : precision == 1 ? ko.conv[l].w16 : ko.conv[l].w32); };
+    auto W_ = [&](int l) {
+        return blob + (SPLIT ? ko.conv[l].w16s : MATH == MATH_BF16 ? ko.conv[l].wbf : precision == 1 ? ko.conv[l].w16 : ko.conv[l].w32);
+    };
     auto Bi = [&](int l) { return reinterpret_cast<const float*>(blob + ko.conv[l].bias); };
     auto args = [&](int l, const void* i0, const void* i1, void* o, void* op) {
         ConvArgs a{};
@@ -532,7 +535,7 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
 #endif
     if (pr.stage == 15) (void)hipEventRecord(pr.ev0, s);
 #define X(l, KIND, C0, C1, COUT, H, W, NB, POOL)                                                                          \
-    if (l < nlayers) { pre(); rc |= launch_conv<T, KIND, C0, C1, COUT, H, W, NB, POOL, KIND == CONV3, SPLIT>(L[l], s); post(); } \
+    if (l < nlayers) { pre(); rc |= launch_conv<T, KIND, C0, C1, COUT, H, W, NB, POOL, KIND == CONV3, MATH>(L[l], s); post(); } \
     else { pre(); post(); }
     GIGA_UNET_LAYERS(X)
 #undef X
@@ -546,7 +549,8 @@ int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, fl
     Probe pr{ev0 && ev1 ? probe_stage : -1, static_cast<hipEvent_t>(ev0), static_cast<hipEvent_t>(ev1)};
     const bool fold = (precision & GIGA_FOLD_FINAL) != 0;
     const int prec = precision & ~GIGA_FOLD_FINAL;
-    if (prec == 2) return encoder_run<float, true>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold);
+    if (prec == 2) return encoder_run<float, MATH_SPLIT>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold);
+    if (prec == 3) return encoder_run<float, MATH_BF16>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold);
     return prec == 1 ? encoder_run<half_t>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold)
                      : encoder_run<float>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold);
 }

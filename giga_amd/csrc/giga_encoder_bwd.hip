@@ -608,9 +608,12 @@ BwdWs enc_bwd_workspace(int B) {
 EncWs enc_workspace(int B, int precision);
 int enc_nxp(int B);
 
-int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws,
-                            float* gplanes /* [3B][40][40][32], in: dLoss/dPlanes, clobbered */, uint8_t* gws,
-                            float* grads /* flat, state-dict order */, int head_present, int B, hipStream_t s) {
+// MATH: arithmetic of the thirteen data-gradient convolutions (MATH_NATIVE fp32 MFMA, or MATH_BF16: bf16 operands from the
+// backward blob's bf16 images, fp32 accumulate and fp32 gradients in memory); everything else is fp32.
+template <int MATH>
+static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws,
+                                 float* gplanes /* [3B][40][40][32], in: dLoss/dPlanes, clobbered */, uint8_t* gws,
+                                 float* grads /* flat, state-dict order */, int head_present, int B, hipStream_t s) {
     if (B <= 0) return 0;
     const PackOff ko = pack_offsets();
     const BwdPackOff bo = bwd_pack_offsets();
@@ -669,7 +672,7 @@ int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_
     };
     auto dgrad_args = [&](int l, const float* in, int cs, void* out) {
         ConvArgs a{};
-        a.in0 = in; a.in1 = nullptr; a.w = bwd_blob + bo.conv[l]; a.bias = nullptr; a.out = out; a.nimg = nimg;
+        a.in0 = in; a.in1 = nullptr; a.w = bwd_blob + (MATH == MATH_BF16 ? bo.convbf[l] : bo.conv[l]); a.bias = nullptr; a.out = out; a.nimg = nimg;
         a.cs0 = cs;
         return a;
     };
@@ -677,37 +680,37 @@ int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_
 
     // L12 conv_final (1x1, no activation): gplanes = dOUT
     wgrad3(12, gplanes, F(f.A6), nullptr, 40);
-    rc |= launch_conv<float, CONV1, 32, 0, 32, 40, 40, 2, false, false>(dgrad_args(12, gplanes, 0, G(g.gA6)), s);
+    rc |= launch_conv<float, CONV1, 32, 0, 32, 40, 40, 2, false, false, MATH>(dgrad_args(12, gplanes, 0, G(g.gA6)), s);
     // L11 up1.conv2: A5 -> A6
     relu_bwd(G(g.gA6), F(f.A6), n40 * 32);
     wgrad3(11, G(g.gA6), F(f.A5), nullptr, 40);
-    rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false>(dgrad_args(11, G(g.gA6), 0, G(g.gA5)), s);
+    rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(dgrad_args(11, G(g.gA6), 0, G(g.gA5)), s);
     // L10 up1.conv1: cat(U1, S0) -> A5 ; dgrad output has 64 channels (dU1 | dS0 skip part)
     relu_bwd(G(g.gA5), F(f.A5), n40 * 32);
     wgrad3(10, G(g.gA5), F(f.U1), F(f.S0), 40);
-    rc |= launch_conv<float, CONV3, 32, 0, 64, 40, 40, 2, false, false>(dgrad_args(10, G(g.gA5), 0, G(g.gC1)), s);
+    rc |= launch_conv<float, CONV3, 32, 0, 64, 40, 40, 2, false, false, MATH>(dgrad_args(10, G(g.gA5), 0, G(g.gC1)), s);
     // L9 up1.upconv: A4 (20x20x64) -> U1 (40x40x32); dU1 = gC1[..., 0:32]
     wgrad_up(9, F(f.A4), G(g.gC1), 64, 20);
-    rc |= launch_conv<float, DOWN, 32, 0, 64, 20, 20, 2, false, false>(dgrad_args(9, G(g.gC1), 64, G(g.gA4)), s);
+    rc |= launch_conv<float, DOWN, 32, 0, 64, 20, 20, 2, false, false, MATH>(dgrad_args(9, G(g.gC1), 64, G(g.gA4)), s);
     // L8 up0.conv2: A3 -> A4
     relu_bwd(G(g.gA4), F(f.A4), n20 * 64);
     wgrad3(8, G(g.gA4), F(f.A3), nullptr, 20);
-    rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false>(dgrad_args(8, G(g.gA4), 0, G(g.gA3)), s);
+    rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false, MATH>(dgrad_args(8, G(g.gA4), 0, G(g.gA3)), s);
     // L7 up0.conv1: cat(U0, S1) -> A3 ; dgrad output 128 channels
     relu_bwd(G(g.gA3), F(f.A3), n20 * 64);
     wgrad3(7, G(g.gA3), F(f.U0), F(f.S1), 20);
-    rc |= launch_conv<float, CONV3, 64, 0, 128, 20, 20, 1, false, false>(dgrad_args(7, G(g.gA3), 0, G(g.gC0)), s);
+    rc |= launch_conv<float, CONV3, 64, 0, 128, 20, 20, 1, false, false, MATH>(dgrad_args(7, G(g.gA3), 0, G(g.gC0)), s);
     // L6 up0.upconv: S2 (10x10x128) -> U0 (20x20x64); dU0 = gC0[..., 0:64]
     wgrad_up(6, F(f.S2), G(g.gC0), 128, 10);
-    rc |= launch_conv<float, DOWN, 64, 0, 128, 10, 10, 1, false, false>(dgrad_args(6, G(g.gC0), 128, G(g.gS2)), s);
+    rc |= launch_conv<float, DOWN, 64, 0, 128, 10, 10, 1, false, false, MATH>(dgrad_args(6, G(g.gC0), 128, G(g.gS2)), s);
     // L5 down2.conv2: A2 -> S2
     relu_bwd(G(g.gS2), F(f.S2), n10 * 128);
     wgrad3(5, G(g.gS2), F(f.A2), nullptr, 10);
-    rc |= launch_conv<float, CONV3, 128, 0, 128, 10, 10, 1, false, false>(dgrad_args(5, G(g.gS2), 0, G(g.gA2)), s);
+    rc |= launch_conv<float, CONV3, 128, 0, 128, 10, 10, 1, false, false, MATH>(dgrad_args(5, G(g.gS2), 0, G(g.gA2)), s);
     // L4 down2.conv1: Q1 -> A2
     relu_bwd(G(g.gA2), F(f.A2), n10 * 128);
     wgrad3(4, G(g.gA2), F(f.Q1), nullptr, 10);
-    rc |= launch_conv<float, CONV3, 128, 0, 64, 10, 10, 1, false, false>(dgrad_args(4, G(g.gA2), 0, G(g.gQ1)), s);
+    rc |= launch_conv<float, CONV3, 128, 0, 64, 10, 10, 1, false, false, MATH>(dgrad_args(4, G(g.gA2), 0, G(g.gQ1)), s);
     // pool1 + skip: dS1 = gC0[..., 64:128] + unpool(dQ1)
     {
         const size_t tot = n20 * 64;
@@ -717,11 +720,11 @@ int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_
     // L3 down1.conv2: A1 -> S1
     relu_bwd(G(g.gS1), F(f.S1), n20 * 64);
     wgrad3(3, G(g.gS1), F(f.A1), nullptr, 20);
-    rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false>(dgrad_args(3, G(g.gS1), 0, G(g.gA1)), s);
+    rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false, MATH>(dgrad_args(3, G(g.gS1), 0, G(g.gA1)), s);
     // L2 down1.conv1: Q0 -> A1
     relu_bwd(G(g.gA1), F(f.A1), n20 * 64);
     wgrad3(2, G(g.gA1), F(f.Q0), nullptr, 20);
-    rc |= launch_conv<float, CONV3, 64, 0, 32, 20, 20, 2, false, false>(dgrad_args(2, G(g.gA1), 0, G(g.gQ0)), s);
+    rc |= launch_conv<float, CONV3, 64, 0, 32, 20, 20, 2, false, false, MATH>(dgrad_args(2, G(g.gA1), 0, G(g.gQ0)), s);
     // pool0 + skip: dS0 = gC1[..., 32:64] + unpool(dQ0)
     {
         const size_t tot = n40 * 32;
@@ -731,11 +734,11 @@ int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_
     // L1 down0.conv2: A0 -> S0
     relu_bwd(G(g.gS0), F(f.S0), n40 * 32);
     wgrad3(1, G(g.gS0), F(f.A0), nullptr, 40);
-    rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false>(dgrad_args(1, G(g.gS0), 0, G(g.gA0)), s);
+    rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(dgrad_args(1, G(g.gS0), 0, G(g.gA0)), s);
     // L0 down0.conv1: P0 -> A0
     relu_bwd(G(g.gA0), F(f.A0), n40 * 32);
     wgrad3(0, G(g.gA0), F(f.P0), nullptr, 40);
-    rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false>(dgrad_args(0, G(g.gA0), 0, G(g.gP0)), s);
+    rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(dgrad_args(0, G(g.gA0), 0, G(g.gP0)), s);
     // conv_in + projection
     {
         const int nxp = enc_nxp(B);
@@ -758,6 +761,12 @@ int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_
     }
     if (hipGetLastError() != hipSuccess) rc |= -10;
     return rc;
+}
+
+int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws, float* gplanes,
+                            uint8_t* gws, float* grads, int head_present, int B, hipStream_t s, bool bf16_convs) {
+    return bf16_convs ? encoder_backward_impl<MATH_BF16>(tsdf, blob, bwd_blob, fws, gplanes, gws, grads, head_present, B, s)
+                      : encoder_backward_impl<MATH_NATIVE>(tsdf, blob, bwd_blob, fws, gplanes, gws, grads, head_present, B, s);
 }
 
 }  // namespace giga

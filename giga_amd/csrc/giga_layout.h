@@ -117,7 +117,7 @@ constexpr size_t DEC16S_BYTES = (DEC16S_FRAGS + 1) * FRAG;                // 111
 constexpr int DEC32_FRAGS = NBLK * (12 + 1 + 4 + 4) + 1 + 4;              // 110
 constexpr size_t DEC32_BYTES = (DEC32_FRAGS + 1) * FRAG;                  // 111 KiB: fragments + C table chunk (LDS-DMA image)
 
-struct ConvPackOff { size_t w16, w32, bias, w16s; int nfrag16, nfrag32; };   // w16s: f16x3 split [hi, lo] fragment pairs (2 * nfrag16)
+struct ConvPackOff { size_t w16, w32, bias, w16s, wbf; int nfrag16, nfrag32; };   // wbf: bf16 fragments (f16 fragment layout), derived from w32   // w16s: f16x3 split [hi, lo] fragment pairs (2 * nfrag16)
 struct PackOff {
     size_t convin_w;        // fp32 [2][7][64]  B operands (channel half, K-step of 4 taps; tap 27 = 0)
     size_t convin_b;        // fp32 [32]
@@ -160,6 +160,7 @@ inline PackOff pack_offsets() {
     }
     for (int l = 0; l < NCONV; ++l) { o.conv[l].w16s = at; at += (size_t)2 * o.conv[l].nfrag16 * FRAG; }
     o.convin_ws = at; at += 4 * FRAG;
+    for (int l = 0; l < NCONV; ++l) { o.conv[l].wbf = at; at += (size_t)o.conv[l].nfrag16 * FRAG; }
     o.total = at;
     return o;
 }
@@ -174,6 +175,7 @@ struct BwdPackOff {
     size_t conv[NCONV];          // fragment offset of layer l's dgrad image
     int nfrag[NCONV];
     size_t dec[NHEADS];          // transposed decoder matrices of head h
+    size_t convbf[NCONV];        // bf16 images of the dgrad fragments (f16 fragment layout, nfrag[l] / 2 fragments)
     size_t total;
 };
 // decoder backward image per head: 5 blocks x (Wc^T: 3 row blocks x 4 frags, W0^T 4 frags, W1^T 4 frags)
@@ -192,6 +194,7 @@ inline BwdPackOff bwd_pack_offsets() {
         o.conv[l] = at; at += (size_t)o.nfrag[l] * FRAG;
     }
     for (int h = 0; h < NHEADS; ++h) { o.dec[h] = at; at += DECB_BYTES; }
+    for (int l = 0; l < NCONV; ++l) { o.convbf[l] = at; at += (size_t)(o.nfrag[l] / 2) * FRAG; }
     o.total = at;
     return o;
 }

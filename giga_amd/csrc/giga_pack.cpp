@@ -17,6 +17,12 @@ namespace giga {
 typedef _Float16 half_t;
 
 static inline half_t f2h(float x) { return (half_t)x; }   // round-to-nearest-even
+// fp32 -> bf16 bits, round-to-nearest-even (what v_cvt_pk_bf16_f32 does for finite values)
+static inline uint16_t f2bf(float x) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
 
 // hidden-layer feature held in k-slot (hi, j) of f16 chunk c   (D regs r = 8c + j)
 static inline int hid16(int c, int hi, int j) { return drow(8 * c + j, hi); }
@@ -198,6 +204,7 @@ static void pack_conv(const float* P, const ParamOff& po, const PackOff& ko, int
     const int cin = d.cin0 + d.cin1, taps = conv_taps(d), nsub = conv_nsub(d), nb16 = d.cout / 16;
     half_t* f16 = reinterpret_cast<half_t*>(blob + ko.conv[l].w16);
     half_t* f16s = reinterpret_cast<half_t*>(blob + ko.conv[l].w16s);      // split: fragment pair (2*i16, 2*i16 + 1) = (hi, lo)
+    uint16_t* fbf = reinterpret_cast<uint16_t*>(blob + ko.conv[l].wbf);    // bf16, same fragment layout as f16
     float* f32 = reinterpret_cast<float*>(blob + ko.conv[l].w32);
     size_t i16 = 0, i32 = 0;
     for (int sub = 0; sub < nsub; ++sub)
@@ -213,6 +220,7 @@ static void pack_conv(const float* P, const ParamOff& po, const PackOff& ko, int
                             f16[i16 * 512 + lane * 8 + e] = h;
                             f16s[(2 * i16) * 512 + lane * 8 + e] = h;
                             f16s[(2 * i16 + 1) * 512 + lane * 8 + e] = f2h(w - (float)h);
+                            fbf[i16 * 512 + lane * 8 + e] = f2bf(w);
                         }
                     }
                 for (int kg = 0; kg < cin / 16; ++kg, ++i32)
@@ -362,6 +370,18 @@ int pack_bwd_host(const float* P, size_t n_params, int head_present, uint8_t* bl
     for (int l = 0; l < NCONV; ++l) pack_conv_dgrad(P, po, bo, l, blob);
     for (int h = 0; h < NHEADS; ++h)
         if (head_present >> h & 1) pack_head_bwd(P, po.head[h], HEAD_OUT[h], blob + bo.dec[h]);
+    // bf16 images of the dgrad fragments: f16-layout fragment i16 (k-group of 32) = fp32 fragments 2*i16 and 2*i16 + 1
+    for (int l = 0; l < NCONV; ++l) {
+        const float* f32 = reinterpret_cast<const float*>(blob + bo.conv[l]);
+        uint16_t* bf = reinterpret_cast<uint16_t*>(blob + bo.convbf[l]);
+        for (int i16 = 0; i16 < bo.nfrag[l] / 2; ++i16)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int j = lane & 15, c = 8 * (lane >> 4) + e;
+                    bf[(size_t)i16 * 512 + lane * 8 + e] =
+                        f2bf(f32[((size_t)(2 * i16 + c / 16) * 64 + ((c % 16) / 4) * 16 + j) * 4 + c % 4]);
+                }
+    }
     return 0;
 }
 
@@ -376,6 +396,7 @@ int pack_bwd_map_host(int head_present, int32_t* map, size_t nwords) {
     if (rc) return rc;
     const float* f = reinterpret_cast<const float*>(blob.data());
     for (size_t w = 0; w < bo.total / 4; ++w) map[w] = f[w] == 0.f ? -1 : (int32_t)f[w] - 1;
+    for (size_t w = bo.convbf[0] / 4; w < bo.total / 4; ++w) map[w] = -2;      // bf16 images: derived on the device, not gathered
     return 0;
 }
 

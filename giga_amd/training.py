@@ -1,5 +1,9 @@
-"""Training path: autograd bridge to the HIP forward/backward kernels (fp32) and the fused loss of the joint objective
-(reference scripts/train_giga.py:154-211).
+"""Training path: autograd bridge to the HIP forward/backward kernels and the fused loss of the joint objective
+(reference scripts/train_giga.py:154-211).  Two arithmetic modes (`net.set_train_precision`): "fp32" (every GEMM on the
+fp32-input MFMA; gradients match torch autograd to <= 6e-6 relative) and "bf16" (BASELINE config c5: the U-Net's forward and
+data-gradient convolutions -- two thirds of the step's FLOPs -- take bf16 operands with fp32 accumulation on
+v_mfma_f32_16x16x32_bf16; activations, weight gradients, the decoder, conv_in, master weights and the optimizer stay fp32,
+as under torch.autocast; gradients then carry bf16 operand rounding, ~1e-2 relative).
 
 `ConvolutionalOccupancyNetwork.forward` dispatches here when autograd is enabled and parameters require grad, so the
 reference loop works unchanged with ITS OWN helpers (`select`, `loss_fn` of train_giga.py stay in the caller):
@@ -57,6 +61,7 @@ class _TrainState:
         self.flat = torch.empty(self.n_params, device=device, dtype=torch.float32)
         self.repacks = 0                # how often the images were rebuilt: identifies the weights they currently hold
         self._wkey = None               # (storage, version) of every parameter the images were built from
+        self.bf16 = False               # set by ConvolutionalOccupancyNetwork.set_train_precision("bf16")
         self.data_parallel = False      # set by ConvolutionalOccupancyNetwork.enable_data_parallel()
         self.group = None
         self._pool = []
@@ -68,20 +73,28 @@ class _TrainState:
         stale-graph check in GigaFunction.backward."""
         key = tuple((q.data_ptr(), q._version) for q in params)
         L = _capi.lib()
-        flat = self.flat
-        views, at = [], 0
-        for q in params:
-            n = q.numel()
-            views.append(flat[at:at + n].view(q.shape))
-            at += n
-        if at != self.n_params:
-            raise _capi.GigaHipError("parameter list does not match the head set")
-        torch._foreach_copy_(views, [q.detach() for q in params])
+        if len(params) == 1 and params[0].dim() == 1:       # flattened module (flatten_parameters): the parameter IS the buffer
+            flat = params[0].detach()
+            if flat.numel() != self.n_params or flat.dtype != torch.float32 or not flat.is_contiguous():
+                raise _capi.GigaHipError("flat parameter does not match the head set")
+        else:
+            flat = self.flat
+            views, at = [], 0
+            for q in params:
+                n = q.numel()
+                views.append(flat[at:at + n].view(q.shape))
+                at += n
+            if at != self.n_params:
+                raise _capi.GigaHipError("parameter list does not match the head set")
+            torch._foreach_copy_(views, [q.detach() for q in params])
         s = _capi.stream_ptr(self.device)
         _capi.check(L.giga_repack_device(_capi.ptr(flat), _capi.ptr(self.map_fwd), _capi.ptr(self.blob),
                                          self.map_fwd.numel(), s), "giga_repack_device")
         _capi.check(L.giga_repack_device(_capi.ptr(flat), _capi.ptr(self.map_bwd), _capi.ptr(self.bwd_blob),
                                          self.map_bwd.numel(), s), "giga_repack_device")
+        if self.bf16:                   # bf16 images of the convolution fragments, from the fp32 fragments just rebuilt
+            _capi.check(L.giga_derive_bf16_fragments(_capi.ptr(self.blob), _capi.ptr(self.bwd_blob), s),
+                        "giga_derive_bf16_fragments")
         if key != self._wkey:
             self.repacks += 1
         self._wkey = key
@@ -149,7 +162,8 @@ class GigaFunction(torch.autograd.Function):
             state.repack(params)
             sb = state.acquire(B, N, M)
             s = _capi.stream_ptr(dev)
-            _capi.check(L.giga_encoder_forward(_capi.ptr(x), _capi.ptr(state.blob), _capi.ptr(sb.nhwc), None, B, 0,
+            _capi.check(L.giga_encoder_forward(_capi.ptr(x), _capi.ptr(state.blob), _capi.ptr(sb.nhwc), None, B,
+                                               _capi.ENC_BF16 if state.bf16 else 0,
                                                _capi.ptr(sb.ws), sb.ws.numel(), s), "giga_encoder_forward")
             hp = state.head_present
             o = [torch.empty((B, N), device=dev) if hp & 1 and N > 0 else None,
@@ -164,6 +178,7 @@ class GigaFunction(torch.autograd.Function):
                 _capi.check(L.giga_decoder_forward(_capi.ptr(sb.nhwc), _capi.ptr(p_tsdf), _capi.ptr(state.blob), 8, None,
                                                    None, None, _capi.ptr(o[3]), B, M, 0, 0, s), "giga_decoder_forward")
         ctx.state, ctx.dims, ctx.lease, ctx.repacks = state, (B, N, M), _Lease(sb), state.repacks
+        ctx.bf16 = state.bf16
         # save_for_backward, not a plain attribute: a node that holds its own outputs in a Python attribute is a reference
         # cycle (output -> grad_fn -> ctx -> output) that only the cyclic GC would free
         ctx.save_for_backward(x, p, p_tsdf, *o)
@@ -194,10 +209,14 @@ class GigaFunction(torch.autograd.Function):
             _capi.check(L.giga_backward(
                 _capi.ptr(x), _capi.ptr(state.blob), _capi.ptr(state.bwd_blob), _capi.ptr(sb.ws), _capi.ptr(sb.nhwc),
                 _capi.ptr(p), _capi.ptr(p_tsdf), _ptr_array(outs), _ptr_array(douts), _capi.ptr(grads),
-                grads.numel(), state.head_present | state.bwd_flags, B, N, M, _capi.ptr(sb.wsb), sb.wsb.numel(),
+                grads.numel(), state.head_present | state.bwd_flags | (_capi.BF16_CONVS if ctx.bf16 else 0), B, N, M,
+                _capi.ptr(sb.wsb), sb.wsb.numel(),
                 _capi.stream_ptr(dev)), "giga_backward")
         if state.data_parallel:
             allreduce_mean_(grads, state.group)
+        lease.release()
+        if len(ctx.shapes) == 1 and len(ctx.shapes[0]) == 1:  # flattened module: one gradient for the one flat parameter
+            return (None, None, None, None, grads)
         views, at = [], 0
         for shp in ctx.shapes:
             n = 1
@@ -205,7 +224,6 @@ class GigaFunction(torch.autograd.Function):
                 n *= d
             views.append(grads[at:at + n].view(shp))
             at += n
-        lease.release()
         return (None, None, None, None) + tuple(views)
 
 

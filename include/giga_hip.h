@@ -17,7 +17,10 @@
  *                  2 = f16x3 split operands / fp32 accumulate: every operand is the pair hi = f16(v), lo = f16(v - hi)
  *                      and every product W_lo*x_hi + W_hi*x_lo + W_hi*x_hi on the f16 MFMA (~22-bit operands, results
  *                      within 1e-5 of the fp32 path).  Decoder entry points only change arithmetic; planes are fp32
- *                      (as for precision 0) and the encoder entry points run their fp32 kernels for this value;
+ *                      (as for precision 0); the encoder runs its convolutions (conv_in and the U-Net) in the same split
+ *                      arithmetic;
+ *                  3 = (encoder entry points only) bf16 operands / fp32 accumulate in the U-Net convolutions, fp32 activations
+ *                      in memory, fp32 conv_in: the forward of the bf16 training step (see GIGA_BF16_CONVS);
  *   - "NHWC planes": one buffer [3 (xz,xy,yz)][B][40 (H)][40 (W)][32 (C)] of float (precision 0 and 2) or
  *     _Float16 (precision 1).  H/W follow the reference's plane indexing (ConvONets/common.py:246-251,
  *     303-318): xz -> (H=z, W=x), xy -> (H=y, W=x), yz -> (H=z, W=y).
@@ -139,6 +142,13 @@ int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, cons
  * giga_pack_bwd_map + giga_repack_device on the device every step).  Weight gradients are reduced with fp32
  * atomics (run-to-run differences at rounding level, as in PyTorch's own GPU backward). */
 #define GIGA_DETACH_OCC 16
+/* GIGA_BF16_CONVS, OR-ed into giga_backward's head_present: the thirteen data-gradient convolutions of the U-Net run on bf16
+ * MFMA (operands rounded to bf16, fp32 accumulate, fp32 gradients in memory) from the backward blob's bf16 images; pairs with an
+ * encoder forward at precision 3.  Weight gradients, the decoder and conv_in stay fp32.  BASELINE config c5 ("bf16"). */
+#define GIGA_BF16_CONVS 32
+/* bf16 images of the convolution fragments, derived ON THE DEVICE from the fp32 fragments of the same blob(s) after
+ * giga_repack_device (either pointer may be NULL).  giga_pack_weights / giga_pack_bwd_weights fill them on the host too. */
+int giga_derive_bf16_fragments(void* packed_dev, void* bwd_packed_dev, void* stream);
 size_t giga_bwd_packed_bytes(void);
 int giga_pack_bwd_weights(const float* params_host, size_t n_params, int head_present, void* packed_host,
                           size_t packed_bytes);

@@ -69,8 +69,14 @@ def project_planes(feat):
     }
 
 
-def unet_forward(sd, x, prefix="encoder.unet."):
-    """unet.py:225-239 for UNet(32, in_channels=32, depth=3, start_filts=32, merge='concat')."""
+def unet_forward(sd, x, prefix="encoder.unet.", rnd=None):
+    """unet.py:225-239 for UNet(32, in_channels=32, depth=3, start_filts=32, merge='concat').
+    rnd (test aid, not in the reference): a rounding applied to the INPUT and WEIGHT of every convolution (bias and
+    accumulation stay fp32), e.g. lambda t: t.bfloat16().float() to emulate bf16 MFMA operands."""
+    if rnd is not None:
+        st = unet_stages(sd, x, prefix, rnd)
+        return st["OUT"]
+
     def c3(name, t):
         return F.relu(F.conv2d(t, sd[prefix + name + ".weight"], sd[prefix + name + ".bias"],
                                padding=1))
@@ -91,14 +97,16 @@ def unet_forward(sd, x, prefix="encoder.unet."):
     return F.conv2d(x, sd[prefix + "conv_final.weight"], sd[prefix + "conv_final.bias"])
 
 
-def unet_stages(sd, x, prefix="encoder.unet."):
+def unet_stages(sd, x, prefix="encoder.unet.", rnd=None):
     """Same arithmetic as unet_forward, returning every intermediate activation (NCHW) under the
-    workspace names of giga_encoder.hip (A0 S0 Q0 A1 S1 Q1 A2 S2 U0 A3 A4 U1 A5 A6 OUT)."""
+    workspace names of giga_encoder.hip (A0 S0 Q0 A1 S1 Q1 A2 S2 U0 A3 A4 U1 A5 A6 OUT).  rnd: see unet_forward."""
+    q = rnd if rnd is not None else (lambda t: t)
+
     def c3(name, t):
-        return F.relu(F.conv2d(t, sd[prefix + name + ".weight"], sd[prefix + name + ".bias"], padding=1))
+        return F.relu(F.conv2d(q(t), q(sd[prefix + name + ".weight"]), sd[prefix + name + ".bias"], padding=1))
 
     def up(name, t):
-        return F.conv_transpose2d(t, sd[prefix + name + ".weight"], sd[prefix + name + ".bias"], stride=2)
+        return F.conv_transpose2d(q(t), q(sd[prefix + name + ".weight"]), sd[prefix + name + ".bias"], stride=2)
 
     st = {}
     st["A0"] = c3("down_convs.0.conv1", x); st["S0"] = c3("down_convs.0.conv2", st["A0"])
@@ -110,14 +118,14 @@ def unet_stages(sd, x, prefix="encoder.unet."):
     st["A3"] = c3("up_convs.0.conv1", torch.cat((st["U0"], st["S1"]), 1)); st["A4"] = c3("up_convs.0.conv2", st["A3"])
     st["U1"] = up("up_convs.1.upconv", st["A4"])
     st["A5"] = c3("up_convs.1.conv1", torch.cat((st["U1"], st["S0"]), 1)); st["A6"] = c3("up_convs.1.conv2", st["A5"])
-    st["OUT"] = F.conv2d(st["A6"], sd[prefix + "conv_final.weight"], sd[prefix + "conv_final.bias"])
+    st["OUT"] = F.conv2d(q(st["A6"]), q(sd[prefix + "conv_final.weight"]), sd[prefix + "conv_final.bias"])
     return st
 
 
-def encoder_forward(sd, x):
-    """LocalVoxelEncoder.forward voxels.py:89-121.  x (B,40,40,40) -> {'xz','xy','yz'}: (B,32,40,40)."""
+def encoder_forward(sd, x, rnd=None):
+    """LocalVoxelEncoder.forward voxels.py:89-121.  x (B,40,40,40) -> {'xz','xy','yz'}: (B,32,40,40).  rnd: see unet_forward."""
     planes = project_planes(conv_in_relu(sd, x))
-    return {k: unet_forward(sd, planes[k]) for k in PLANES}
+    return {k: unet_forward(sd, planes[k], rnd=rnd) for k in PLANES}
 
 
 # --------------------------------------------------------------------------------------------

@@ -46,5 +46,5 @@ def test_multi_rank_code_path_at_world_size_one():
     ex = out["extra"]
     assert ex["rccl_ranks"] == 1
     assert ex["c3_gather"]["own_rows_match_on_every_rank"] is True and ex["c3_gather"]["scenes"] == 32
-    assert ex["c5_train_step_fp32_data_parallel"]["ms_per_step"] > 0
+    assert ex["c5_train_step_fp32_data_parallel"]["ms_per_step"] > 0 and ex["c5_train_step_bf16_data_parallel"]["ms_per_step"] > 0
     assert out["roofline"]["kernel"] in out["roofline"]["stages"]

@@ -30,6 +30,8 @@ def _blob_and_offsets(sd):
         at += nblk * taps * (cin // 16) * 1024 + nblk * taps * (cin // 8) * 1024 + up(co * 4)
         tail += 2 * nblk * taps * (cin // 16) * 1024          # f16x3 split conv fragments ([hi, lo] pairs), appended
     tail += 4 * 1024                                           # f16x3 split conv_in fragments
+    tail += sum((co // 32 * (4 if kind == 1 else 1)) * (9 if kind == 0 else 1) * ((c0 + c1) // 16) * 1024
+                for kind, c0, c1, co in conv)                  # bf16 conv fragments (f16 fragment layout)
     dec16, dec32 = [], []
     for _ in range(4):
         dec16.append(at); at += up(59 * 1024)          # 58 fragments + C table in a 59th 1 KiB chunk

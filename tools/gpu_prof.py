@@ -88,9 +88,9 @@ with torch.no_grad():
                 torch.cuda.synchronize()
                 print(prec, "B", Bt, "stage us:", out, "sum", round(sum(out), 1), "wall/iter us", round((time.perf_counter() - t0) / 10 * 1e6, 1))
 
-if what == "train":
+if what in ("train", "train_bf16"):
     from giga_amd.training import giga_loss
-    net.train()
+    net.train().set_train_precision("bf16" if what.endswith("bf16") else "fp32")
     x = torch.from_numpy(synth.tsdf_batch(0, B)).to(dev); pos = torch.from_numpy(synth.query_points(0, B, 1, stream=2)).to(dev)
     pos_occ = torch.from_numpy(synth.query_points(0, B, 2048, stream=3)).to(dev)
     y = tuple(torch.from_numpy(a).to(dev) for a in synth.train_labels(0, B, 2048))
