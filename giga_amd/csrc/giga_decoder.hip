@@ -67,9 +67,12 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16_kernel(DecArgs a) {
     // Every workgroup owns one contiguous, equally sized range of 32-point tiles and walks it in rounds of NW*T
     // tiles, so the ragged last round is a PARTIAL round on every CU (fewer active waves per SIMD) instead of a
     // full extra round on some CUs while the others idle.
+    // (workgroup i runs on XCD i % 8: the ranges are handed out so that an XCD owns a contiguous eighth of the points, i.e. an
+    //  eighth of the scenes, whose planes then stay in its own L2 -- 171 MB of fabric traffic per 32-scene launch otherwise)
     const long long tiles_total = (a.P + 31) / 32;
-    const long long tile_lo = tiles_total * blockIdx.x / gridDim.x;
-    const long long tile_hi = tiles_total * (blockIdx.x + 1) / gridDim.x;
+    const int bid = xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+    const long long tile_lo = tiles_total * bid / gridDim.x;
+    const long long tile_hi = tiles_total * (bid + 1) / gridDim.x;
     const int rounds = (int)((tile_hi - tile_lo + NW * T - 1) / (NW * T));
     if (rounds <= 0) return;
     // Step s uses the weight image of head s % nheads.  Waves 4..7 (the second wave of every SIMD) run
@@ -318,7 +321,16 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16s_kernel(DecArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, hi = lane >> 5;
-    const int hsel = blockIdx.x % a.nheads, slot = blockIdx.x / a.nheads, slots = gridDim.x / a.nheads;
+    // workgroup -> (head, slot of the tile range).  Workgroup i runs on XCD i % 8; when the grid is a multiple of 8 * nheads the
+    // slots of one XCD are made contiguous (an eighth of the points = an eighth of the scenes: their planes stay in that XCD's
+    // L2; with the plain i % nheads / i / nheads map every XCD walked every scene: 527 MB of fabric traffic per launch)
+    const int slots = gridDim.x / a.nheads;
+    int hsel = blockIdx.x % a.nheads, slot = blockIdx.x / a.nheads;
+    if (gridDim.x % (8 * a.nheads) == 0) {
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3, spx = slots >> 3;
+        hsel = k % a.nheads;
+        slot = xcd * spx + k / a.nheads;
+    }
     dma_head_image<NW, NCH>(a.blob + a.head_off[hsel], smem, wave, lane);
 
     const long long tiles_total = (a.P + 31) / 32;
@@ -881,11 +893,12 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
     const bool resident = precision == 2 ||
                           (precision == 1 && (force_resident >= 0 ? force_resident != 0 : tiles * a.nheads < (lat ? 16000 : 6000)));
     if (resident) {
-        const int cap = 256 / a.nheads;
+        const int cap = 256 / (8 * a.nheads) * 8;              // slots: a multiple of 8 (XCD-contiguous ranges), <= 256 / nheads
         auto go = [&](auto kern, int NW, int T, size_t lds) {
             const int per_round = NW * T;
             int slots = (int)((tiles + per_round - 1) / per_round);
             if (slots > cap) slots = cap;
+            else if (slots >= 8) slots &= ~7;
             a.nbatch = slots;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(kern, dim3(slots * a.nheads), dim3(NW * 64), lds, s, a);

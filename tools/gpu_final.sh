@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-of-round evidence in ONE GPU call: GPU tests, smoke, the default bench line, rocprofv3 kernel stats of the bench
 # command and of a training step, HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE separately).  Outputs: gpurun_out/final/.
-cd "${GRAFT_REPO_ROOT:-/root/repo}"; R=$PWD
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; R=$PWD; export GIGA_COMMIT=${GIGA_COMMIT:-0af03c6}
 O=$R/gpurun_out/final; mkdir -p $O; export TMPDIR=/tmp PYTHONPATH=$R
 timeout 900 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -n 2 $O/pytest.log
 timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 2 $O/smoke.log
