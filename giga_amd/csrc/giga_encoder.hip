@@ -330,20 +330,23 @@ EncWs enc_workspace(int B, int precision) {
 //   Co-residency of the 256 workgroups is what the barrier needs; the spin is bounded (no hang if another kernel holds CUs:
 //   the flag word behind the counter is set and the host falls back to per-layer launches).
 // ====================================================================================================
+// X(layer, KIND, C0, C1, COUT, H, W, NB, POOL, NB16): NB = 16-channel output blocks per unit for 4-byte operands (fp32, split:
+// the resident weights of NB blocks must fit LDS next to the patches); NB16 = the same for native f16 activations, whose
+// weights are half the size -- more blocks per unit = more MFMAs per A-operand read (the f16 layers are LDS-read-bound)
 #define GIGA_UNET_LAYERS(X)                              \
-    X(0, CONV3, 32, 0, 32, 40, 40, 2, false)             \
-    X(1, CONV3, 32, 0, 32, 40, 40, 2, true)              \
-    X(2, CONV3, 32, 0, 64, 20, 20, 1, false)             \
-    X(3, CONV3, 64, 0, 64, 20, 20, 1, true)              \
-    X(4, CONV3, 64, 0, 128, 10, 10, 1, false)            \
-    X(5, CONV3, 128, 0, 128, 10, 10, 1, false)           \
-    X(6, UPCONV, 128, 0, 64, 10, 10, 2, false)           \
-    X(7, CONV3, 64, 64, 64, 20, 20, 1, false)            \
-    X(8, CONV3, 64, 0, 64, 20, 20, 1, false)             \
-    X(9, UPCONV, 64, 0, 32, 20, 20, 2, false)            \
-    X(10, CONV3, 32, 32, 32, 40, 40, 2, false)           \
-    X(11, CONV3, 32, 0, 32, 40, 40, 2, false)            \
-    X(12, CONV1, 32, 0, 32, 40, 40, 2, false)
+    X(0, CONV3, 32, 0, 32, 40, 40, 2, false, 2)          \
+    X(1, CONV3, 32, 0, 32, 40, 40, 2, true, 2)           \
+    X(2, CONV3, 32, 0, 64, 20, 20, 1, false, 4)          \
+    X(3, CONV3, 64, 0, 64, 20, 20, 1, true, 4)           \
+    X(4, CONV3, 64, 0, 128, 10, 10, 1, false, 4)         \
+    X(5, CONV3, 128, 0, 128, 10, 10, 1, false, 2)        \
+    X(6, UPCONV, 128, 0, 64, 10, 10, 2, false, 2)        \
+    X(7, CONV3, 64, 64, 64, 20, 20, 1, false, 2)         \
+    X(8, CONV3, 64, 0, 64, 20, 20, 1, false, 4)          \
+    X(9, UPCONV, 64, 0, 32, 20, 20, 2, false, 2)         \
+    X(10, CONV3, 32, 32, 32, 40, 40, 2, false, 2)        \
+    X(11, CONV3, 32, 0, 32, 40, 40, 2, false, 2)         \
+    X(12, CONV1, 32, 0, 32, 40, 40, 2, false, 2)
 
 #ifdef GIGA_MEGA_EXPERIMENT   // measured slower than per-layer launches (profiles/r02e_persistent_unet_experiment.txt)
 struct MegaArgs {
@@ -357,7 +360,7 @@ constexpr int MEGA_NW = CONV_NW;                  // waves per workgroup of the 
 template <typename T, bool SPLIT>
 constexpr size_t mega_lds_bytes() {
     size_t m = 0;
-#define X(l, KIND, C0, C1, COUT, H, W, NB, POOL) \
+#define X(l, KIND, C0, C1, COUT, H, W, NB, POOL, NB16) \
     { constexpr size_t v = conv_lds_bytes<T, KIND, C0, C1, COUT, H, W, NB, SPLIT>(); m = v > m ? v : m; }
     GIGA_UNET_LAYERS(X)
 #undef X
@@ -534,8 +537,8 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     }
 #endif
     if (pr.stage == 15) (void)hipEventRecord(pr.ev0, s);
-#define X(l, KIND, C0, C1, COUT, H, W, NB, POOL)                                                                          \
-    if (l < nlayers) { pre(); rc |= launch_conv<T, KIND, C0, C1, COUT, H, W, NB, POOL, KIND == CONV3, MATH>(L[l], s); post(); } \
+#define X(l, KIND, C0, C1, COUT, H, W, NB, POOL, NB16)                                                                    \
+    if (l < nlayers) { pre(); rc |= launch_conv<T, KIND, C0, C1, COUT, H, W, (sizeof(T) == 2 ? NB16 : NB), POOL, KIND == CONV3, MATH>(L[l], s); post(); } \
     else { pre(); post(); }
     GIGA_UNET_LAYERS(X)
 #undef X
