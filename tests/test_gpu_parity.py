@@ -188,6 +188,37 @@ def test_ragged_and_tiny_batches(net, dev, sd7, prec):
             assert maxerr(a, b) < 2e-4, (B, N, M)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp16x3", "fp16"])
+def test_empty_and_degenerate_inputs(net, dev, prec):
+    """Empty batch, zero query points, zero occupancy points, non-contiguous / float64 inputs, mismatched batch sizes."""
+    net.set_precision(prec)
+    x = torch.from_numpy(synth.tsdf_batch(3, 2)).to(dev)
+    p = torch.from_numpy(synth.query_points(3, 2, 40, stream=1)).to(dev)
+    with torch.no_grad():
+        ref = net(x, p, p_tsdf=p)
+        q, r, w = net(x[:0], p[:0])                          # no scenes
+        assert q.shape == (0, 40) and r.shape == (0, 40, 4) and w.shape == (0, 40)
+        q, r, w, t = net(x, p[:, :0], p_tsdf=p)              # no grasp queries
+        assert q.shape == (2, 0) and r.shape == (2, 0, 4) and torch.equal(t, ref[3])
+        q, r, w, t = net(x, p, p_tsdf=p[:, :0])              # no occupancy queries
+        assert t.shape == (2, 0) and torch.equal(q, ref[0]) and torch.equal(r, ref[1])
+        # non-contiguous views and float64 inputs are accepted and converted (the reference calls .float() itself)
+        xt = x.permute(0, 3, 2, 1).contiguous().permute(0, 3, 2, 1)
+        pw = torch.cat((p, p), 2)[:, :, 3:]
+        out = net(xt.double(), pw.double(), p_tsdf=pw)
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b)
+        planes = net.encode_inputs(x)
+        with pytest.raises(ValueError):
+            net.decode(p[:1], planes)                        # one scene of points, two scenes of planes
+        with pytest.raises(ValueError):
+            net.encode_inputs(x[:, :39])                     # not a 40^3 grid
+    from giga_amd import _capi
+    with pytest.raises(_capi.GigaHipError):
+        net(x.cpu(), p.cpu())                                # no CPU fallback
+    net.set_precision("fp32")
+
+
 def test_scene_independence_and_determinism(net, dev):
     """Batch dim is carried untouched: scene i of a batch == the same scene alone; reruns are bit-identical."""
     net.set_precision("fp32")
