@@ -477,7 +477,8 @@ class _ParamListCache:
         return super().load_state_dict(*args, **kwargs)
 
     def train(self, mode=True):
-        self.invalidate_packed()
+        if mode != self.training:                            # (training loops call net.train() every iteration: keep that free)
+            self.invalidate_packed()
         return super().train(mode)
 
 

@@ -893,12 +893,15 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
     const bool resident = precision == 2 ||
                           (precision == 1 && (force_resident >= 0 ? force_resident != 0 : tiles * a.nheads < (lat ? 16000 : 6000)));
     if (resident) {
-        const int cap = 256 / (8 * a.nheads) * 8;              // slots: a multiple of 8 (XCD-contiguous ranges), <= 256 / nheads
+        const int cap = 256 / a.nheads;                        // one workgroup per CU
+        const int cap8 = 256 / (8 * a.nheads) * 8;             // ... or a multiple of 8 slots: XCD-contiguous ranges (L2 locality)
         auto go = [&](auto kern, int NW, int T, size_t lds) {
             const int per_round = NW * T;
             int slots = (int)((tiles + per_round - 1) / per_round);
-            if (slots > cap) slots = cap;
-            else if (slots >= 8) slots &= ~7;
+            // large launches trade the last few CUs for L2 locality; small ones (a single scene: 2000 tiles) are latency-bound and
+            // take every CU -- 240 instead of 255 workgroups would add a third, nearly empty round
+            if (slots > cap) slots = tiles >= 8LL * cap * per_round ? cap8 : cap;
+            else if (slots >= 8 && tiles >= 8LL * slots) slots &= ~7;
             a.nbatch = slots;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(kern, dim3(slots * a.nheads), dim3(NW * 64), lds, s, a);
