@@ -422,6 +422,196 @@ static int launch_wgrad3(const Wgrad3Args& a, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
+// ------------------------------- 3x3 weight gradient on bf16 MFMA (BASELINE c5) -----------------------------
+// dW[co][ci][tap] = sum_pixels dY[p][co] * X[p + tap][ci]   with bf16 operands, fp32 accumulation: v_mfma_f32_32x32x16_bf16,
+// D[co][ci] += A[co][k] * B[k][ci], k = 16 PIXELS per instruction (the fp32 kernel above: 2 pixels per 64-cycle instruction).
+// Same decomposition, partial images, epilogue and reduce kernel as conv3_wgrad_kernel; what changes is the operand side:
+//   * the contraction runs over pixels, so a lane needs 8 consecutive pixels of ONE channel: the strips are staged
+//     TRANSPOSED, channel-major bf16 -- Xt[ci][row][col], Yt[co][row][col].  A staging item is (4 channels, row, 8-pixel
+//     group): eight coalesced float4 loads (a pixel's channels are contiguous across lanes), converted and written as four
+//     16-byte rows.  Rounding to bf16 happens here, once per element.
+//   * a k-chunk = two 8-pixel groups (lane half hi takes group 2j + hi); groups tile the rows (40 = 5 groups; 20 and 10 are
+//     padded to 24 / 16 with zeros, which contribute nothing).
+//   * the three horizontal taps are ONE aligned 16-byte read plus the two neighbouring elements (two 4-byte reads), shifted
+//     into place with v_alignbyte_b32: per k-chunk 1 + 3 x 3 LDS reads and 24 VALU feed nine MFMAs (288 matrix cycles).
+//   X columns: data at col 8 + x; cols < 8 and >= 8 + 8G stay zero (the convolution's zero padding), zeroed once.
+typedef __bf16 wbf8 __attribute__((ext_vector_type(8)));
+
+template <int C0, int C1, int COUT, int H, int RS>
+__global__ __launch_bounds__(512) void conv3_wgrad_bf16_kernel(Wgrad3Args a) {
+    constexpr int W = H, CIN = C0 + C1;
+    constexpr int NBK = CIN / 32, NBLK = (COUT / 32) * NBK;
+    constexpr int BPG = NBLK < 8 ? NBLK : 8;          // blocks per workgroup
+    constexpr int KS = 8 / BPG;                       // waves sharing a block (K split)
+    constexpr int G = (W + 7) / 8;                    // 8-pixel groups per row
+    constexpr int PY = 8 * G, PX = 8 * G + 16;        // row pitches (bf16 elements)
+    constexpr int XR = RS + 2;
+    constexpr int NVX = (CIN / 4) * XR * G, NVY = (COUT / 4) * RS * G, NV = NVX + NVY;
+    static_assert(NV <= 512, "one staging item per thread");
+    constexpr int XELEMS = CIN * XR * PX, YELEMS = COUT * RS * PY;
+    constexpr int NCH = RS * G / 2;                   // k-chunks (two groups each) per strip
+    static_assert((RS * G) % 2 == 0 && H % RS == 0, "strip geometry");
+    extern __shared__ __attribute__((aligned(16))) float wg_lds[];
+    __bf16* Xt = reinterpret_cast<__bf16*>(wg_lds);
+    __bf16* Yt = Xt + XELEMS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, hi = lane >> 5;
+    const int blk = blockIdx.y * BPG + wave / KS, ks = wave % KS;
+    const int mb = blk / NBK, nb = blk % NBK;
+
+    // zero the whole X image once: the halo columns are never written again
+    for (int v = tid; v < XELEMS / 8; v += 512) reinterpret_cast<uint4*>(Xt)[v] = make_uint4(0, 0, 0, 0);
+
+    // this thread's staging item
+    const bool isx = tid < NVX, isy = !isx && tid < NV;
+    const int u = isx ? tid : tid - NVX;
+    const int cq = isx ? u % (CIN / 4) : u % (COUT / 4);
+    const int rest = isx ? u / (CIN / 4) : u / (COUT / 4);
+    const int sg = rest % G, sr = rest / G;           // group within the row, strip row
+    constexpr int SPI = H / RS;
+    const int nstrips = a.nimg * SPI;
+    float4 stg[8];
+    auto issue = [&](int st) {
+        const int img = st / SPI, y0 = (st % SPI) * RS;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int x = 8 * sg + e;
+            if (isy) {
+                if (x < W) val = *reinterpret_cast<const float4*>(a.dY + ((size_t)(img * H + y0 + sr) * W + x) * COUT + 4 * cq);
+            } else if (isx) {
+                const int gy = y0 - 1 + sr, c = 4 * cq;
+                if (gy >= 0 && gy < H && x < W) {
+                    const size_t px = (size_t)(img * H + gy) * W + x;
+                    val = c < C0 ? *reinterpret_cast<const float4*>(a.in0 + px * C0 + c)
+                                 : *reinterpret_cast<const float4*>(a.in1 + px * C1 + (c - C0));
+                }
+            }
+            stg[e] = val;
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const __bf16* ya = Yt + (size_t)(mb * 32 + n) * RS * PY;          // this lane's dY channel row block
+    const __bf16* xb = Xt + (size_t)(nb * 32 + n) * XR * PX + 8;      // this lane's X channel, col of x = 0
+
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    int st = blockIdx.x;
+    if (st < nstrips) issue(st);
+    for (; st < nstrips; st += gridDim.x) {
+        __syncthreads();                              // everyone is done reading the previous strip (and the zero fill)
+        if (isx || isy) {
+            __bf16* dst = isx ? Xt + ((size_t)(4 * cq) * XR + sr) * PX + 8 + 8 * sg : Yt + ((size_t)(4 * cq) * RS + sr) * PY + 8 * sg;
+            const int cstride = isx ? XR * PX : RS * PY;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                const float v8[8] = {ch == 0 ? stg[0].x : ch == 1 ? stg[0].y : ch == 2 ? stg[0].z : stg[0].w,
+                                     ch == 0 ? stg[1].x : ch == 1 ? stg[1].y : ch == 2 ? stg[1].z : stg[1].w,
+                                     ch == 0 ? stg[2].x : ch == 1 ? stg[2].y : ch == 2 ? stg[2].z : stg[2].w,
+                                     ch == 0 ? stg[3].x : ch == 1 ? stg[3].y : ch == 2 ? stg[3].z : stg[3].w,
+                                     ch == 0 ? stg[4].x : ch == 1 ? stg[4].y : ch == 2 ? stg[4].z : stg[4].w,
+                                     ch == 0 ? stg[5].x : ch == 1 ? stg[5].y : ch == 2 ? stg[5].z : stg[5].w,
+                                     ch == 0 ? stg[6].x : ch == 1 ? stg[6].y : ch == 2 ? stg[6].z : stg[6].w,
+                                     ch == 0 ? stg[7].x : ch == 1 ? stg[7].y : ch == 2 ? stg[7].z : stg[7].w};
+                wbf8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (__bf16)v8[e];
+                *reinterpret_cast<wbf8*>(dst + (size_t)ch * cstride) = o;
+                if (isy && blockIdx.y == 0)           // bias gradient: column sums of dY, from the fp32 values
+                    bsum[ch] += ((v8[0] + v8[1]) + (v8[2] + v8[3])) + ((v8[4] + v8[5]) + (v8[6] + v8[7]));
+            }
+        }
+        __syncthreads();
+        if (st + (int)gridDim.x < nstrips) issue(st + gridDim.x);      // flies under this strip's MFMAs
+        for (int j = ks; j < NCH; j += KS) {
+            const int gi = 2 * j + hi, r = gi / G, xg = gi % G;
+            const wbf8 A = *reinterpret_cast<const wbf8*>(ya + r * PY + 8 * xg);
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty) {
+                const __bf16* row = xb + (r + ty) * PX + 8 * xg;                 // X row y + ty - 1, col of the group's x0
+                const uint4 mid = *reinterpret_cast<const uint4*>(row);
+                const unsigned wp = *reinterpret_cast<const unsigned*>(row - 2);  // elements x0-2, x0-1
+                const unsigned wn = *reinterpret_cast<const unsigned*>(row + 8);  // elements x0+8, x0+9
+                const uint4 left = {__builtin_amdgcn_alignbyte(mid.x, wp, 2), __builtin_amdgcn_alignbyte(mid.y, mid.x, 2),
+                                    __builtin_amdgcn_alignbyte(mid.z, mid.y, 2), __builtin_amdgcn_alignbyte(mid.w, mid.z, 2)};
+                const uint4 right = {__builtin_amdgcn_alignbyte(mid.y, mid.x, 2), __builtin_amdgcn_alignbyte(mid.z, mid.y, 2),
+                                     __builtin_amdgcn_alignbyte(mid.w, mid.z, 2), __builtin_amdgcn_alignbyte(wn, mid.w, 2)};
+                acc[3 * ty + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(wbf8, left), acc[3 * ty + 0], 0, 0, 0);
+                acc[3 * ty + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(wbf8, mid), acc[3 * ty + 1], 0, 0, 0);
+                acc[3 * ty + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(wbf8, right), acc[3 * ty + 2], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: as conv3_wgrad_kernel (the D layout of the bf16 MFMA is the same 32x32 map) ----------------------
+    if (blockIdx.y == 0) {
+        __syncthreads();
+        // per-channel totals: threads of the dY items hold 4 channels each for their (row, group)
+        float* red = wg_lds;                                          // [COUT] after zeroing
+        for (int c = tid; c < COUT; c += 512) red[c] = 0.f;
+        __syncthreads();
+        if (isy) {
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) atomicAdd(red + 4 * cq + ch, bsum[ch]);      // LDS, <= RS*G addends per channel
+        }
+        __syncthreads();
+        if (tid < COUT)
+            a.partial[(size_t)gridDim.y * gridDim.x * BPG * 9 * 1024 + (size_t)blockIdx.x * COUT + tid] = red[tid];
+    }
+    float4* slot = reinterpret_cast<float4*>(wg_lds);                 // [wave][tap of the round][r4][lane]
+    constexpr int RN = 9 * 1024;
+    float* part = a.partial + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * BPG) * RN;
+#pragma unroll
+    for (int g3 = 0; g3 < 3; ++g3) {
+        __syncthreads();
+#pragma unroll
+        for (int tl = 0; tl < 3; ++tl)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                slot[((wave * 3 + tl) * 4 + r4) * 64 + lane] =
+                    make_float4(acc[3 * g3 + tl][4 * r4], acc[3 * g3 + tl][4 * r4 + 1], acc[3 * g3 + tl][4 * r4 + 2],
+                                acc[3 * g3 + tl][4 * r4 + 3]);
+        __syncthreads();
+        for (int v = tid; v < BPG * 3 * 4 * 64; v += 512) {
+            const int ln = v & 63, r4 = (v >> 6) & 3, tl = (v >> 8) % 3, b = v / 768;
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < KS; ++q) {
+                const float4 x = slot[(((b * KS + q) * 3 + tl) * 4 + r4) * 64 + ln];
+                sum.x += x.x; sum.y += x.y; sum.z += x.z; sum.w += x.w;
+            }
+            const int nn = ln & 31, m0 = 8 * r4 + 4 * (ln >> 5);      // D rows of registers 4*r4 .. 4*r4+3: m0 .. m0+3
+            float* dst = part + ((size_t)(b * 9 + 3 * g3 + tl) * 32 + m0) * 32 + nn;
+            dst[0] = sum.x; dst[32] = sum.y; dst[64] = sum.z; dst[96] = sum.w;
+        }
+    }
+}
+
+template <int C0, int C1, int COUT, int H, int RS>
+static int launch_wgrad3_bf16(const Wgrad3Args& a, hipStream_t s) {
+    constexpr int CIN = C0 + C1, W = H;
+    constexpr int NBLK = (COUT / 32) * (CIN / 32), BPG = NBLK < 8 ? NBLK : 8, NY = NBLK / BPG;
+    constexpr int G = (W + 7) / 8;
+    constexpr size_t strip = ((size_t)CIN * (RS + 2) * (8 * G + 16) + (size_t)COUT * RS * 8 * G) * 2;
+    constexpr size_t lds = strip > 8 * 3 * 4 * 64 * 16 ? strip : 8 * 3 * 4 * 64 * 16;      // strip or the epilogue slots (96 KiB)
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    const int nstrips = a.nimg * (H / RS);
+    int gx = 256 / NY;
+    if (gx > nstrips) gx = nstrips;
+    auto kern = conv3_wgrad_bf16_kernel<C0, C1, COUT, H, RS>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(gx, NY), dim3(512), lds, s, a);
+    constexpr int NZ = NBLK >= 8 ? 1 : 8 / NBLK;
+    hipLaunchKernelGGL((wgrad3_reduce_kernel<CIN, BPG, NZ>), dim3(9 * 1024 / 256 + 1, NBLK, NZ), dim3(256), 0, s, a.partial, gx,
+                       a.dW, a.db, COUT, NY);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
 // ------------------------------- conv_in backward ----------------------------------------------------------
 // Same decomposition as convin_project_kernel: workgroup = (x-part, iy-group x channel half, scene), the haloed TSDF
 // sub-volume is staged in LDS once, every wave owns SXW slices and runs without workgroup barriers; units of 16 voxels x
@@ -643,14 +833,16 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
         a.nimg = nimg; a.H = H; a.W = H;
         if (d.kind == CONV3) {
             Wgrad3Args w3{dpre, in0, in1, grads + po.conv_w[l], grads + po.conv_b[l], G(g.WG), nimg};
+#define WG3(...) (MATH == MATH_BF16 ? launch_wgrad3_bf16<__VA_ARGS__>(w3, s) : launch_wgrad3<__VA_ARGS__>(w3, s))
             switch (l) {   // <C0, C1, COUT, H, rows per strip>
-                case 0: case 1: case 11: rc |= launch_wgrad3<32, 0, 32, 40, 4>(w3, s); break;
-                case 10: rc |= launch_wgrad3<32, 32, 32, 40, 2>(w3, s); break;
-                case 2: rc |= launch_wgrad3<32, 0, 64, 20, 4>(w3, s); break;
-                case 3: case 8: rc |= launch_wgrad3<64, 0, 64, 20, 4>(w3, s); break;
-                case 7: rc |= launch_wgrad3<64, 64, 64, 20, 2>(w3, s); break;
-                case 4: rc |= launch_wgrad3<64, 0, 128, 10, 2>(w3, s); break;
-                case 5: rc |= launch_wgrad3<128, 0, 128, 10, 2>(w3, s); break;
+                case 0: case 1: case 11: rc |= WG3(32, 0, 32, 40, 4); break;
+                case 10: rc |= WG3(32, 32, 32, 40, 2); break;
+                case 2: rc |= WG3(32, 0, 64, 20, 4); break;
+                case 3: case 8: rc |= WG3(64, 0, 64, 20, 4); break;
+                case 7: rc |= WG3(64, 64, 64, 20, 2); break;
+                case 4: rc |= WG3(64, 0, 128, 10, 2); break;
+                case 5: rc |= WG3(128, 0, 128, 10, 2); break;
+#undef WG3
                 default: rc |= launch_wgrad(a, s); colsum(dpre, d.cout, 0, d.cout, (size_t)nimg * H * H, l);
             }
         } else {

@@ -1,9 +1,9 @@
 """Training path: autograd bridge to the HIP forward/backward kernels and the fused loss of the joint objective
 (reference scripts/train_giga.py:154-211).  Two arithmetic modes (`net.set_train_precision`): "fp32" (every GEMM on the
-fp32-input MFMA; gradients match torch autograd to <= 6e-6 relative) and "bf16" (BASELINE config c5: the U-Net's forward and
-data-gradient convolutions -- two thirds of the step's FLOPs -- take bf16 operands with fp32 accumulation on
-v_mfma_f32_16x16x32_bf16; activations, weight gradients, the decoder, conv_in, master weights and the optimizer stay fp32,
-as under torch.autocast; gradients then carry bf16 operand rounding, ~1e-2 relative).
+fp32-input MFMA; gradients match torch autograd to <= 6e-6 relative) and "bf16" (BASELINE config c5: the forward, data-gradient
+and weight-gradient GEMMs of the 3x3 U-Net layers -- ~95 % of the step's FLOPs -- take bf16 operands with fp32 accumulation on the
+bf16 MFMA; activations in memory, the decoders, conv_in, ConvTranspose / 1x1 weight gradients, master weights and the optimizer
+stay fp32, as under torch.autocast; gradients then carry bf16 operand rounding).
 
 `ConvolutionalOccupancyNetwork.forward` dispatches here when autograd is enabled and parameters require grad, so the
 reference loop works unchanged with ITS OWN helpers (`select`, `loss_fn` of train_giga.py stay in the caller):

@@ -142,9 +142,10 @@ int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, cons
  * giga_pack_bwd_map + giga_repack_device on the device every step).  Weight gradients are reduced with fp32
  * atomics (run-to-run differences at rounding level, as in PyTorch's own GPU backward). */
 #define GIGA_DETACH_OCC 16
-/* GIGA_BF16_CONVS, OR-ed into giga_backward's head_present: the thirteen data-gradient convolutions of the U-Net run on bf16
- * MFMA (operands rounded to bf16, fp32 accumulate, fp32 gradients in memory) from the backward blob's bf16 images; pairs with an
- * encoder forward at precision 3.  Weight gradients, the decoder and conv_in stay fp32.  BASELINE config c5 ("bf16"). */
+/* GIGA_BF16_CONVS, OR-ed into giga_backward's head_present: the thirteen data-gradient convolutions of the U-Net (from the
+ * backward blob's bf16 images) and the weight gradients of its eleven 3x3 layers run on bf16 MFMA (operands rounded to bf16,
+ * fp32 accumulate, fp32 gradients in memory); pairs with an encoder forward at precision 3.  ConvTranspose / 1x1 weight
+ * gradients, the decoder and conv_in stay fp32.  BASELINE config c5 ("bf16"). */
 #define GIGA_BF16_CONVS 32
 /* bf16 images of the convolution fragments, derived ON THE DEVICE from the fp32 fragments of the same blob(s) after
  * giga_repack_device (either pointer may be NULL).  giga_pack_weights / giga_pack_bwd_weights fill them on the host too. */
