@@ -60,6 +60,22 @@ __device__ __forceinline__ half8 pack_relu8(const f32x16& d, int c) {
 // f16x3 split of relu(D registers 8c..8c+7): hi = f16(x) (round to nearest), lo = f16(x - hi); hi + lo carries x to
 // ~2^-22 relative.  The subtraction is written as an fma on the widened half so that it selects v_fma_mix_f32 (one
 // instruction, exact: x - hi has at most 13 significant bits).
+// global_store_dword in its saddr form: uniform 64-bit base in SGPRs + 32-bit per-lane byte offset.  (The compiler hoists the
+// zero-extension of the offset out of loops and then selects a 64-bit VALU add per store instead.)
+__device__ __forceinline__ void store_f32_saddr(float* uniform_base, unsigned byte_off, float v) {
+    asm volatile("global_store_dword %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(uniform_base) : "memory");
+}
+
+// v_permlane32_swap / v_permlane16_swap (gfx950): a's upper half (odd 16-lane rows) <-> b's lower half (even rows); plain VALU,
+// no LDS.  Inline asm: the builtin's second result is mis-assigned by this compiler (both results alias the first operand).
+// The leading s_nop covers the VALU-write -> permlane-read hazard the compiler cannot see through the asm.
+__device__ __forceinline__ void lane32_swap(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lane16_swap(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
 __device__ __forceinline__ void split_relu8(const f32x16& d, int c, half8& hi, half8& lo) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

@@ -35,9 +35,10 @@ namespace giga {
 
 constexpr int CV_RS = 44;                         // floats per (ix, iy) row of the staged sub-volume: iz + 1 in [0, 41]
 constexpr int CV_ROWS = 12;                       // the group's 10 iy rows + halo
-constexpr size_t ci_lds_bytes(int sxw) {
-    const size_t stage = (size_t)(8 * sxw + 2) * CV_ROWS * CV_RS * sizeof(float);
-    const size_t red = (size_t)8 * 10 * 64 * 16;  // yz reduction: 8 waves x 10 units x 64 lanes x 16 B
+constexpr int ci_red_units(int nw) { return nw == 4 ? 25 : 13; }   // yz reduction: units per round (8 waves: 13 + 12, 104 KiB; 4 waves: all 25)
+constexpr size_t ci_lds_bytes(int xw, int nw) {
+    const size_t stage = (size_t)(xw + 3) * CV_ROWS * CV_RS * sizeof(float);   // + one slab: the A-operand prefetch runs one slice ahead
+    const size_t red = (size_t)nw * ci_red_units(nw) * 64 * 16;                // NW waves x UR units x 64 lanes x 16 B
     return stage > red ? stage : red;
 }
 
@@ -45,8 +46,15 @@ constexpr size_t ci_lds_bytes(int sxw) {
 // holding the pair (hi = f16(v), lo = f16(v - hi)); the 27 taps (+5 zero weights) are ONE K = 32 step, i.e. three
 // v_mfma_f32_16x16x32_f16 per unit (W_lo*x_hi + W_hi*x_lo + W_hi*x_hi, bias in the C operand) instead of seven
 // v_mfma_f32_16x16x4_f32; a lane gathers its 8 tap words and separates them into the hi and lo operand with 8 byte-permutes.
-template <typename TOut, int SXW, bool SPLIT = false>
-__global__ __launch_bounds__(512) void convin_project_kernel(
+#ifdef GIGA_TRACE
+static __device__ long long g_ci_trace[8 * 64];
+#define CI_T(idx) do { if (blockIdx.x == 43 && lane == 0) \
+        g_ci_trace[wave * 64 + (idx)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CI_T(idx) do {} while (0)
+#endif
+template <typename TOut, int SXW, bool SPLIT = false, int NW = 8>
+__global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for NW = 4: a 256-thread bound makes the compiler put the MFMA results into AGPRs and copy them out for the epilogue)
     const float* __restrict__ tsdf,        // [B][40][40][40]
     const float* __restrict__ wpk,         // [2][7][64] packed B operands (SPLIT: [2][hi|lo][64] x 8 halfs)
     const float* __restrict__ bias,        // [32]
@@ -54,37 +62,63 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
     float* __restrict__ xz_partial,        // [4 iy-groups][B][40(iz)][40(ix)][32] sums over the group's 10 iy
     float* __restrict__ yz_partial,        // [NXP][B][40(iz)][40(iy)][32] sums over the part's ix
     int B) {
-    constexpr int XW = 8 * SXW;
+    constexpr int XW = NW * SXW, NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
-    const int xp = blockIdx.x, grp = blockIdx.y >> 1, chh = blockIdx.y & 1, b = blockIdx.z;
+    // SXW == 5 (one x-part): a 1-D grid of 8 B workgroups, re-mapped so that the eight workgroups of a scene (4 iy-groups x
+    // 2 channel halves, which share the scene's sub-volumes) run on ONE XCD and hit in its L2: workgroup i runs on XCD i % 8.
+    int xp = blockIdx.x, wy = blockIdx.y, b = blockIdx.z;
+    if constexpr (XW == RES) {
+        const int i = blockIdx.x, nfull = (B >> 3) << 6;           // workgroups of the scenes that fill whole groups of 8
+        xp = 0;
+        if (i < nfull) { const int xcd = i & 7, slot = i >> 3; b = (slot >> 3) * 8 + xcd; wy = slot & 7; }
+        else           { b = i >> 3; wy = i & 7; }
+    }
+    const int grp = wy >> 1, chh = wy & 1;
     const int x0 = xp * XW;
     const float* vol = tsdf + (size_t)b * RES * RES * RES;
+    CI_T(0);
 
     // ---- stage the haloed sub-volume: rows (xl, yl) of 40 iz values + the two iz halo cells; outside = 0 ----
-    for (int v = tid; v < (XW + 2) * CV_ROWS * 10; v += 512) {
-        const int q = v % 10, row = v / 10, yl = row % CV_ROWS, xl = row / CV_ROWS;
-        const int ix = x0 - 1 + xl, iy = 10 * grp - 1 + yl;
-        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ix >= 0 && ix < RES && iy >= 0 && iy < RES)
-            val = *reinterpret_cast<const float4*>(vol + ((size_t)ix * RES + iy) * RES + 4 * q);
-        float* dst = lds + row * CV_RS + 1 + 4 * q;
-        if constexpr (SPLIT) {                     // word = hi | lo << 16
-            const float v4[4] = {val.x, val.y, val.z, val.w};
+    // All global loads of a thread are issued before the first LDS write (one memory latency, not one per item).
+    constexpr int NITEM = (XW + 2) * CV_ROWS * 10, NIT = (NITEM + NT - 1) / NT;
+    constexpr int NBT = 10;                                  // loads in flight per thread and batch
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const half_t h = (half_t)v4[e];
-                const half_t l = (half_t)__builtin_fmaf((float)h, -1.0f, v4[e]);
-                const unsigned w = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
-                dst[e] = __builtin_bit_cast(float, w);
-            }
-        } else {
-            dst[0] = val.x; dst[1] = val.y; dst[2] = val.z; dst[3] = val.w;
+    for (int it0 = 0; it0 < NIT; it0 += NBT) {
+        float4 vals[NBT];
+#pragma unroll
+        for (int it = 0; it < NBT; ++it) {
+            const int v = tid + NT * (it0 + it);
+            const int q = v % 10, row = v / 10, yl = row % CV_ROWS, xl = row / CV_ROWS;
+            const int ix = x0 - 1 + xl, iy = 10 * grp - 1 + yl;
+            vals[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it0 + it < NIT && v < NITEM && ix >= 0 && ix < RES && iy >= 0 && iy < RES)
+                vals[it] = *reinterpret_cast<const float4*>(vol + ((size_t)ix * RES + iy) * RES + 4 * q);
         }
-        if (q == 0) dst[-1] = 0.f;
-        if (q == 9) dst[4] = 0.f;
+#pragma unroll
+        for (int it = 0; it < NBT; ++it) {
+            const int v = tid + NT * (it0 + it);
+            if (it0 + it >= NIT || v >= NITEM) break;
+            const int q = v % 10, row = v / 10;
+            const float4 val = vals[it];
+            float* dst = lds + row * CV_RS + 1 + 4 * q;
+            if constexpr (SPLIT) {                     // word = hi | lo << 16
+                const float v4[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const half_t h = (half_t)v4[e];
+                    const half_t l = (half_t)__builtin_fmaf((float)h, -1.0f, v4[e]);
+                    const unsigned w = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+                    dst[e] = __builtin_bit_cast(float, w);
+                }
+            } else {
+                dst[0] = val.x; dst[1] = val.y; dst[2] = val.z; dst[3] = val.w;
+            }
+            if (q == 0) dst[-1] = 0.f;
+            if (q == 9) dst[4] = 0.f;
+        }
     }
     float wreg[7];
     half8 wsh = {0, 0, 0, 0, 0, 0, 0, 0}, wsl = wsh;
@@ -127,138 +161,182 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
     float* xzp = xz_partial + ((size_t)grp * B + b) * img_stride;
     const f32x4v bias4 = {bn, bn, bn, bn};            // the bias rides in the C operand of the first MFMA
     const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
-    const int xz_lane = 4 * (g & 1) * RES * CD + ch;  // lane part of the xz-partial index (uniform base + 32-bit offset)
+    const unsigned xz_lane_b = ((4 * (g & 1) + 2 * (g >> 1)) * RES * CD + ch) * 4u;   // lane part of the xz-partial address (bytes): rows r = 2 (g >> 1) + {0, 1}
+    // plane xz [iz][ix][c], this iy-group's share of one (ix, iz-group): the other iy row of each tile lives in lane^32.
+    // Two v_permlane32_swap (plain VALU: no LDS round trip, no wait) leave rows r = 0,1 summed in lanes 0..31 and rows
+    // r = 2,3 in lanes 32..63, so every lane stores two values.  `dst` = uniform part of the address.
+    auto xz_store = [&](const f32x4v& part, float* dst) {
+        float a02 = part[0], b02 = part[2], a13 = part[1], b13 = part[3];
+        lane32_swap(a02, b02);
+        lane32_swap(a13, b13);
+        store_f32_saddr(dst, xz_lane_b, a02 + b02);                 // uniform base + 32-bit lane offset: no VALU address arithmetic
+        store_f32_saddr(dst + RES * CD, xz_lane_b, a13 + b13);
+    };
+    // plane xy [iy][ix][c] of one ix: the other half of the 8 iz of each tile lives in lane^16.  v_permlane16_swap pairs two
+    // iy-pairs: even 16-lane rows end up with the total of pair `ia`, odd rows with `ib`.
+    auto xy_store = [&](const f32x2v (&sz)[5], TOut* dst) {
+#pragma unroll
+        for (int ia = 0; ia < 5; ia += 2) {
+            const int ib = ia + 1 < 5 ? ia + 1 : ia;
+            float sa = sz[ia][0] + sz[ia][1], sb = sz[ib][0] + sz[ib][1];
+            lane16_swap(sa, sb);
+            if (ia != ib || (g & 1) == 0) {
+                const int iy = grp * 10 + 2 * (ia + (g & 1) * (ib - ia)) + (g >> 1);
+                dst[iy * RES * CD + ch] = (TOut)((sa + sb) * inv);
+            }
+        }
+    };
+    CI_T(1);
     __syncthreads();
+    CI_T(2);
 
+    if constexpr (SPLIT) {
     for (int sx = 0; sx < SXW; ++sx) {
         const int ixl = wave * SXW + sx, ix = x0 + ixl;
-        int addr[7];
-#pragma unroll
-        for (int s = 0; s < 7; ++s) addr[s] = abase[s] + ixl * CV_ROWS * CV_RS;
         f32x2v sum_z[5];                  // per iy-pair: sum over the 5 iz-groups and the 4 in-lane iz (two partials)
 #pragma unroll
         for (int ip = 0; ip < 5; ++ip) sum_z[ip] = f32x2v{0.f, 0.f};
-        // Software pipeline over the 5 iz-groups.  Per group: five independent 7-MFMA chains (the iy-pairs).
-        // A operands of MFMA steps 0..2 are loaded one group ahead (P), those of steps 3..6 at the top of the
-        // group (Q) under the first 15 MFMAs, so no LDS round trip is exposed.  The 35 MFMAs stay one
-        // uninterrupted burst (an extra issue slot between MFMAs costs far more than the slot itself); the ReLU /
-        // axis-sum epilogue is paid in full: fp32 MFMA shares the VALU with it.
-        float P[3][5], Q[4][5];
         const unsigned* ldw = reinterpret_cast<const unsigned*>(lds);
-        if constexpr (SPLIT) {
-        } else {
-#pragma unroll
-            for (int s = 0; s < 3; ++s)
-#pragma unroll
-                for (int ip = 0; ip < 5; ++ip) P[s][ip] = lds[addr[s] + 2 * ip * CV_RS];
-        }
 #pragma unroll
         for (int zg = 0; zg < 5; ++zg) {
             f32x4v d[5];
-            if constexpr (SPLIT) {
-                // two batches (3 + 2 units) keep the operand registers low: the 100 yz accumulators stay resident
+            CI_T(3 + 6 * sx + zg);
+            // two batches (3 + 2 units) keep the operand registers low: the 100 yz accumulators stay resident
 #pragma unroll
-                for (int b0 = 0; b0 < 5; b0 += 3) {
-                    constexpr int NBATCH = 3;
-                    half8 ah[NBATCH], al[NBATCH];
+            for (int b0 = 0; b0 < 5; b0 += 3) {
+                constexpr int NBATCH = 3;
+                half8 ah[NBATCH], al[NBATCH];
 #pragma unroll
-                    for (int u = 0; u < NBATCH; ++u) {
-                        const int ip = b0 + u;
-                        if (ip < 5) {
-                            unsigned w8[8];
+                for (int u = 0; u < NBATCH; ++u) {
+                    const int ip = b0 + u;
+                    if (ip < 5) {
+                        unsigned w8[8];
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) w8[e] = ldw[sbase[e] + ixl * CV_ROWS * CV_RS + 2 * ip * CV_RS + 8 * zg];
-                            unsigned hw[4], lw[4];
+                        for (int e = 0; e < 8; ++e) w8[e] = ldw[sbase[e] + ixl * CV_ROWS * CV_RS + 2 * ip * CV_RS + 8 * zg];
+                        unsigned hw[4], lw[4];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {   // bytes [w0.b0 w0.b1 w1.b0 w1.b1] = two hi halfs, [w0.b2 w0.b3 w1.b2 w1.b3] = two lo halfs
-                                hw[q] = __builtin_amdgcn_perm(w8[2 * q + 1], w8[2 * q], 0x05040100u);
-                                lw[q] = __builtin_amdgcn_perm(w8[2 * q + 1], w8[2 * q], 0x07060302u);
-                            }
-                            ah[u] = __builtin_bit_cast(half8, uint4{hw[0], hw[1], hw[2], hw[3]});
-                            al[u] = __builtin_bit_cast(half8, uint4{lw[0], lw[1], lw[2], lw[3]});
+                        for (int q = 0; q < 4; ++q) {   // bytes [w0.b0 w0.b1 w1.b0 w1.b1] = two hi halfs, [w0.b2 w0.b3 w1.b2 w1.b3] = two lo halfs
+                            hw[q] = __builtin_amdgcn_perm(w8[2 * q + 1], w8[2 * q], 0x05040100u);
+                            lw[q] = __builtin_amdgcn_perm(w8[2 * q + 1], w8[2 * q], 0x07060302u);
                         }
+                        ah[u] = __builtin_bit_cast(half8, uint4{hw[0], hw[1], hw[2], hw[3]});
+                        al[u] = __builtin_bit_cast(half8, uint4{lw[0], lw[1], lw[2], lw[3]});
                     }
-#pragma unroll
-                    for (int u = 0; u < NBATCH; ++u) if (b0 + u < 5) d[b0 + u] = mfma16_16(ah[u], wsl, bias4);
-#pragma unroll
-                    for (int u = 0; u < NBATCH; ++u) if (b0 + u < 5) d[b0 + u] = mfma16_16(al[u], wsh, d[b0 + u]);
-#pragma unroll
-                    for (int u = 0; u < NBATCH; ++u) if (b0 + u < 5) d[b0 + u] = mfma16_16(ah[u], wsh, d[b0 + u]);
                 }
-            } else {
 #pragma unroll
-            for (int s = 3; s < 7; ++s)
+                for (int u = 0; u < NBATCH; ++u) if (b0 + u < 5) d[b0 + u] = mfma16_16(ah[u], wsl, bias4);
 #pragma unroll
-                for (int ip = 0; ip < 5; ++ip) Q[s - 3][ip] = lds[addr[s] + 2 * ip * CV_RS + 8 * zg];
-            __builtin_amdgcn_sched_barrier(0);
+                for (int u = 0; u < NBATCH; ++u) if (b0 + u < 5) d[b0 + u] = mfma16_16(al[u], wsh, d[b0 + u]);
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
-#pragma unroll
-                for (int ip = 0; ip < 5; ++ip) d[ip] = mfma32_16(P[s][ip], wreg[s], s == 0 ? bias4 : d[ip]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (zg + 1 < 5) {
-#pragma unroll
-                for (int s = 0; s < 3; ++s)
-#pragma unroll
-                    for (int ip = 0; ip < 5; ++ip) P[s][ip] = lds[addr[s] + 2 * ip * CV_RS + 8 * (zg + 1)];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 3; s < 7; ++s)
-#pragma unroll
-                for (int ip = 0; ip < 5; ++ip) d[ip] = mfma32_16(Q[s - 3][ip], wreg[s], d[ip]);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int u = 0; u < NBATCH; ++u) if (b0 + u < 5) d[b0 + u] = mfma16_16(ah[u], wsh, d[b0 + u]);
             }
             f32x4v part_y = zero4;            // per r: sum over the 5 iy-pairs of this group
 #pragma unroll
             for (int ip = 0; ip < 5; ++ip) {
                 const f32x4v v = {relu(d[ip][0]), relu(d[ip][1]), relu(d[ip][2]), relu(d[ip][3])};
                 acc_yz[ip][zg] += v;
+                // pin the accumulation here: the IR sinking pass otherwise moves it to the loop latch and keeps all 100
+                // ReLU outputs of a slice live next to the 100 accumulators (spills)
+                asm volatile("" : "+v"(acc_yz[ip][zg]));
                 sum_z[ip] += f32x2v{v[0], v[1]} + f32x2v{v[2], v[3]};
                 part_y += v;
             }
-            // plane xz [iz][ix][c], this iy-group's share: the other iy row of each tile lives in lane^32
-            float other[4];
+            xz_store(part_y, xzp + (8 * zg * RES + ix) * CD);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        xy_store(sum_z, plane_xy + ix * CD);
+    }
+    } else {
+    // ---- fp32-input MFMA path.  On gfx950 v_mfma_f32_*_f32 and ordinary VALU work share one pipe (no co-execution, not even
+    // across waves: tools/mfma_valu_overlap.hip) and every MFMA <-> VALU switch costs ~10 clocks on top (a VALU instruction
+    // between two MFMAs costs 14 clocks, in a run 4.4: tools/mfma_issue_cost.hip).  So a stage (= one iz-group) is ONE
+    // uninterrupted burst of 35 MFMAs (7 k-steps x 5 iy-pairs) carrying only the LDS reads of the A operands three k-steps
+    // ahead (rolling window, runs on into the next stage / slice: nothing is ever waited for), followed by ONE dense run of
+    // VALU work: ReLU, the three axis sums, the lane swaps and the plane stores.
+    constexpr int SLICE = CV_ROWS * CV_RS;
+    // two LDS base addresses per k-step (iy-pairs 0..2 / 3..4), kept in registers for the whole kernel and bumped once per
+    // slice: every read of the burst is base + immediate (the asm pins stop the compiler from re-deriving them inside it)
+    typedef __attribute__((address_space(3))) const float lds_cfloat;
+    const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char*)lds);
+    int a_lo[7], a_hi[7];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) other[r] = __shfl_xor(part_y[r], 32);       // four exchanges, one wait
-            if ((g >> 1) == 0) {
+    for (int s = 0; s < 7; ++s) {
+        a_lo[s] = (int)lds_base + 4 * (abase[s] + wave * SXW * SLICE);   // absolute LDS byte addresses
+        a_hi[s] = a_lo[s] + 4 * 6 * CV_RS;
+        asm volatile("" : "+v"(a_lo[s]), "+v"(a_hi[s]));
+    }
+    float A[7][5];
+    auto load_a = [&](int s, int off) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    xzp[xz_lane + ((8 * zg + r) * RES + ix) * CD] = part_y[r] + other[r];      // 32-bit offsets
+        for (int ip = 0; ip < 5; ++ip)
+            A[s][ip] = *(lds_cfloat*)((size_t)(unsigned)((ip < 3 ? a_lo[s] : a_hi[s]) + 4 * (2 * (ip < 3 ? ip : ip - 3) * CV_RS + off)));
+    };
+    load_a(0, 0); load_a(1, 0); load_a(2, 0);
+    for (int sx = 0; sx < SXW; ++sx) {
+        const int ix = x0 + wave * SXW + sx;
+        f32x2v sum_z[5];                  // per iy-pair: sum over the 5 iz-groups and the 4 in-lane iz (two partials)
+#pragma unroll
+        for (int zg = 0; zg < 5; ++zg) {
+            CI_T(3 + 6 * sx + zg);
+            f32x4v d[5];
+        #pragma unroll
+            for (int s = 0; s < 7; ++s) {
+                if (s + 3 < 7) load_a(s + 3, 8 * zg);
+                else           load_a(s - 4, zg < 4 ? 8 * (zg + 1) : 0);           // next iz-group / next slice (bases 0..2 already moved on)
+#pragma unroll
+                for (int ip = 0; ip < 5; ++ip) d[ip] = mfma32_16(A[s][ip], wreg[s], s == 0 ? bias4 : d[ip]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            f32x4v part_y;                // per r: sum over the 5 iy-pairs of this group
+#pragma unroll
+            for (int ip = 0; ip < 5; ++ip) {
+                const f32x4v v = {relu(d[ip][0]), relu(d[ip][1]), relu(d[ip][2]), relu(d[ip][3])};
+                acc_yz[ip][zg] += v;
+                asm volatile("" : "+v"(acc_yz[ip][zg]));         // keep the accumulation here (see the split path)
+                const f32x2v h = f32x2v{v[0], v[1]} + f32x2v{v[2], v[3]};
+                sum_z[ip] = zg == 0 ? h : sum_z[ip] + h;
+                part_y = ip == 0 ? v : part_y + v;
+            }
+            xz_store(part_y, xzp + (8 * zg * RES + ix) * CD);
+            if (zg == 3) {                // k-steps 0..2 of this slice have all been read: their bases move to the next slice
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    a_lo[s] += 4 * SLICE; a_hi[s] += 4 * SLICE;
+                    asm volatile("" : "+v"(a_lo[s]), "+v"(a_hi[s]));
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // plane xy [iy][ix][c]: other half of the 8 iz of each tile lives in lane^16
+        xy_store(sum_z, plane_xy + ix * CD);
 #pragma unroll
-        for (int ip = 0; ip < 5; ++ip) {
-            const float sl = sum_z[ip][0] + sum_z[ip][1];
-            const float sm = sl + __shfl_xor(sl, 16);
-            if ((g & 1) == 0) {
-                const int iy = grp * 10 + 2 * ip + (g >> 1);
-                plane_xy[(iy * RES + ix) * CD + ch] = (TOut)(sm * inv);
-            }
+        for (int s = 3; s < 7; ++s) {
+            a_lo[s] += 4 * SLICE; a_hi[s] += 4 * SLICE;
+            asm volatile("" : "+v"(a_lo[s]), "+v"(a_hi[s]));
         }
     }
-    // ---- plane yz: fixed-order sum of the 8 waves (each holds the sum over its own slices), 10 units per round ----
+    }
+    // ---- plane yz: fixed-order sum of the NW waves (each holds the sum over its own slices), UR units per round ----
     f32x4v* slot = reinterpret_cast<f32x4v*>(lds);                     // [wave][unit of the round][lane]
+    CI_T(40);
     float* yzp = yz_partial + ((size_t)xp * B + b) * img_stride;
+    constexpr int UR = ci_red_units(NW), NRD = (25 + UR - 1) / UR;
 #pragma unroll
-    for (int rd = 0; rd < 3; ++rd) {
-        constexpr int U0[3] = {0, 10, 20}, UN[3] = {10, 10, 5};
+    for (int rd = 0; rd < NRD; ++rd) {
+        const int u0 = rd * UR, un = 25 - u0 < UR ? 25 - u0 : UR;
         __syncthreads();                                               // (round 0: every wave is done with the sub-volume)
 #pragma unroll
-        for (int ul = 0; ul < UN[rd]; ++ul)
-            slot[(wave * 10 + ul) * 64 + lane] = acc_yz[(U0[rd] + ul) / 5][(U0[rd] + ul) % 5];
+        for (int ul = 0; ul < UR; ++ul)
+            if (ul < un) slot[(wave * UR + ul) * 64 + lane] = acc_yz[(u0 + ul) / 5][(u0 + ul) % 5];
         __syncthreads();
-        for (int e = tid; e < UN[rd] * 64; e += 512) {
+        for (int e = tid; e < un * 64; e += NT) {
             const int ul = e >> 6, ln = e & 63;
             f32x4v sum = slot[ul * 64 + ln];
 #pragma unroll
-            for (int w = 1; w < 8; ++w) sum += slot[(w * 10 + ul) * 64 + ln];
-            const int u = U0[rd] + ul, ip = u / 5, zg = u % 5, lg = ln >> 4, lj = ln & 15;
+            for (int w = 1; w < NW; ++w) sum += slot[(w * UR + ul) * 64 + ln];
+            const int u = u0 + ul, ip = u / 5, zg = u % 5, lg = ln >> 4, lj = ln & 15;
             const int iy = grp * 10 + 2 * ip + (lg >> 1), iz0 = 8 * zg + 4 * (lg & 1);
             const int di = (iz0 * RES + iy) * CD + 16 * chh + lj;
-            if constexpr (SXW == 5) {                          // one x-part: this IS the plane (mean over all 40 ix)
+            if constexpr (XW == RES) {                         // one x-part: this IS the plane (mean over all 40 ix)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) plane_yz[di + r * RES * CD] = (TOut)(sum[r] * inv);
             } else {
@@ -266,7 +344,9 @@ __global__ __launch_bounds__(512) void convin_project_kernel(
                 for (int r = 0; r < 4; ++r) yzp[di + r * RES * CD] = sum[r];
             }
         }
+        CI_T(41 + rd);
     }
+    CI_T(63);
 }
 
 // planes xz = (sum of the 4 iy-group partials) / 40, yz = (sum of the NXP x-part partials) / 40
@@ -458,16 +538,19 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     const float* cw = reinterpret_cast<const float*>(blob + (SPLIT ? ko.convin_ws : ko.convin_w));
     const float* cb = reinterpret_cast<const float*>(blob + ko.convin_b);
     pre();
+    // 8 waves x 5 slices.  (4 waves x 10 slices -- one wave per SIMD, half the yz partials -- measured slower for the fp32
+    // path, 50.5 vs 47.3 us at 32 scenes: the second wave of a SIMD hides the slice-boundary and LDS-issue bubbles.)
+    constexpr int NW = 8;
     if (nxp == 1) {
-        auto kern = convin_project_kernel<T, 5, SPLIT>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)ci_lds_bytes(5));
-        hipLaunchKernelGGL(kern, dim3(1, 8, B), dim3(512), ci_lds_bytes(5), s, tsdf, cw, cb, P0, XZP, YZP, B);
+        auto kern = convin_project_kernel<T, RES / NW, SPLIT, NW>;
+        constexpr size_t lds = ci_lds_bytes(RES, NW);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(8 * B), dim3(NW * 64), lds, s, tsdf, cw, cb, P0, XZP, YZP, B);
     } else {
-        auto kern = convin_project_kernel<T, 1, SPLIT>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)ci_lds_bytes(1));
-        hipLaunchKernelGGL(kern, dim3(5, 8, B), dim3(512), ci_lds_bytes(1), s, tsdf, cw, cb, P0, XZP, YZP, B);
+        auto kern = convin_project_kernel<T, 8 / NW, SPLIT, NW>;
+        constexpr size_t lds = ci_lds_bytes(8, NW);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(5, 8, B), dim3(NW * 64), lds, s, tsdf, cw, cb, P0, XZP, YZP, B);
     }
     post();
     {
@@ -562,6 +645,9 @@ int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, fl
 
 #ifdef GIGA_TRACE
 // diagnostic build only: select the traced U-Net layer (host_out == nullptr) or read the timeline back
+extern "C" int giga_debug_convin_trace(long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(giga::g_ci_trace), sizeof(long long) * 8 * 64) == hipSuccess ? 0 : -10;
+}
 extern "C" int giga_debug_conv_trace(int layer, long long* host_out) {
     if (!host_out) return hipMemcpyToSymbol(HIP_SYMBOL(giga::g_conv_trace_layer), &layer, sizeof(int)) == hipSuccess ? 0 : -10;
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(giga::g_conv_trace), sizeof(long long) * giga::CONV_NW * 64) == hipSuccess ? 0 : -10;
