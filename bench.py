@@ -57,13 +57,15 @@ STAGE_NAMES = ["convin_project", "plane_finalize"] + [
     "unet.down0.conv1", "unet.down0.conv2+pool", "unet.down1.conv1", "unet.down1.conv2+pool", "unet.down2.conv1",
     "unet.down2.conv2", "unet.up0.upconv", "unet.up0.conv1", "unet.up0.conv2", "unet.up1.upconv",
     "unet.up1.conv1", "unet.up1.conv2", "unet.conv_final"]
-HEADLINE_STAGE = 0                      # convin_project: the kernel VERDICT r01 names; see pick_headline()
+HEADLINE_STAGE = 9                      # unet.up0.conv1: the layer with the most FLOPs (5.66 GFLOP at 32 scenes) and, since the
+                                        # round-2 conv_in rewrite, the longest launch of the step; see pick_headline()
+NAMED_STAGE = 0                         # convin_project: the kernel VERDICT r01 names; reported beside it (roofline.r01_kernel)
 
 
 # kernel-name fragments (rocprofv3 names) of the stages whose HBM traffic bench.py quotes from the committed PMC tables
-TRAFFIC_KERNEL = {"convin_project": "convin_project_kernel<float, 5, false>",
-                  "unet.up0.conv1": "conv16_kernel<float, 0, 64, 64, 64, 20, 20, 1, false, true, false>",
-                  "unet.up1.conv1": "conv16_kernel<float, 0, 32, 32, 32, 40, 40, 2, false, true, false>"}
+TRAFFIC_KERNEL = {"convin_project": "convin_project_kernel<float, 5, false",
+                  "unet.up0.conv1": "conv16_kernel<float, 0, 64, 64, 64, 20, 20, 1, false, true, 0>",
+                  "unet.up1.conv1": "conv16_kernel<float, 0, 32, 32, 32, 40, 40, 2, false, true, 0>"}
 
 
 def traffic_lookup(workload, fragment):
@@ -94,8 +96,9 @@ def stage_flops(stage, B):
 
 
 def pick_headline(stage_ms):
-    """Deterministic choice of the roofline kernel: the conv_in + projection kernel unless another stage takes more than
-    1.15x its time (two stages used to sit within 1 us of each other and the argmax flipped between runs)."""
+    """Deterministic choice of the roofline kernel = the dominant (longest) launch of the step: unet.up0.conv1, the layer
+    with the most FLOPs, unless another stage takes more than 1.15x its time (a plain argmax flips between runs when two
+    stages sit within a microsecond of each other, as up0.conv1 and up1.conv1 do)."""
     top = int(np.argmax(stage_ms))
     return HEADLINE_STAGE if stage_ms[HEADLINE_STAGE] * 1.15 >= stage_ms[top] else top
 
@@ -221,14 +224,16 @@ def main():
     t0 = time.perf_counter()
     for i in range(K):
         marks[i].record()
-        step(probe=(dom, evs[i][0], evs[i][1]))
+        # even steps bracket the dominant kernel, odd steps the kernel VERDICT r01 names (conv_in + projection)
+        step(probe=(dom if i % 2 == 0 else NAMED_STAGE, evs[i][0], evs[i][1]))
     marks[K].record()
     barrier()
     elapsed_s = time.perf_counter() - t0
-    dom_ms = []
-    for a, b in evs:
-        dom_ms.append(elapsed(a, b))
+    dom_ms, named_ms = [], []
+    for i, (a, b) in enumerate(evs):
+        (dom_ms if i % 2 == 0 else named_ms).append(elapsed(a, b))
         L.giga_event_destroy(a); L.giga_event_destroy(b)
+    named_ms = named_ms or dom_ms
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(K)]
     t_elapsed = torch.tensor([elapsed_s], dtype=torch.float64, device=dev)
     rccl = None
@@ -264,7 +269,7 @@ def main():
 
     # The contract line is assembled BEFORE the multi-GPU extras run, and a watchdog prints it if they hang: a collective
     # that one rank never enters (an exception elsewhere, a wedged RCCL ring) must not cost the scaling run its numbers.
-    out = core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, dec_occ_ms, dom, dom_ms, step_ms) if rank == 0 else None
+    out = core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, dec_occ_ms, dom, dom_ms, step_ms, named_ms) if rank == 0 else None
     extra = dict(multi)
     if dist is not None and not args.no_extra:
         import threading
@@ -326,7 +331,7 @@ def main():
     finish()
 
 
-def core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, dec_occ_ms, dom, dom_ms, step_ms):
+def core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, dec_occ_ms, dom, dom_ms, step_ms, named_ms):
     """The contract keys + roofline of the timed region (rank 0)."""
     # HBM bytes per launch: PMC counters cannot be collected from inside this process, so they come from the committed
     # rocprofv3 PMC table of the same workload (tools/gpu_traffic.sh -> profiles/*traffic_c2.json), stamped with the commit
@@ -334,6 +339,9 @@ def core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, d
     traffic, traffic_src = traffic_lookup("c2", TRAFFIC_KERNEL.get(STAGE_NAMES[dom])) if B == 32 else (None, None)
     dom_avg_ms = float(np.mean(dom_ms))
     dom_flops = stage_flops(dom, B)
+    named_avg_ms, named_flops = float(np.mean(named_ms)), stage_flops(NAMED_STAGE, B)
+    named_traffic, named_src = traffic_lookup("c2", TRAFFIC_KERNEL.get(STAGE_NAMES[NAMED_STAGE])) if B == 32 else (None, None)
+    named_ach = named_flops / (named_avg_ms * 1e-3) / 1e12
     achieved = dom_flops / (dom_avg_ms * 1e-3) / 1e12
     flop_scene = FLOP_ENCODER + FLOP_GRASP3 * 1 + FLOP_HEAD["tsdf"] * M
     points_per_scene = 1 * 3 + M          # head evaluations per scene
@@ -372,8 +380,13 @@ def core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, d
             "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
             "frac_of_measured_peak": achieved / MEASURED_F32_MATRIX_TFLOPS,
             "avg_launch_ms": dom_avg_ms, "median_launch_ms": float(np.median(dom_ms)), "flops_per_launch": dom_flops,
-            "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) peak; events on the launch stream inside the timed steps; "
-                    "kernel = conv_in + projection unless another stage exceeds 1.15x its time (pick_headline)",
+            "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) peak; events on the launch stream inside the timed steps (even steps); "
+                    "kernel = the longest launch of the step: unet.up0.conv1 unless another stage exceeds 1.15x its time (pick_headline)",
+            # the kernel VERDICT r01 named (roofline_frac 0.46 then), measured the same way on the odd steps
+            "r01_kernel": {"kernel": STAGE_NAMES[NAMED_STAGE], "achieved": named_ach, "frac": named_ach / PEAK_F32_MATRIX_TFLOPS,
+                           "frac_of_measured_peak": named_ach / MEASURED_F32_MATRIX_TFLOPS, "avg_launch_ms": named_avg_ms,
+                           "median_launch_ms": float(np.median(named_ms)), "flops_per_launch": named_flops,
+                           "traffic": named_traffic, "traffic_source": named_src},
             "stages": stages,
         },
         "stage_note": "unet.conv_final is not launched in this call: the 1x1 convolution is folded into the heads' fc_c weights "
@@ -519,7 +532,7 @@ def bench_c2_mode(net, x, pos, pos_occ, prec, steps=30):
         el, per = _time_steps(lambda: net(x, pos, p_tsdf=pos_occ), steps, 5)
     net.set_precision("fp32")
     B = x.shape[0]
-    return {"workload": f"c2 in mode {prec}: fp32 encoder + f16x3 split-operand decoders (fp32-grade results)",
+    return {"workload": f"c2 in mode {prec}: f16x3 split-operand encoder and decoders (fp32-grade results, <= 6e-6 vs the oracle)",
             "ms_per_step": el * 1e3, "step_ms_median": float(np.median(per)), "scenes_per_sec": B / el}
 
 

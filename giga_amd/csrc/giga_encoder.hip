@@ -33,15 +33,17 @@ namespace giga {
 // Plane pixel (H,W) conventions (common.py:246-251,303-318): xz -> [iz][ix], xy -> [iy][ix], yz -> [iz][iy].
 // ====================================================================================================
 
-constexpr int CV_RS = 44;                         // floats per (ix, iy) row of the staged sub-volume: iz + 1 in [0, 41]
+constexpr int CV_RS = 44;                         // floats per (ix, iy) row of the staged sub-volume
+constexpr int CV_OFF = 3;                         // iz = -1 sits at float CV_OFF of its row, iz = 40 at float 44 = float 0 of the next row
 constexpr int CV_ROWS = 12;                       // the group's 10 iy rows + halo
 constexpr int ci_red_units(int nw) { return nw == 4 ? 25 : 13; }   // yz reduction: units per round (8 waves: 13 + 12, 104 KiB; 4 waves: all 25)
 constexpr size_t ci_lds_bytes(int xw, int nw) {
-    const size_t stage = (size_t)(xw + 3) * CV_ROWS * CV_RS * sizeof(float);   // + one slab: the A-operand prefetch runs one slice ahead
+    const size_t stage = ((size_t)(xw + 3) * CV_ROWS * CV_RS + 4) * sizeof(float);   // + one slab: the A-operand prefetch runs one slice ahead
     const size_t red = (size_t)nw * ci_red_units(nw) * 64 * 16;                // NW waves x UR units x 64 lanes x 16 B
     return stage > red ? stage : red;
 }
 
+// LO = false (plain f16 mode): only the hi x hi product, i.e. f16 operands / fp32 accumulate, one MFMA per unit.
 // SPLIT: f16x3 split-operand arithmetic for the 27-tap contraction.  The sub-volume is staged as one 32-bit word per voxel
 // holding the pair (hi = f16(v), lo = f16(v - hi)); the 27 taps (+5 zero weights) are ONE K = 32 step, i.e. three
 // v_mfma_f32_16x16x32_f16 per unit (W_lo*x_hi + W_hi*x_lo + W_hi*x_hi, bias in the C operand) instead of seven
@@ -53,7 +55,7 @@ static __device__ long long g_ci_trace[8 * 64];
 #else
 #define CI_T(idx) do {} while (0)
 #endif
-template <typename TOut, int SXW, bool SPLIT = false, int NW = 8>
+template <typename TOut, int SXW, bool SPLIT = false, int NW = 8, bool LO = true>
 __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for NW = 4: a 256-thread bound makes the compiler put the MFMA results into AGPRs and copy them out for the epilogue)
     const float* __restrict__ tsdf,        // [B][40][40][40]
     const float* __restrict__ wpk,         // [2][7][64] packed B operands (SPLIT: [2][hi|lo][64] x 8 halfs)
@@ -82,44 +84,23 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
     CI_T(0);
 
     // ---- stage the haloed sub-volume: rows (xl, yl) of 40 iz values + the two iz halo cells; outside = 0 ----
-    // All global loads of a thread are issued before the first LDS write (one memory latency, not one per item).
-    constexpr int NITEM = (XW + 2) * CV_ROWS * 10, NIT = (NITEM + NT - 1) / NT;
-    constexpr int NBT = 10;                                  // loads in flight per thread and batch
+    // The 12 rows of one ix slab are 120 consecutive float4 in memory.  A thread keeps ONE (row, float4) position of a slab
+    // for the whole kernel and walks the slabs (NT / 120 per pass), so an item costs two adds, not four divisions; all global
+    // loads are in flight before the first LDS write, and the setup arithmetic below runs under their latency.
+    constexpr int SPP = NT / 120, NPASS = (XW + 2 + SPP - 1) / SPP;          // slabs per pass, passes
+    const int st_slab = tid / 120, st_e = tid - 120 * st_slab, st_yl = st_e / 10, st_q = st_e - 10 * st_yl;
+    const int st_iy = 10 * grp - 1 + st_yl;
+    const bool st_on = st_slab < SPP && st_iy >= 0 && st_iy < RES;
+    const float* st_src = vol + ((size_t)(x0 - 1 + st_slab) * RES + st_iy) * RES + 4 * st_q;
+    float4 vals[NPASS];
 #pragma unroll
-    for (int it0 = 0; it0 < NIT; it0 += NBT) {
-        float4 vals[NBT];
-#pragma unroll
-        for (int it = 0; it < NBT; ++it) {
-            const int v = tid + NT * (it0 + it);
-            const int q = v % 10, row = v / 10, yl = row % CV_ROWS, xl = row / CV_ROWS;
-            const int ix = x0 - 1 + xl, iy = 10 * grp - 1 + yl;
-            vals[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (it0 + it < NIT && v < NITEM && ix >= 0 && ix < RES && iy >= 0 && iy < RES)
-                vals[it] = *reinterpret_cast<const float4*>(vol + ((size_t)ix * RES + iy) * RES + 4 * q);
-        }
-#pragma unroll
-        for (int it = 0; it < NBT; ++it) {
-            const int v = tid + NT * (it0 + it);
-            if (it0 + it >= NIT || v >= NITEM) break;
-            const int q = v % 10, row = v / 10;
-            const float4 val = vals[it];
-            float* dst = lds + row * CV_RS + 1 + 4 * q;
-            if constexpr (SPLIT) {                     // word = hi | lo << 16
-                const float v4[4] = {val.x, val.y, val.z, val.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const half_t h = (half_t)v4[e];
-                    const half_t l = (half_t)__builtin_fmaf((float)h, -1.0f, v4[e]);
-                    const unsigned w = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
-                    dst[e] = __builtin_bit_cast(float, w);
-                }
-            } else {
-                dst[0] = val.x; dst[1] = val.y; dst[2] = val.z; dst[3] = val.w;
-            }
-            if (q == 0) dst[-1] = 0.f;
-            if (q == 9) dst[4] = 0.f;
-        }
+    for (int p = 0; p < NPASS; ++p) {
+        const int xl = st_slab + SPP * p, ix = x0 - 1 + xl;
+        vals[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (st_on && xl < XW + 2 && ix >= 0 && ix < RES)
+            vals[p] = *reinterpret_cast<const float4*>(st_src + (size_t)SPP * p * RES * RES);
     }
+    CI_T(50);
     float wreg[7];
     half8 wsh = {0, 0, 0, 0, 0, 0, 0, 0}, wsl = wsh;
     if constexpr (SPLIT) {
@@ -139,7 +120,7 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
     for (int s = 0; s < 7; ++s) {
         int t = 4 * s + g;
         t = t > 26 ? 26 : t;
-        abase[s] = ((t / 9) * CV_ROWS + (j >> 3) + (t / 3) % 3) * CV_RS + 4 * ((j >> 2) & 1) + (j & 3) + t % 3;
+        abase[s] = ((t / 9) * CV_ROWS + (j >> 3) + (t / 3) % 3) * CV_RS + CV_OFF + 4 * ((j >> 2) & 1) + (j & 3) + t % 3;
     }
     // SPLIT: k-slot g of the single K = 32 step supplies taps 8g .. 8g+7 (taps > 26 have zero weight and read tap 26's voxel)
     int sbase[8];
@@ -147,7 +128,7 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
     for (int e = 0; e < 8; ++e) {
         int t = 8 * g + e;
         t = t > 26 ? 26 : t;
-        sbase[e] = ((t / 9) * CV_ROWS + (j >> 3) + (t / 3) % 3) * CV_RS + 4 * ((j >> 2) & 1) + (j & 3) + t % 3;
+        sbase[e] = ((t / 9) * CV_ROWS + (j >> 3) + (t / 3) % 3) * CV_RS + CV_OFF + 4 * ((j >> 2) & 1) + (j & 3) + t % 3;
     }
     f32x4v acc_yz[5][5];
 #pragma unroll
@@ -186,6 +167,30 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
             }
         }
     };
+    // ---- the staged values go to LDS: row = 44 floats, iz = -1 at float 3 (so the 40 values start 16-byte aligned: one
+    // ds_write_b128 per item), iz = 40 at float 44 = the unused float 0 of the next row ----
+    if (st_slab < SPP) {
+        float* st_dst = lds + (st_slab * CV_ROWS + st_yl) * CV_RS + CV_OFF + 1 + 4 * st_q;
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            if (st_slab + SPP * p >= XW + 2) break;
+            float* dst = st_dst + SPP * p * CV_ROWS * CV_RS;
+            float4 val = vals[p];
+            if constexpr (SPLIT) {                     // word = hi | lo << 16
+                float* v4 = reinterpret_cast<float*>(&val);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const half_t h = (half_t)v4[e];
+                    const half_t l = (half_t)__builtin_fmaf((float)h, -1.0f, v4[e]);
+                    const unsigned w = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+                    v4[e] = __builtin_bit_cast(float, w);
+                }
+            }
+            *reinterpret_cast<float4*>(dst) = val;
+            if (st_q == 0) dst[-1] = 0.f;
+            if (st_q == 9) dst[4] = 0.f;
+        }
+    }
     CI_T(1);
     __syncthreads();
     CI_T(2);
@@ -213,20 +218,20 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
                         unsigned w8[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) w8[e] = ldw[sbase[e] + ixl * CV_ROWS * CV_RS + 2 * ip * CV_RS + 8 * zg];
-                        unsigned hw[4], lw[4];
+                        unsigned hw[4], lw[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {   // bytes [w0.b0 w0.b1 w1.b0 w1.b1] = two hi halfs, [w0.b2 w0.b3 w1.b2 w1.b3] = two lo halfs
                             hw[q] = __builtin_amdgcn_perm(w8[2 * q + 1], w8[2 * q], 0x05040100u);
-                            lw[q] = __builtin_amdgcn_perm(w8[2 * q + 1], w8[2 * q], 0x07060302u);
+                            if constexpr (LO) lw[q] = __builtin_amdgcn_perm(w8[2 * q + 1], w8[2 * q], 0x07060302u);
                         }
                         ah[u] = __builtin_bit_cast(half8, uint4{hw[0], hw[1], hw[2], hw[3]});
                         al[u] = __builtin_bit_cast(half8, uint4{lw[0], lw[1], lw[2], lw[3]});
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < NBATCH; ++u) if (b0 + u < 5) d[b0 + u] = mfma16_16(ah[u], wsl, bias4);
+                for (int u = 0; u < NBATCH; ++u) if (b0 + u < 5) d[b0 + u] = LO ? mfma16_16(ah[u], wsl, bias4) : bias4;
 #pragma unroll
-                for (int u = 0; u < NBATCH; ++u) if (b0 + u < 5) d[b0 + u] = mfma16_16(al[u], wsh, d[b0 + u]);
+                for (int u = 0; u < NBATCH; ++u) if (LO && b0 + u < 5) d[b0 + u] = mfma16_16(al[u], wsh, d[b0 + u]);
 #pragma unroll
                 for (int u = 0; u < NBATCH; ++u) if (b0 + u < 5) d[b0 + u] = mfma16_16(ah[u], wsh, d[b0 + u]);
             }
@@ -535,19 +540,21 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     float* XZP = reinterpret_cast<float*>(ws + w.YZ);
     float* YZP = XZP + 4 * per;
     const int nxp = enc_nxp(B);
-    const float* cw = reinterpret_cast<const float*>(blob + (SPLIT ? ko.convin_ws : ko.convin_w));
+    constexpr bool CI_F16 = SPLIT || sizeof(T) == 2;        // conv_in on the f16 MFMA: split mode (hi/lo) and plain f16 (hi only)
+    constexpr bool CI_LO = SPLIT;
+    const float* cw = reinterpret_cast<const float*>(blob + (CI_F16 ? ko.convin_ws : ko.convin_w));
     const float* cb = reinterpret_cast<const float*>(blob + ko.convin_b);
     pre();
     // 8 waves x 5 slices.  (4 waves x 10 slices -- one wave per SIMD, half the yz partials -- measured slower for the fp32
     // path, 50.5 vs 47.3 us at 32 scenes: the second wave of a SIMD hides the slice-boundary and LDS-issue bubbles.)
     constexpr int NW = 8;
     if (nxp == 1) {
-        auto kern = convin_project_kernel<T, RES / NW, SPLIT, NW>;
+        auto kern = convin_project_kernel<T, RES / NW, CI_F16, NW, CI_LO>;
         constexpr size_t lds = ci_lds_bytes(RES, NW);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(8 * B), dim3(NW * 64), lds, s, tsdf, cw, cb, P0, XZP, YZP, B);
     } else {
-        auto kern = convin_project_kernel<T, 8 / NW, SPLIT, NW>;
+        auto kern = convin_project_kernel<T, 8 / NW, CI_F16, NW, CI_LO>;
         constexpr size_t lds = ci_lds_bytes(8, NW);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(5, 8, B), dim3(NW * 64), lds, s, tsdf, cw, cb, P0, XZP, YZP, B);

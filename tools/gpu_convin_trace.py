@@ -19,7 +19,7 @@ torch.cuda.synchronize()
 buf = np.zeros((8, 64), np.int64)
 dbg(buf.ctypes.data_as(ctypes.c_void_p))
 t0 = buf[:, 0][buf[:, 0] > 0].min()
-names = {0: "entry", 1: "staged", 2: "barrier", 40: "loop end", 41: "red0", 42: "red1", 43: "red2", 63: "exit"}
+names = {50: "loads out", 0: "entry", 1: "staged", 2: "barrier", 40: "loop end", 41: "red0", 42: "red1", 43: "red2", 63: "exit"}
 for sx in range(5):
     for zg in range(5):
         names[3 + 6 * sx + zg] = f"s{sx} zg{zg}"

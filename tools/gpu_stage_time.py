@@ -16,7 +16,7 @@ BS = [int(b) for b in os.environ.get("GIGA_DIAG_B", "8,16,32,64,128,256").split(
 dev = torch.device("cuda:0")
 net = networks.get_network("giga")
 net.load_state_dict(weights.make_state_dict(7))
-net = net.to(dev).eval().set_precision("fp32")
+net = net.to(dev).eval().set_precision(os.environ.get("GIGA_DIAG_PREC", "fp32"))
 L = _capi.lib()
 ev = (L.giga_event_create(), L.giga_event_create())
 ms = ctypes.c_float()
