@@ -310,6 +310,12 @@ constexpr int DEC16S_CHUNKS = (int)(DEC16S_BYTES / FRAG);    // 111
 
 // SPLIT = false runs the same head-resident structure with single f16 operands (the plain f16 image of 59 KiB, f16 planes):
 // it serves small launches of the fp16 mode, where decoder_f16_kernel's shared-feature rounds leave most CUs idle.
+#ifdef GIGA_TRACE   // diagnostic build: issue timeline (s_memtime) of one workgroup of the head-resident decoder
+static __device__ long long g_dec_trace[16 * 16];
+#define DEC_T(idx) do { if (blockIdx.x == 100 && lane == 0 && (idx) < 16) g_dec_trace[wave * 16 + (idx)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DEC_T(idx) do {} while (0)
+#endif
 template <int T, bool LATTICE, int NW, bool SPLIT>
 __global__ __launch_bounds__(NW * 64) void decoder_f16s_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -331,7 +337,9 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16s_kernel(DecArgs a) {
         hsel = k % a.nheads;
         slot = xcd * spx + k / a.nheads;
     }
+    DEC_T(0);
     dma_head_image<NW, NCH>(a.blob + a.head_off[hsel], smem, wave, lane);
+    DEC_T(1);
 
     const long long tiles_total = (a.P + 31) / 32;
     const long long tile_lo = tiles_total * slot / slots;
@@ -465,11 +473,13 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16s_kernel(DecArgs a) {
                 }
             }
         }
+        DEC_T(2 + 3 * iter);
         if (iter == 0) {
             __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): my share of the weight image has landed
             __syncthreads();                                  // everyone's share (all waves run iteration 0)
         }
         if (!has) break;
+        DEC_T(3 + 3 * iter);
         // ---------------- the chain.  Fragment indices per block b (PR = fragments per chunk): fc_c BLK*b + PR*c, aux
         // BLK*b + 6*PR, fc_0 .. + 1 + PR*c, fc_1 .. + 1 + 2*PR + PR*c; tail aux NBLK*BLK, fc_out + 1 + PR*c
         f32x16 net[T], hh[T];
@@ -554,8 +564,18 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16s_kernel(DecArgs a) {
             for (int t = 0; t < T; ++t)
                 if (hi == 0 && valid[t]) store_head(a, hsel, gidx[t], o[t][0], o[t][1], o[t][2], o[t][3]);
         }
+        DEC_T(4 + 3 * iter);
     }
+    DEC_T(15);
 }
+
+#ifdef GIGA_TRACE
+}  // namespace giga
+extern "C" int giga_debug_dec_trace(long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(giga::g_dec_trace), sizeof(long long) * 16 * 16) == hipSuccess ? 0 : -10;
+}
+namespace giga {
+#endif
 
 // =============================== exact fp32 MFMA path ==============================================
 // Same chain on v_mfma_f32_32x32x2_f32 (bitwise an fp32 fma chain).  B operand of MFMA s of a hidden

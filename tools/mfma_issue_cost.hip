@@ -12,14 +12,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define M(d) "v_mfma_f32_16x16x4_f32 %" #d ", %4, %5, %" #d "\n"
 template <int KIND>
 __global__ __launch_bounds__(512) void k(float* out, int iters, long long* cyc) {
-    __shared__ float sm[2048];
+    __shared__ float sm[4096];
     sm[threadIdx.x] = threadIdx.x; sm[threadIdx.x + 512] = 1.f;
     __syncthreads();
     f32x4 d0 = {0, 0, 0, 0}, d1 = d0, d2 = d0, d3 = d0;
     float a = threadIdx.x * 1e-3f, b = 1.0001f;
     float v0 = a, v1 = a + 1, v2 = a + 2, v3 = a + 3;
     f32x2 p0 = {a, a}, p1 = {b, b}, p2 = p0, p3 = p1;
-    unsigned la = (threadIdx.x & 255) * 4;
+    unsigned la = (threadIdx.x & 255) * 4, la4 = (threadIdx.x & 63) * 16;
     float l0 = 0, l1 = 0, l2 = 0, l3 = 0;
     const long long t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; ++i) {
@@ -38,14 +38,15 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, long long* cyc) 
         if constexpr (KIND == 2)
             asm volatile(M(0) P1 M(1) P2 M(2) P1 M(3) P2 M(0) P1 M(1) P2 M(2) P1 M(3) P2 M(0) P1 M(1) P2 M(2) P1 M(3) P2 M(0) P1 M(1) P2 M(2) P1 M(3) P2
                          : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a), "v"(b), "v"(p0), "v"(p1), "v"(p2), "v"(p3));
-#define L1 "ds_read_b32 %6, %10\n"
-#define L2 "ds_read_b32 %7, %10 offset:1024\n"
-#define L3 "ds_read_b32 %8, %10 offset:2048\n"
-#define L4 "ds_read_b32 %9, %10 offset:3072\n"
+#define ML(d) "v_mfma_f32_16x16x4_f32 %" #d ", %8, %9, %" #d "\n"
+#define L1 "ds_read_b32 %4, %10\n"
+#define L2 "ds_read_b32 %5, %10 offset:1024\n"
+#define L3 "ds_read_b32 %6, %10 offset:2048\n"
+#define L4 "ds_read_b32 %7, %10 offset:3072\n"
         if constexpr (KIND == 3)
-            asm volatile(M(0) L1 M(1) L2 M(2) L3 M(3) L4 M(0) L1 M(1) L2 M(2) L3 M(3) L4 M(0) L1 M(1) L2 M(2) L3 M(3) L4 M(0) L1 M(1) L2 M(2) L3 M(3) L4
+            asm volatile(ML(0) L1 ML(1) L2 ML(2) L3 ML(3) L4 ML(0) L1 ML(1) L2 ML(2) L3 ML(3) L4 ML(0) L1 ML(1) L2 ML(2) L3 ML(3) L4 ML(0) L1 ML(1) L2 ML(2) L3 ML(3) L4
                          "s_waitcnt lgkmcnt(0)\n"
-                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a), "v"(b), "v"(l0), "v"(l1), "v"(l2), "v"(l3), "v"(la));
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3) : "v"(a), "v"(b), "v"(la));
 #define N "s_nop 0\n"
         if constexpr (KIND == 4)
             asm volatile(M(0) N M(1) N M(2) N M(3) N M(0) N M(1) N M(2) N M(3) N M(0) N M(1) N M(2) N M(3) N M(0) N M(1) N M(2) N M(3) N
@@ -59,6 +60,23 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, long long* cyc) 
             asm volatile(M(0) X1 X2 X3 X4 M(1) X1 X2 X3 X4 M(2) X1 X2 X3 X4 M(3) X1 X2 X3 X4 M(0) X1 X2 X3 X4 M(1) X1 X2 X3 X4 M(2) X1 X2 X3 X4 M(3) X1 X2 X3 X4
                          M(0) X1 X2 X3 X4 M(1) X1 X2 X3 X4 M(2) X1 X2 X3 X4 M(3) X1 X2 X3 X4 M(0) X1 X2 X3 X4 M(1) X1 X2 X3 X4 M(2) X1 X2 X3 X4 M(3) X1 X2 X3 X4
                          : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a), "v"(b), "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+#define MQ(d) "v_mfma_f32_16x16x4_f32 %" #d ", %6, %7, %" #d "\n"
+#define Q1 "ds_read_b128 %4, %8\n"
+#define Q2 "ds_read_b128 %5, %8 offset:4096\n"
+        if constexpr (KIND == 8) {  // one 1-KiB LDS read per MFMA
+            f32x4 q0, q1;
+            asm volatile(MQ(0) Q1 MQ(1) Q2 MQ(2) Q1 MQ(3) Q2 MQ(0) Q1 MQ(1) Q2 MQ(2) Q1 MQ(3) Q2 MQ(0) Q1 MQ(1) Q2 MQ(2) Q1 MQ(3) Q2 MQ(0) Q1 MQ(1) Q2 MQ(2) Q1 MQ(3) Q2
+                         "s_waitcnt lgkmcnt(0)\n"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "=&v"(q0), "=&v"(q1) : "v"(a), "v"(b), "v"(la4));
+            l0 += q0[0] + q1[0];
+        }
+        if constexpr (KIND == 9) {  // three 1-KiB LDS reads per 8 MFMAs (the conv16 fp32 ratio, NB = 2)
+            f32x4 q0, q1;
+            asm volatile(MQ(0) Q1 MQ(1) Q2 MQ(2) Q1 MQ(3) MQ(0) MQ(1) MQ(2) MQ(3) MQ(0) Q1 MQ(1) Q2 MQ(2) Q1 MQ(3) MQ(0) MQ(1) MQ(2) MQ(3)
+                         "s_waitcnt lgkmcnt(0)\n"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "=&v"(q0), "=&v"(q1) : "v"(a), "v"(b), "v"(la4));
+            l0 += q0[0] + q1[0];
+        }
         if constexpr (KIND == 7)   // VALU only: 64 adds
             asm volatile(X1 X2 X3 X4 X1 X2 X3 X4 X1 X2 X3 X4 X1 X2 X3 X4 X1 X2 X3 X4 X1 X2 X3 X4 X1 X2 X3 X4 X1 X2 X3 X4
                          X1 X2 X3 X4 X1 X2 X3 X4 X1 X2 X3 X4 X1 X2 X3 X4 X1 X2 X3 X4 X1 X2 X3 X4 X1 X2 X3 X4 X1 X2 X3 X4
@@ -100,5 +118,7 @@ int main(int argc, char** argv) {
     if (only < 0 || only == 5) run<5>("+ s_add_u32 per MFMA", out, cyc, 16);
     if (only < 0 || only == 6) run<6>("+ 4 v_add_f32 per MFMA", out, cyc, 64);
     if (only < 0 || only == 7) run<7>("64 v_add_f32 only", out, cyc, 64);
+    if (only < 0 || only == 8) run<8>("+ ds_read_b128 per MFMA", out, cyc, 16);
+    if (only < 0 || only == 9) run<9>("+ 3 ds_read_b128 per 8 MFMA", out, cyc, 6);
     return 0;
 }
