@@ -30,6 +30,8 @@ struct ConvArgs {
     void* out;                           // NHWC [img][H'][W'][COUT]
     void* out_pool;                      // NHWC [img][H/2][W/2][COUT] (POOL only)
     float* out_nchw;                     // optional fp32 NCHW copy (CONV1 only)
+    const float* mask;                   // optional fp32 tensor of the output's shape: out = mask > 0 ? out : 0 (ReLU backward
+                                         // of the layer below, fused into a data-gradient convolution; not with UPCONV)
     int nimg;
     int cs0, co0, cs1, co1;              // channel stride / first channel of in0, in1 (0 stride = dense C0 / C1)
     int trace_id;                        // layer index (diagnostic builds)
@@ -341,6 +343,7 @@ __device__ __forceinline__ void conv16_run(const ConvArgs& a, uint8_t* smem, int
                             const int oy = 2 * y + (sub >> 1), ox = 2 * x + (sub & 1);
                             out[((size_t)(img * 2 * H + oy) * (2 * W) + ox) * COUT + co] = (T)v[e];
                         } else {
+                            if (a.mask && !(a.mask[((size_t)(img * H + y) * W + x) * COUT + co] > 0.f)) v[e] = 0.f;
                             out[((size_t)(img * H + y) * W + x) * COUT + co] = (T)v[e];
                             if (KIND == CONV1 && a.out_nchw)
                                 a.out_nchw[((size_t)img * COUT + co) * H * W + y * W + x] = v[e];

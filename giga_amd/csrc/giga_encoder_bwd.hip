@@ -15,18 +15,9 @@
 namespace giga {
 
 // ------------------------------- elementwise ------------------------------------------------------------
-__global__ void relu_bwd_kernel(float4* __restrict__ g, const float4* __restrict__ out, size_t n4) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    float4 v = g[i];
-    const float4 o = out[i];
-    v.x = o.x > 0.f ? v.x : 0.f; v.y = o.y > 0.f ? v.y : 0.f;
-    v.z = o.z > 0.f ? v.z : 0.f; v.w = o.w > 0.f ? v.w : 0.f;
-    g[i] = v;
-}
-
 // dS[img][y][x][c] = dCat[img][y][x][coff + c] (skip half of the concat gradient, channel stride cs)
 //                  + (S[y][x][c] == Q[y/2][x/2][c] ? dQ[y/2][x/2][c] : 0)      (MaxPool2d(2,2) backward)
+// and, S being the ReLU output of the layer below, its backward in the same pass: dS = S > 0 ? dS : 0
 __global__ void pool_bwd_add_kernel(float* __restrict__ dS, const float* __restrict__ dcat, int cs, int coff,
                                     const float* __restrict__ dQ, const float* __restrict__ S,
                                     const float* __restrict__ Q, int nimg, int H, int W, int C) {
@@ -39,7 +30,7 @@ __global__ void pool_bwd_add_kernel(float* __restrict__ dS, const float* __restr
     const size_t img = pix / ((size_t)W * H);
     const size_t qi = ((img * (H / 2) + y / 2) * (W / 2) + x / 2) * C + c;
     const float s = S[i];
-    dS[i] = dcat[pix * cs + coff + c] + (s == Q[qi] ? dQ[qi] : 0.f);
+    dS[i] = s > 0.f ? dcat[pix * cs + coff + c] + (s == Q[qi] ? dQ[qi] : 0.f) : 0.f;
 }
 
 // db[c] += sum over rows of g[row * cs + coff + c]
@@ -814,10 +805,6 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
     auto F = [&](size_t off) { return reinterpret_cast<const float*>(fws + off); };
     auto G = [&](size_t off) { return reinterpret_cast<float*>(gws + off); };
     int rc = 0;
-    auto relu_bwd = [&](float* grad, const float* out, size_t n) {
-        hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s,
-                           reinterpret_cast<float4*>(grad), reinterpret_cast<const float4*>(out), n / 4);
-    };
     auto colsum = [&](const float* grad, int cs, int coff, int C, size_t rows, int layer) {
         hipLaunchKernelGGL(colsum_kernel, dim3(256), dim3(256), 0, s, grad, cs, coff, C, rows, grads + po.conv_b[layer]);
     };
@@ -862,45 +849,42 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
         rc |= launch_wgrad(a, s);
         colsum(dcat, cs_cat, 0, d.cout, (size_t)nimg * 4 * H * H, l);
     };
-    auto dgrad_args = [&](int l, const float* in, int cs, void* out) {
+    // data gradient of layer l; relu_of: the forward activation the gradient flows into next (ReLU output of the layer
+    // below): its backward mask is applied in the convolution's epilogue instead of by a separate pass over the tensor
+    auto dgrad_args = [&](int l, const float* in, int cs, void* out, const float* relu_of = nullptr) {
         ConvArgs a{};
         a.in0 = in; a.in1 = nullptr; a.w = bwd_blob + (MATH == MATH_BF16 ? bo.convbf[l] : bo.conv[l]); a.bias = nullptr; a.out = out; a.nimg = nimg;
         a.cs0 = cs;
+        a.mask = relu_of;
         return a;
     };
     const size_t n40 = (size_t)nimg * 1600, n20 = (size_t)nimg * 400, n10 = (size_t)nimg * 100;
 
     // L12 conv_final (1x1, no activation): gplanes = dOUT
     wgrad3(12, gplanes, F(f.A6), nullptr, 40);
-    rc |= launch_conv<float, CONV1, 32, 0, 32, 40, 40, 2, false, false, MATH>(dgrad_args(12, gplanes, 0, G(g.gA6)), s);
+    rc |= launch_conv<float, CONV1, 32, 0, 32, 40, 40, 2, false, false, MATH>(dgrad_args(12, gplanes, 0, G(g.gA6), F(f.A6)), s);
     // L11 up1.conv2: A5 -> A6
-    relu_bwd(G(g.gA6), F(f.A6), n40 * 32);
     wgrad3(11, G(g.gA6), F(f.A5), nullptr, 40);
-    rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(dgrad_args(11, G(g.gA6), 0, G(g.gA5)), s);
+    rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(dgrad_args(11, G(g.gA6), 0, G(g.gA5), F(f.A5)), s);
     // L10 up1.conv1: cat(U1, S0) -> A5 ; dgrad output has 64 channels (dU1 | dS0 skip part)
-    relu_bwd(G(g.gA5), F(f.A5), n40 * 32);
     wgrad3(10, G(g.gA5), F(f.U1), F(f.S0), 40);
     rc |= launch_conv<float, CONV3, 32, 0, 64, 40, 40, 2, false, false, MATH>(dgrad_args(10, G(g.gA5), 0, G(g.gC1)), s);
     // L9 up1.upconv: A4 (20x20x64) -> U1 (40x40x32); dU1 = gC1[..., 0:32]
     wgrad_up(9, F(f.A4), G(g.gC1), 64, 20);
-    rc |= launch_conv<float, DOWN, 32, 0, 64, 20, 20, 2, false, false, MATH>(dgrad_args(9, G(g.gC1), 64, G(g.gA4)), s);
+    rc |= launch_conv<float, DOWN, 32, 0, 64, 20, 20, 2, false, false, MATH>(dgrad_args(9, G(g.gC1), 64, G(g.gA4), F(f.A4)), s);
     // L8 up0.conv2: A3 -> A4
-    relu_bwd(G(g.gA4), F(f.A4), n20 * 64);
     wgrad3(8, G(g.gA4), F(f.A3), nullptr, 20);
-    rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false, MATH>(dgrad_args(8, G(g.gA4), 0, G(g.gA3)), s);
+    rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false, MATH>(dgrad_args(8, G(g.gA4), 0, G(g.gA3), F(f.A3)), s);
     // L7 up0.conv1: cat(U0, S1) -> A3 ; dgrad output 128 channels
-    relu_bwd(G(g.gA3), F(f.A3), n20 * 64);
     wgrad3(7, G(g.gA3), F(f.U0), F(f.S1), 20);
     rc |= launch_conv<float, CONV3, 64, 0, 128, 20, 20, 1, false, false, MATH>(dgrad_args(7, G(g.gA3), 0, G(g.gC0)), s);
     // L6 up0.upconv: S2 (10x10x128) -> U0 (20x20x64); dU0 = gC0[..., 0:64]
     wgrad_up(6, F(f.S2), G(g.gC0), 128, 10);
-    rc |= launch_conv<float, DOWN, 64, 0, 128, 10, 10, 1, false, false, MATH>(dgrad_args(6, G(g.gC0), 128, G(g.gS2)), s);
+    rc |= launch_conv<float, DOWN, 64, 0, 128, 10, 10, 1, false, false, MATH>(dgrad_args(6, G(g.gC0), 128, G(g.gS2), F(f.S2)), s);
     // L5 down2.conv2: A2 -> S2
-    relu_bwd(G(g.gS2), F(f.S2), n10 * 128);
     wgrad3(5, G(g.gS2), F(f.A2), nullptr, 10);
-    rc |= launch_conv<float, CONV3, 128, 0, 128, 10, 10, 1, false, false, MATH>(dgrad_args(5, G(g.gS2), 0, G(g.gA2)), s);
+    rc |= launch_conv<float, CONV3, 128, 0, 128, 10, 10, 1, false, false, MATH>(dgrad_args(5, G(g.gS2), 0, G(g.gA2), F(f.A2)), s);
     // L4 down2.conv1: Q1 -> A2
-    relu_bwd(G(g.gA2), F(f.A2), n10 * 128);
     wgrad3(4, G(g.gA2), F(f.Q1), nullptr, 10);
     rc |= launch_conv<float, CONV3, 128, 0, 64, 10, 10, 1, false, false, MATH>(dgrad_args(4, G(g.gA2), 0, G(g.gQ1)), s);
     // pool1 + skip: dS1 = gC0[..., 64:128] + unpool(dQ1)
@@ -910,11 +894,9 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
                            G(g.gC0), 128, 64, G(g.gQ1), F(f.S1), F(f.Q1), nimg, 20, 20, 64);
     }
     // L3 down1.conv2: A1 -> S1
-    relu_bwd(G(g.gS1), F(f.S1), n20 * 64);
     wgrad3(3, G(g.gS1), F(f.A1), nullptr, 20);
-    rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false, MATH>(dgrad_args(3, G(g.gS1), 0, G(g.gA1)), s);
+    rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false, MATH>(dgrad_args(3, G(g.gS1), 0, G(g.gA1), F(f.A1)), s);
     // L2 down1.conv1: Q0 -> A1
-    relu_bwd(G(g.gA1), F(f.A1), n20 * 64);
     wgrad3(2, G(g.gA1), F(f.Q0), nullptr, 20);
     rc |= launch_conv<float, CONV3, 64, 0, 32, 20, 20, 2, false, false, MATH>(dgrad_args(2, G(g.gA1), 0, G(g.gQ0)), s);
     // pool0 + skip: dS0 = gC1[..., 32:64] + unpool(dQ0)
@@ -924,11 +906,9 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
                            G(g.gC1), 64, 32, G(g.gQ0), F(f.S0), F(f.Q0), nimg, 40, 40, 32);
     }
     // L1 down0.conv2: A0 -> S0
-    relu_bwd(G(g.gS0), F(f.S0), n40 * 32);
     wgrad3(1, G(g.gS0), F(f.A0), nullptr, 40);
-    rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(dgrad_args(1, G(g.gS0), 0, G(g.gA0)), s);
+    rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(dgrad_args(1, G(g.gS0), 0, G(g.gA0), F(f.A0)), s);
     // L0 down0.conv1: P0 -> A0
-    relu_bwd(G(g.gA0), F(f.A0), n40 * 32);
     wgrad3(0, G(g.gA0), F(f.P0), nullptr, 40);
     rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(dgrad_args(0, G(g.gA0), 0, G(g.gP0)), s);
     // conv_in + projection
