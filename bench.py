@@ -456,11 +456,15 @@ def bench_c4(net, dev, L, _capi, synth, decode_heads, prec, Bc=32, steps=10):
     for _ in range(8):                     # also absorbs the allocator's one-off work after a change of batch size
         step()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
     for i in range(steps):
+        marks[i].record()
         step(ev[i])
+    marks[steps].record()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     ms = ctypes.c_float()
     dms = []
     for a, b in ev:
@@ -487,7 +491,8 @@ def bench_c4(net, dev, L, _capi, synth, decode_heads, prec, Bc=32, steps=10):
                     + ("f16x3 split-operand f16-MFMA decoder (fp32-grade, <= 6e-6 vs oracle) + fp32 encoder" if split else
                        "f16 MFMA decoder (lattice path) + f16 encoder"),
         "scenes_per_sec": Bc * steps / el, "query_points_per_sec": Bc * steps * N / el,
-        "ms_per_step": el / steps * 1e3, "dtype": "f16x3 split operands / f32 accumulate" if split else "f16 operands / f32 accumulate",
+        "ms_per_step": el / steps * 1e3, "step_ms_median": float(np.median(per_step)), "step_ms_max": float(np.max(per_step)),
+        "dtype": "f16x3 split operands / f32 accumulate" if split else "f16 operands / f32 accumulate",
         "roofline": roof,
     }
 
