@@ -188,6 +188,28 @@ def test_ragged_and_tiny_batches(net, dev, sd7, prec):
             assert maxerr(a, b) < 2e-4, (B, N, M)
 
 
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-4), ("fp16x3", 1e-4), ("fp16", 2e-2)])
+@pytest.mark.parametrize("B", [33, 44])
+def test_batches_that_do_not_fill_groups_of_eight(net, dev, sd7, prec, tol, B):
+    """From 32 scenes up conv_in runs one workgroup group per scene and maps whole groups of 8 scenes onto the 8 XCDs; the
+    scenes beyond the last full group take the plain order.  Every scene of such a batch equals the same scene run alone
+    (the small-batch kernels), and the first / last scene equal the oracle."""
+    net.set_precision(prec)
+    x = torch.from_numpy(synth.tsdf_batch(700, B)).to(dev)
+    with torch.no_grad():
+        pl = net.encode_inputs(x)
+        for k in (0, 7, 8, 31, 32, B - 1):
+            one = net.encode_inputs(x[k:k + 1].contiguous())
+            for key in ("xz", "xy", "yz"):
+                assert maxerr(pl[key][k:k + 1], one[key].cpu()) < (1e-5 if prec != "fp16" else 1e-2), (k, key)
+    for k in (0, B - 1):
+        ref = O.encoder_forward(sd7, x[k:k + 1].cpu())
+        for key in ("xz", "xy", "yz"):
+            scale = max(1.0, float(ref[key].abs().max()))
+            assert maxerr(pl[key][k:k + 1], ref[key]) < tol * scale, (k, key)
+    net.set_precision("fp32")
+
+
 @pytest.mark.parametrize("prec", ["fp32", "fp16x3", "fp16"])
 def test_empty_and_degenerate_inputs(net, dev, prec):
     """Empty batch, zero query points, zero occupancy points, non-contiguous / float64 inputs, mismatched batch sizes."""
