@@ -68,6 +68,7 @@ _SIGNATURES = {
     "giga_train_loss_backward": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5),
     "giga_event_create": (ctypes.c_void_p, []),
     "giga_event_destroy": (None, [ctypes.c_void_p]),
+    "giga_event_record": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "giga_event_elapsed_ms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "giga_encoder_forward_probe": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                   ctypes.c_void_p, ctypes.c_int, ctypes.c_int,

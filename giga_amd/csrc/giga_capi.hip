@@ -185,6 +185,10 @@ void* giga_event_create(void) {
     return hipEventCreate(&e) == hipSuccess ? static_cast<void*>(e) : nullptr;
 }
 void giga_event_destroy(void* ev) { if (ev) (void)hipEventDestroy(static_cast<hipEvent_t>(ev)); }
+int giga_event_record(void* ev, void* stream) {
+    if (!ev) return -1;
+    return hipEventRecord(static_cast<hipEvent_t>(ev), static_cast<hipStream_t>(stream)) == hipSuccess ? 0 : -10;
+}
 int giga_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms) {
     if (!ev_start || !ev_stop || !ms) return -1;
     if (hipEventSynchronize(static_cast<hipEvent_t>(ev_stop)) != hipSuccess) return -10;

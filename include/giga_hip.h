@@ -234,6 +234,7 @@ int giga_grasp_select(const float* tsdf, const float* qual, const float* rot, co
 void* giga_event_create(void);
 void giga_event_destroy(void* ev);
 int giga_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises on ev_stop */
+int giga_event_record(void* ev, void* stream);   /* bench.py: an EMPTY bracket measures what the two records themselves cost */
 int giga_encoder_forward_probe(const float* tsdf, const void* packed, void* planes_nhwc, float* planes_nchw,
                                int B, int precision, void* workspace, size_t workspace_bytes, void* stream,
                                int probe_stage, void* ev_start, void* ev_stop);
