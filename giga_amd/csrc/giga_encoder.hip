@@ -397,7 +397,7 @@ EncWs enc_workspace(int B, int precision) {
     w.U1 = take(n * 1600 * 32, es); w.A5 = take(n * 1600 * 32, es); w.A6 = take(n * 1600 * 32, es);
     w.YZ = take((size_t)(4 + enc_nxp(B)) * B * 1600 * 32, 4);   // 4 xz partials (iy-groups) + NXP yz partials (x-parts)
     w.XZ = w.YZ;
-    w.SYNC = take(64, 4);
+    w.SYNC = take(8 * 128, 4);             // per-XCD barrier counters of the persistent U-Net kernel
     w.total = at;
     return w;
 }
@@ -433,93 +433,123 @@ EncWs enc_workspace(int B, int precision) {
     X(11, CONV3, 32, 0, 32, 40, 40, 2, false, 2)         \
     X(12, CONV1, 32, 0, 32, 40, 40, 2, false, 2)
 
-#ifdef GIGA_MEGA_EXPERIMENT   // measured slower than per-layer launches (profiles/r02e_persistent_unet_experiment.txt)
+// ----------------------------------------------------------------------------------------------------
+// The U-Net as ONE persistent launch, synchronised per XCD.
+//   Images are independent, so the 3B images are split into 8 contiguous ranges and XCD x (the 32 workgroups i with
+//   i % 8 == x: workgroup i runs on XCD i % 8) takes range x through all layers.  A layer boundary is then a barrier among
+//   the 32 workgroups of ONE XCD, and everything they exchange goes through that XCD's own L2: the producer waits for its
+//   stores (vmcnt 0: acknowledged by the L2), arrives with a workgroup-scope atomic add (performed in the L2) and spins on an
+//   L2 load; a consumer reads buffers nobody on its CU has read before in this launch, so its L1 holds no older copy.  No
+//   agent-scope release / acquire (write-back + invalidate of the whole L2, ~7 us) and no device-scope atomics (resolved
+//   outside the XCD, ~8 us for 256 arrivals): tools/xcd_barrier.hip measures 5 us per write + barrier + read round against
+//   7.7, with zero stale reads, and checks the workgroup -> XCD map against the hardware register XCC_ID.  (The device-wide
+//   version of this kernel, round 2a, lost to per-layer launches: profiles/r02e_persistent_unet_experiment.txt.)
+//   The next layer's weights stream into LDS (LDS-DMA) while the barrier is waited for.  A barrier that does not complete
+//   (fewer than 256 co-resident workgroups: never on an exclusive MI355X) traps after ~1 s instead of hanging the device.
+// ----------------------------------------------------------------------------------------------------
 struct MegaArgs {
     ConvArgs layer[NCONV];
-    unsigned* sync;            // [0] arrival counter (zeroed before the launch), [1] set if a barrier timed out
+    unsigned* sync;            // 8 arrival counters (one per XCD, 128 B apart), zeroed before the launch
     int nlayers;               // 12 (conv_final folded into the decoder) or 13
-    int dbg;                   // experiment bits (GIGA_MEGA_DBG): 1 no fences, 2 no device barrier at all, 4 no sleep in the spin
 };
 constexpr int MEGA_NW = CONV_NW;                  // waves per workgroup of the persistent kernel
 
-template <typename T, bool SPLIT>
+template <typename T, int MATH>
 constexpr size_t mega_lds_bytes() {
     size_t m = 0;
 #define X(l, KIND, C0, C1, COUT, H, W, NB, POOL, NB16) \
-    { constexpr size_t v = conv_lds_bytes<T, KIND, C0, C1, COUT, H, W, NB, SPLIT>(); m = v > m ? v : m; }
+    { constexpr size_t v = conv_lds_bytes<T, KIND, C0, C1, COUT, H, W, (sizeof(T) == 2 ? NB16 : NB), MATH>(); m = v > m ? v : m; }
     GIGA_UNET_LAYERS(X)
 #undef X
     return m;
 }
 
-__device__ __forceinline__ void grid_barrier(unsigned* sync, unsigned target, int dbg = 0) {
-    __syncthreads();                                          // the whole workgroup is done with the layer
-    if (dbg & 2) return;
+#ifdef GIGA_TRACE
+static __device__ long long g_mega_trace[8][32];          // [workgroup 0..7][2 * layer: arrival, release]
+#endif
+__device__ __forceinline__ void xcd_barrier(unsigned* counter, unsigned target, int idx) {
+#ifdef GIGA_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 64 && (blockIdx.x & 7) == 0 && idx < 16) g_mega_trace[blockIdx.x >> 3][2 * idx] = __builtin_amdgcn_s_memtime();
+#endif
     if (threadIdx.x == 0) {
-        if (!(dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");    // this XCD's L2 writes back what the layer produced
-        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // performed in this XCD's L2
         unsigned spins = 0;
-        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (!(dbg & 4)) __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 22)) {                       // seconds: never hang the device
-                __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {   // an L2 read
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24)) __builtin_trap();       // ~1 s: fail loudly, never hang the device
         }
-        if (!(dbg & 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // drop stale lines before reading the other CUs' output
     }
     __syncthreads();
+#ifdef GIGA_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 64 && (blockIdx.x & 7) == 0 && idx < 16) g_mega_trace[blockIdx.x >> 3][2 * idx + 1] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
-template <typename T, bool SPLIT>
+// the image range [img0, img0 + n) of one layer's operands
+template <typename T, int KIND, int C0, int C1, int COUT, int H, int W>
+__device__ __forceinline__ ConvArgs conv_image_range(ConvArgs a, int img0, int n) {
+    constexpr int IH = KIND == DOWN ? 2 * H : H, IW = KIND == DOWN ? 2 * W : W;
+    constexpr int OH = KIND == UPCONV ? 2 * H : H, OW = KIND == UPCONV ? 2 * W : W;
+    const size_t s0 = (size_t)IH * IW * (a.cs0 ? a.cs0 : C0), s1 = (size_t)IH * IW * (a.cs1 ? a.cs1 : C1);
+    a.in0 = reinterpret_cast<const T*>(a.in0) + img0 * s0;
+    if (a.in1) a.in1 = reinterpret_cast<const T*>(a.in1) + img0 * s1;
+    a.out = reinterpret_cast<T*>(a.out) + (size_t)img0 * OH * OW * COUT;
+    if (a.out_pool) a.out_pool = reinterpret_cast<T*>(a.out_pool) + (size_t)img0 * (H / 2) * (W / 2) * COUT;
+    if (a.out_nchw) a.out_nchw += (size_t)img0 * COUT * H * W;
+    if (a.mask) a.mask += (size_t)img0 * OH * OW * COUT;
+    a.nimg = n;
+    return a;
+}
+
+template <typename T, int MATH>
 __global__ __launch_bounds__(MEGA_NW * 64) void unet_mega_kernel(MegaArgs m) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int block = (int)blockIdx.x, nblocks = (int)gridDim.x;
+    const int xcd = (int)blockIdx.x & 7, block = (int)blockIdx.x >> 3, nblocks = (int)gridDim.x >> 3;
+    const int per = m.layer[0].nimg >> 3, img0 = xcd * per;                 // (the host guarantees nimg % 8 == 0)
+    unsigned* counter = m.sync + xcd * 32;
     unsigned epoch = 0;
-#define X(l, KIND, C0, C1, COUT, H, W, NB, POOL)                                                                        \
-    if (l < m.nlayers) {                                                                                                \
-        if (l == 0) conv16_fill<T, KIND, C0, C1, COUT, NB, SPLIT>(m.layer[l], smem, block);                             \
-        conv16_run<T, KIND, C0, C1, COUT, H, W, NB, POOL, KIND == CONV3, SPLIT>(m.layer[l], smem, block, nblocks);      \
+#define X(l, KIND, C0, C1, COUT, H, W, NB, POOL, NB16)                                                                     \
+    if (l < m.nlayers) {                                                                                                   \
+        const ConvArgs a = conv_image_range<T, KIND, C0, C1, COUT, H, W>(m.layer[l], img0, per);                           \
+        if (l == 0) conv16_fill<T, KIND, C0, C1, COUT, (sizeof(T) == 2 ? NB16 : NB), MATH>(a, smem, block);                \
+        conv16_run<T, KIND, C0, C1, COUT, H, W, (sizeof(T) == 2 ? NB16 : NB), POOL, KIND == CONV3, MATH>(a, smem, block, nblocks); \
+        __builtin_amdgcn_s_waitcnt(0x0F70);            /* vmcnt(0): this wave's output stores are in the L2 */              \
+        __syncthreads();                               /* ... everyone's, and everyone has left the weights in LDS */       \
     }
-#define FILL(l, KIND, C0, C1, COUT, H, W, NB, POOL)                                                                     \
-    if (l < m.nlayers) conv16_fill<T, KIND, C0, C1, COUT, NB, SPLIT>(m.layer[l], smem, block);
-    // layer l, then: everyone in the workgroup leaves its LDS -> request layer l+1's weights -> device barrier
-#define STEP(lcur, lnext_args)                                                                                           \
-    __syncthreads();                                                                                                    \
-    FILL lnext_args                                                                                                     \
-    grid_barrier(m.sync, ++epoch * (unsigned)nblocks, m.dbg);
-    X(0, CONV3, 32, 0, 32, 40, 40, 2, false)
-    STEP(0, (1, CONV3, 32, 0, 32, 40, 40, 2, true))
-    X(1, CONV3, 32, 0, 32, 40, 40, 2, true)
-    STEP(1, (2, CONV3, 32, 0, 64, 20, 20, 1, false))
-    X(2, CONV3, 32, 0, 64, 20, 20, 1, false)
-    STEP(2, (3, CONV3, 64, 0, 64, 20, 20, 1, true))
-    X(3, CONV3, 64, 0, 64, 20, 20, 1, true)
-    STEP(3, (4, CONV3, 64, 0, 128, 10, 10, 1, false))
-    X(4, CONV3, 64, 0, 128, 10, 10, 1, false)
-    STEP(4, (5, CONV3, 128, 0, 128, 10, 10, 1, false))
-    X(5, CONV3, 128, 0, 128, 10, 10, 1, false)
-    STEP(5, (6, UPCONV, 128, 0, 64, 10, 10, 2, false))
-    X(6, UPCONV, 128, 0, 64, 10, 10, 2, false)
-    STEP(6, (7, CONV3, 64, 64, 64, 20, 20, 1, false))
-    X(7, CONV3, 64, 64, 64, 20, 20, 1, false)
-    STEP(7, (8, CONV3, 64, 0, 64, 20, 20, 1, false))
-    X(8, CONV3, 64, 0, 64, 20, 20, 1, false)
-    STEP(8, (9, UPCONV, 64, 0, 32, 20, 20, 2, false))
-    X(9, UPCONV, 64, 0, 32, 20, 20, 2, false)
-    STEP(9, (10, CONV3, 32, 32, 32, 40, 40, 2, false))
-    X(10, CONV3, 32, 32, 32, 40, 40, 2, false)
-    STEP(10, (11, CONV3, 32, 0, 32, 40, 40, 2, false))
-    X(11, CONV3, 32, 0, 32, 40, 40, 2, false)
-    if (m.nlayers > 12) {
-        STEP(11, (12, CONV1, 32, 0, 32, 40, 40, 2, false))
-        X(12, CONV1, 32, 0, 32, 40, 40, 2, false)
+    // after layer l: request layer l+1's weights (they land while the barrier is waited for), then the XCD barrier
+#define NEXT(l, KIND, C0, C1, COUT, H, W, NB, POOL, NB16)                                                                  \
+    if (l < m.nlayers) {                                                                                                   \
+        conv16_fill<T, KIND, C0, C1, COUT, (sizeof(T) == 2 ? NB16 : NB), MATH>(m.layer[l], smem, block);                   \
+        xcd_barrier(counter, ++epoch * (unsigned)nblocks, l);                                                                 \
     }
-#undef STEP
-#undef FILL
+    X(0, CONV3, 32, 0, 32, 40, 40, 2, false, 2)
+    NEXT(1, CONV3, 32, 0, 32, 40, 40, 2, true, 2)
+    X(1, CONV3, 32, 0, 32, 40, 40, 2, true, 2)
+    NEXT(2, CONV3, 32, 0, 64, 20, 20, 1, false, 4)
+    X(2, CONV3, 32, 0, 64, 20, 20, 1, false, 4)
+    NEXT(3, CONV3, 64, 0, 64, 20, 20, 1, true, 4)
+    X(3, CONV3, 64, 0, 64, 20, 20, 1, true, 4)
+    NEXT(4, CONV3, 64, 0, 128, 10, 10, 1, false, 4)
+    X(4, CONV3, 64, 0, 128, 10, 10, 1, false, 4)
+    NEXT(5, CONV3, 128, 0, 128, 10, 10, 1, false, 2)
+    X(5, CONV3, 128, 0, 128, 10, 10, 1, false, 2)
+    NEXT(6, UPCONV, 128, 0, 64, 10, 10, 2, false, 2)
+    X(6, UPCONV, 128, 0, 64, 10, 10, 2, false, 2)
+    NEXT(7, CONV3, 64, 64, 64, 20, 20, 1, false, 2)
+    X(7, CONV3, 64, 64, 64, 20, 20, 1, false, 2)
+    NEXT(8, CONV3, 64, 0, 64, 20, 20, 1, false, 4)
+    X(8, CONV3, 64, 0, 64, 20, 20, 1, false, 4)
+    NEXT(9, UPCONV, 64, 0, 32, 20, 20, 2, false, 2)
+    X(9, UPCONV, 64, 0, 32, 20, 20, 2, false, 2)
+    NEXT(10, CONV3, 32, 32, 32, 40, 40, 2, false, 2)
+    X(10, CONV3, 32, 32, 32, 40, 40, 2, false, 2)
+    NEXT(11, CONV3, 32, 0, 32, 40, 40, 2, false, 2)
+    X(11, CONV3, 32, 0, 32, 40, 40, 2, false, 2)
+    NEXT(12, CONV1, 32, 0, 32, 40, 40, 2, false, 2)
+    X(12, CONV1, 32, 0, 32, 40, 40, 2, false, 2)
+#undef NEXT
 #undef X
 }
-#endif  // GIGA_MEGA_EXPERIMENT
 
 // probe: if probe_stage == k, ev0/ev1 (hipEvent_t) are recorded right before / after launch k
 // (k = 0 conv_in+project, 1 plane_finalize, 2..14 = U-Net layers 0..12).
@@ -595,28 +625,30 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
         args(12, b + w.A6, nullptr, planes_nhwc, nullptr)};
     L[12].out_nchw = planes_nchw;
     const int nlayers = fold_final ? 12 : 13;
-#ifdef GIGA_MEGA_EXPERIMENT
-    // One persistent launch for the whole U-Net unless a single layer is being probed (stages 2..14) or the device cannot
-    // hold one workgroup per CU for 256 workgroups (GIGA_UNET_MEGA=0 forces per-layer launches: diagnostics).
+    // OPT-IN (GIGA_UNET_PERSIST=1): one persistent launch for the whole U-Net (unet_mega_kernel) when the images split evenly
+    // over the 8 XCDs, unless a single layer is being probed (stages 2..14).  Measured (tools/gpu_stage_all.py, whole encoder,
+    // us, per-layer launches -> persistent): 8 scenes fp32 189 -> 169, f16 118 -> 96, f16x3 142 -> 122; 32 scenes fp32 422 ->
+    // 423, f16 165 -> 148, f16x3 265 -> 257; 128 scenes 1406 -> 1395, 437 -> 424, 833 -> 796: it removes the launch gaps of the
+    // f16-class layers (~1.4 us per boundary), while an fp32 layer's barrier + weight fill + first patch cost what its launch
+    // ramp cost.  Not the default because spin barriers need all 256 workgroups co-resident: two such kernels started
+    // concurrently from two streams can each hold part of the CUs and wait for the rest (the barrier then traps after ~1 s).
     static const bool mega_ok = [] {
-        const char* e = getenv("GIGA_UNET_MEGA");
-        if (e && atoi(e) == 0) return false;
+        const char* e = getenv("GIGA_UNET_PERSIST");
+        if (!e || atoi(e) == 0) return false;
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess) return false;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-        return cus >= 256;
+        return cus == 256;                                    // 8 XCDs x 32 CUs, one workgroup per CU
     }();
     const bool probe_layer = pr.stage >= 2 && pr.stage <= 14;
-    if (mega_ok && !probe_layer) {
+    if (mega_ok && !probe_layer && nimg % 8 == 0) {
         MegaArgs m{};
         for (int l = 0; l < NCONV; ++l) m.layer[l] = L[l];
         m.sync = reinterpret_cast<unsigned*>(b + w.SYNC);
         m.nlayers = nlayers;
-        static const int dbg = [] { const char* e = getenv("GIGA_MEGA_DBG"); return e ? atoi(e) : 0; }();
-        m.dbg = dbg;
-        if (hipMemsetAsync(m.sync, 0, 8, s) != hipSuccess) return -10;
-        auto kern = unet_mega_kernel<T, SPLIT>;
-        constexpr size_t lds = mega_lds_bytes<T, SPLIT>();
+        if (hipMemsetAsync(m.sync, 0, 8 * 128, s) != hipSuccess) return -10;
+        auto kern = unet_mega_kernel<T, MATH>;
+        constexpr size_t lds = mega_lds_bytes<T, MATH>();
         static_assert(lds <= 160 * 1024, "LDS budget of the persistent U-Net kernel");
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         stage_no = 15;                                        // probe stage 15 = the whole U-Net
@@ -625,7 +657,6 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
         post();
         return hipGetLastError() == hipSuccess ? 0 : -10;
     }
-#endif
     if (pr.stage == 15) (void)hipEventRecord(pr.ev0, s);
 #define X(l, KIND, C0, C1, COUT, H, W, NB, POOL, NB16)                                                                    \
     if (l < nlayers) { pre(); rc |= launch_conv<T, KIND, C0, C1, COUT, H, W, (sizeof(T) == 2 ? NB16 : NB), POOL, KIND == CONV3, MATH>(L[l], s); post(); } \
@@ -652,6 +683,9 @@ int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, fl
 
 #ifdef GIGA_TRACE
 // diagnostic build only: select the traced U-Net layer (host_out == nullptr) or read the timeline back
+extern "C" int giga_debug_mega_trace(long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(giga::g_mega_trace), sizeof(long long) * 8 * 32) == hipSuccess ? 0 : -10;
+}
 extern "C" int giga_debug_convin_trace(long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(giga::g_ci_trace), sizeof(long long) * 8 * 64) == hipSuccess ? 0 : -10;
 }
