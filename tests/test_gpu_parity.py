@@ -434,3 +434,33 @@ def test_batch_256_c3_scene_consistency(net, dev):
                 for a, b in zip(full, one):
                     assert maxerr(a[k:k + 1], b.cpu()) < tol
     net.set_precision("fp32")
+
+
+@pytest.mark.gpu
+def test_persistent_unet_kernel_opt_in_is_bit_identical(tmp_path):
+    """GIGA_UNET_PERSIST=1 (one persistent U-Net launch, barriers per XCD through the XCD's own L2) computes every image with
+    the same instruction sequence as the per-layer launches: the planes of a 32-scene batch are bit-identical in all three
+    modes.  The knob is read once per process, hence the subprocesses."""
+    import os, subprocess, sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "from giga_amd import networks, synth, weights\n"
+        "dev = torch.device('cuda:0')\n"
+        "net = networks.get_network('giga'); net.load_state_dict(weights.make_state_dict(7)); net = net.to(dev).eval()\n"
+        "x = torch.from_numpy(synth.tsdf_batch(500, 32)).to(dev)\n"
+        "out = {}\n"
+        "for prec in ('fp32', 'fp16x3', 'fp16'):\n"
+        "    net.set_precision(prec)\n"
+        "    with torch.no_grad():\n"
+        "        for _ in range(3): pl = net.encode_inputs(x)\n"
+        "    for k in ('xz', 'xy', 'yz'): out[prec + k] = pl[k].float().cpu().numpy()\n"
+        "np.savez(sys.argv[1], **out)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ, GIGA_UNET_PERSIST=flag, PYTHONPATH=root)
+        f = str(tmp_path / f"planes{flag}.npz")
+        subprocess.run([sys.executable, "-c", code, f], check=True, env=env, cwd=root, timeout=300)
+        res[flag] = np.load(f)
+    for k in res["0"].files:
+        assert np.array_equal(res["0"][k], res["1"][k]), k
