@@ -455,7 +455,15 @@ def _settle():
 
 
 def _rewarm(fn, least, min_ms=30.0):
-    """At least `least` untimed calls of fn and at least min_ms of GPU work after a _settle() pause."""
+    """At least `least` untimed calls of fn and at least min_ms of GPU work after a _settle() pause.  With more than one rank
+    the count is FIXED (16 calls beyond `least`): fn may contain a collective (the data-parallel training step all-reduces its
+    gradients), and a time-based count would differ between ranks."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        for _ in range(max(least, 4) + 16):
+            fn()
+        torch.cuda.synchronize()
+        return
     t0, n = time.perf_counter(), 0
     while n < least or (time.perf_counter() - t0) * 1e3 < min_ms:
         for _ in range(4):
