@@ -40,13 +40,17 @@ def build(force=False, verbose=False):
         if r.returncode != 0:
             sys.stderr.write((r.stdout or "") + (r.stderr or ""))
             raise RuntimeError("hipcc build of examples/c_abi_demo.cpp failed")
-    # the MFMA peak micro-benchmark behind the "measured peak" figures (tools/mfma_peak.hip); standalone
-    if os.path.exists(PEAK_SRC) and (force or not os.path.exists(PEAK) or os.path.getmtime(PEAK) < os.path.getmtime(PEAK_SRC)):
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        r = subprocess.run([hipcc, "-O2", "--offload-arch=gfx950", PEAK_SRC, "-o", PEAK], capture_output=not verbose, text=True)
-        if r.returncode != 0:
-            sys.stderr.write((r.stdout or "") + (r.stderr or ""))
-            raise RuntimeError("hipcc build of tools/mfma_peak.hip failed")
+    # the standalone micro-benchmarks behind the hardware figures quoted in DESIGN.md (tools/*.hip): sustained MFMA / HBM
+    # peaks, fp32 MFMA vs VALU co-execution and per-instruction issue cost, the XCD-local barrier, f16 MFMA denormals
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    tools = os.path.join(os.path.dirname(HERE), "tools")
+    for name in ("mfma_peak", "mfma_valu_overlap", "mfma_issue_cost", "xcd_barrier", "mfma_denorm"):
+        src, out = os.path.join(tools, name + ".hip"), os.path.join(HERE, "lib", name)
+        if os.path.exists(src) and (force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src)):
+            r = subprocess.run([hipcc, "-O2", "--offload-arch=gfx950", src, "-o", out], capture_output=not verbose, text=True)
+            if r.returncode != 0:
+                sys.stderr.write((r.stdout or "") + (r.stderr or ""))
+                raise RuntimeError(f"hipcc build of tools/{name}.hip failed")
     return LIB
 
 
