@@ -552,6 +552,13 @@ def bench_c4(net, dev, L, _capi, synth, decode_heads, prec, Bc=32, steps=10):
 
 def bench_c4_all(net, dev, L, _capi, synth, decode_heads):
     out = {}
+    # the opt-in one-launch U-Net (net.set_persistent_unet: caller vouches for one stream per device, which holds here)
+    net.set_persistent_unet(True)
+    for prec, key in (("fp16", "c4_persistent_unet"), ("fp16x3", "c4_fp16x3_persistent_unet")):
+        r = bench_c4(net, dev, L, _capi, synth, decode_heads, prec)
+        out[key] = {k: r[k] for k in ("workload", "scenes_per_sec", "ms_per_step", "step_ms_median", "step_ms_max")}
+        out[key]["workload"] += "; U-Net as one persistent launch (GIGA_PERSIST_UNET)"
+    net.set_persistent_unet(False)
     for prec, key in (("fp16", "c4"), ("fp16x3", "c4_fp16x3")):
         out[key] = bench_c4(net, dev, L, _capi, synth, decode_heads, prec)
         sweep = []

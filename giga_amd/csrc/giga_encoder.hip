@@ -557,7 +557,7 @@ struct Probe { int stage; hipEvent_t ev0, ev1; };
 
 template <typename T, int MATH = MATH_NATIVE>
 static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc, float* planes_nchw, int B,
-                       uint8_t* ws, hipStream_t s, const Probe& pr, bool fold_final) {
+                       uint8_t* ws, hipStream_t s, const Probe& pr, bool fold_final, bool persist) {
     constexpr bool SPLIT = MATH == MATH_SPLIT;
     int stage_no = 0;
     auto pre = [&]() { if (pr.stage == stage_no) (void)hipEventRecord(pr.ev0, s); };
@@ -625,21 +625,22 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
         args(12, b + w.A6, nullptr, planes_nhwc, nullptr)};
     L[12].out_nchw = planes_nchw;
     const int nlayers = fold_final ? 12 : 13;
-    // OPT-IN (GIGA_UNET_PERSIST=1): one persistent launch for the whole U-Net (unet_mega_kernel) when the images split evenly
-    // over the 8 XCDs, unless a single layer is being probed (stages 2..14).  Measured (tools/gpu_stage_all.py, whole encoder,
-    // us, per-layer launches -> persistent): 8 scenes fp32 189 -> 169, f16 118 -> 96, f16x3 142 -> 122; 32 scenes fp32 422 ->
-    // 423, f16 165 -> 148, f16x3 265 -> 257; 128 scenes 1406 -> 1395, 437 -> 424, 833 -> 796: it removes the launch gaps of the
-    // f16-class layers (~1.4 us per boundary), while an fp32 layer's barrier + weight fill + first patch cost what its launch
-    // ramp cost.  Not the default because spin barriers need all 256 workgroups co-resident: two such kernels started
-    // concurrently from two streams can each hold part of the CUs and wait for the rest (the barrier then traps after ~1 s).
-    static const bool mega_ok = [] {
-        const char* e = getenv("GIGA_UNET_PERSIST");
-        if (!e || atoi(e) == 0) return false;
+    // OPT-IN (flag GIGA_PERSIST_UNET of the call, or GIGA_UNET_PERSIST=1 in the environment for every call): one persistent
+    // launch for the whole U-Net (unet_mega_kernel) when the images split evenly over the 8 XCDs, unless a single layer is being
+    // probed (stages 2..14).  Measured (tools/gpu_stage_all.py, whole encoder, us, per-layer launches -> persistent): 8 scenes
+    // fp32 189 -> 169, f16 118 -> 96, f16x3 142 -> 122; 32 scenes fp32 422 -> 423, f16 165 -> 148, f16x3 265 -> 257; 128 scenes
+    // 1406 -> 1395, 437 -> 424, 833 -> 796: it removes the launch gaps of the f16-class layers (~1.4 us per boundary), while an
+    // fp32 layer's barrier + weight fill + first patch cost what its launch ramp cost.  Not the default because spin barriers
+    // need all 256 workgroups co-resident: two such kernels started concurrently from two streams can each hold part of the CUs
+    // and wait for the rest (the barrier then traps after ~1 s); whoever sets the flag vouches that this cannot happen.
+    static const bool env_persist = [] { const char* e = getenv("GIGA_UNET_PERSIST"); return e && atoi(e) != 0; }();
+    static const bool full_device = [] {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess) return false;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
         return cus == 256;                                    // 8 XCDs x 32 CUs, one workgroup per CU
     }();
+    const bool mega_ok = (persist || env_persist) && full_device;
     const bool probe_layer = pr.stage >= 2 && pr.stage <= 14;
     if (mega_ok && !probe_layer && nimg % 8 == 0) {
         MegaArgs m{};
@@ -671,12 +672,12 @@ int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, fl
                    int precision, uint8_t* ws, hipStream_t s, int probe_stage, void* ev0, void* ev1) {
     if (B <= 0) return 0;
     Probe pr{ev0 && ev1 ? probe_stage : -1, static_cast<hipEvent_t>(ev0), static_cast<hipEvent_t>(ev1)};
-    const bool fold = (precision & GIGA_FOLD_FINAL) != 0;
-    const int prec = precision & ~GIGA_FOLD_FINAL;
-    if (prec == 2) return encoder_run<float, MATH_SPLIT>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold);
-    if (prec == 3) return encoder_run<float, MATH_BF16>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold);
-    return prec == 1 ? encoder_run<half_t>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold)
-                     : encoder_run<float>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold);
+    const bool fold = (precision & GIGA_FOLD_FINAL) != 0, persist = (precision & GIGA_PERSIST_UNET) != 0;
+    const int prec = precision & ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET);
+    if (prec == 2) return encoder_run<float, MATH_SPLIT>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist);
+    if (prec == 3) return encoder_run<float, MATH_BF16>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist);
+    return prec == 1 ? encoder_run<half_t>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist)
+                     : encoder_run<float>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist);
 }
 
 }  // namespace giga

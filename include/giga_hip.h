@@ -110,6 +110,13 @@ int giga_decoder_forward(const void* planes_nhwc, const float* p, const void* pa
  * outputs (fp32 rounding-level differences), one layer less.  planes_nchw must be NULL with this flag: the planes it
  * produces are NOT LocalVoxelEncoder's return value and are only meaningful to a decoder call carrying the flag. */
 #define GIGA_FOLD_FINAL 16
+/* GIGA_PERSIST_UNET, OR-ed into `precision` of giga_encoder_forward*: run the U-Net layers as ONE persistent launch whose
+ * layer boundaries are barriers among the 32 workgroups of each XCD (applies when 3 * B is a multiple of 8 on a 256-CU device;
+ * ignored otherwise).  Same results bit for bit; removes the launch gaps between the layers (f16-class modes: -10 % encoder time
+ * at 8-32 scenes; fp32: nothing).  CALLER'S CONTRACT: no other launch carrying this flag may be in flight on the device at the
+ * same time (other streams, other processes) -- the spin barriers need all 256 workgroups of the launch co-resident, and a
+ * barrier that cannot complete traps after about a second.  One stream per device satisfies it trivially. */
+#define GIGA_PERSIST_UNET 32
 
 /* Inference fast path for the FIXED QUERY LATTICE of VGNImplicit (detection_implicit.py:28-31,107):
  * the R^3 points meshgrid(lin, lin, lin, 'ij') with z fastest, shared by all B scenes.  Each plane is
