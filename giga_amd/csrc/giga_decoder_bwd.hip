@@ -38,6 +38,7 @@ struct DecBwdArgs {
     int nheads, B, N;
     long long P;
     int nbatch; float invN;
+    int heads_per_wg;           // heads handled by one workgroup (blockIdx.y selects the group): 1 when the point batches cannot fill the chip
 };
 
 template <int CHUNKS>
@@ -114,7 +115,12 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) dc[pl][r] = 0.f;
 
-        for (int h = 0; h < a.nheads; ++h) {
+        // few point batches (train_giga's single grasp query per scene = ONE batch): every head gets its own workgroup -- the
+        // three grasp heads of 32 points took 120 us one after the other in a single workgroup, 40 us side by side; the plane
+        // gradient is accumulated with atomics either way
+        const int h_begin = (int)blockIdx.y * a.heads_per_wg;
+        const int h_end = h_begin + a.heads_per_wg < a.nheads ? h_begin + a.heads_per_wg : a.nheads;
+        for (int h = h_begin; h < h_end; ++h) {
             float* S = a.scratch[h];
             const size_t AS = (size_t)a.P * 32;                     // array stride
             // ================= 1. forward recompute (fragment order of giga_pack.cpp::pack_head32) ==========
@@ -416,10 +422,12 @@ int launch_decoder_backward(const float* planes, const float* p, const uint8_t* 
     const long long tiles = (P + 31) / 32;
     a.nbatch = (int)((tiles + 3) / 4);
     const int grid = a.nbatch < 256 ? a.nbatch : 256;
+    const bool split = grid * a.nheads <= 256;                  // the point batches alone cannot fill the chip
+    a.heads_per_wg = split ? 1 : a.nheads;
     const size_t lds = DEC32_BYTES > DECB_BYTES ? DEC32_BYTES : DECB_BYTES;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-    hipLaunchKernelGGL(decoder_bwd_kernel, dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(decoder_bwd_kernel, dim3(grid, split ? a.nheads : 1), dim3(256), lds, s, a);
     // weight / bias gradients: one launch per head
     for (int hh = 0; hh < a.nheads; ++hh) {
         const int h = a.head_id[hh];
