@@ -315,7 +315,9 @@ def main():
                 ("c2_fp16x3", lambda: bench_c2_mode(net, x, pos, pos_occ, "fp16x3")),
                 ("c5_train_step_fp32_param_list", lambda: bench_train(net, dev, synth, B, M, flat=False)),
                 ("c5_train_step_fp32", lambda: bench_train(net, dev, synth, B, M)),
-                ("c5_train_step_bf16", lambda: bench_train(net, dev, synth, B, M, precision="bf16")))
+                ("c5_train_step_bf16", lambda: bench_train(net, dev, synth, B, M, precision="bf16")),
+                ("c5_train_step_fp32_flat_adam", lambda: bench_train(net, dev, synth, B, M, giga_adam=True)),
+                ("c5_train_step_bf16_flat_adam", lambda: bench_train(net, dev, synth, B, M, precision="bf16", giga_adam=True)))
         for key, fn in legs:
             try:
                 r = fn()
@@ -603,7 +605,7 @@ def bench_c2_mode(net, x, pos, pos_occ, prec, steps=30):
             "ms_per_step": el * 1e3, "step_ms_median": float(np.median(per)), "scenes_per_sec": B / el}
 
 
-def bench_train(net, dev, synth, B, M, steps=50, rank=0, world=1, sync=None, precision="fp32", flat=True):
+def bench_train(net, dev, synth, B, M, steps=50, rank=0, world=1, sync=None, precision="fp32", flat=True, giga_adam=False):
     """One optimisation step of scripts/train_giga.py:198-211 on this rank's scenes: forward, the fused joint loss
     (giga_amd.training.giga_loss = select + loss_fn of the reference), HIP backward, fused Adam.  world > 1: the backward
     all-reduces (means) the flat gradient bucket over RCCL (net.enable_data_parallel), BASELINE config c5."""
@@ -617,7 +619,11 @@ def bench_train(net, dev, synth, B, M, steps=50, rank=0, world=1, sync=None, pre
     # the reference's optimiser (train_giga.py:49: Adam, lr 2e-4) in torch's fused form (the default per-tensor foreach path
     # costs 6 ms of host time per step for the 164 parameter tensors); flat: over the module's single flat parameter
     # (net.flatten_parameters(): one Adam launch instead of five, no per-step flattening copy, one gradient for autograd)
-    opt = torch.optim.Adam(net.flatten_parameters() if flat else [q for q in net.parameters() if q.requires_grad], lr=2e-4, fused=True)
+    if giga_adam:                                        # the same update as one HIP launch over the flat buffer (giga_amd/optim.py)
+        from giga_amd.optim import FlatAdam
+        opt = FlatAdam(net.flatten_parameters(), lr=2e-4)
+    else:
+        opt = torch.optim.Adam(net.flatten_parameters() if flat else [q for q in net.parameters() if q.requires_grad], lr=2e-4, fused=True)
     last = {}
 
     def step():
@@ -639,6 +645,7 @@ def bench_train(net, dev, synth, B, M, steps=50, rank=0, world=1, sync=None, pre
              "gradients, decoders, conv_in, master weights)") if precision == "bf16" else "fp32"
     return {"workload": f"joint GIGA training step (train_giga.py:198-211): B={B} scenes/GPU, 1 grasp query + {M} "
                         f"occupancy queries, forward + fused loss + HIP backward + fused Adam"
+                        f"{' (giga_amd.optim.FlatAdam: one launch)' if giga_adam else ''}"
                         f"{' over one flat parameter' if flat else ' over the 164 parameter tensors'}, {arith}, {world} GPU"
                         + (", one RCCL all-reduce of the flat gradient bucket per step" if world > 1 else ""),
             "steps": steps, "ms_per_step": el * 1e3, "step_ms_median": float(np.median(per)), "step_ms_max": float(np.max(per)),

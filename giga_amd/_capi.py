@@ -67,6 +67,9 @@ _SIGNATURES = {
     "giga_train_loss": (ctypes.c_int, [ctypes.c_void_p] * 8 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                                                ctypes.c_void_p]),
     "giga_train_loss_backward": (ctypes.c_int, [ctypes.c_void_p] * 9 + [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 5),
+    "giga_adam_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                      ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int,
+                                      ctypes.c_void_p]),
     "giga_event_create": (ctypes.c_void_p, []),
     "giga_event_destroy": (None, [ctypes.c_void_p]),
     "giga_event_record": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

@@ -39,6 +39,8 @@ int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, fl
                    int precision, uint8_t* ws, hipStream_t s, int probe_stage, void* ev0, void* ev1);
 // giga_decoder.hip
 int launch_decoder(const DecArgs& a, int precision, hipStream_t s, void* ev0, void* ev1);
+int launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps, double wd,
+                     int step, hipStream_t s);
 int launch_planes_pack(const float* xz, const float* xy, const float* yz, void* dst, int B, int precision, hipStream_t s);
 int launch_lattice_resample(const void* planes, const float* lin, void* out, int B, int R, int precision, hipStream_t s);
 int launch_planes_unpack(const void* src, float* dst, int B, int precision, hipStream_t s);
@@ -403,6 +405,15 @@ int giga_train_loss_backward(const float* qual, const float* rot, const float* w
     if (M > 0 && (!occ_logits || !occ_target || !docc)) return -1;
     return launch_train_loss_backward(qual, rot, width, occ_logits, label, rot_targets, width_target, occ_target, grad_loss,
                                       B, M, dqual, drot, dwidth, docc, static_cast<hipStream_t>(stream));
+}
+
+int giga_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
+                   double beta2, double eps, double weight_decay, int step, void* stream) {
+    if (n == 0) return 0;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || step < 1) return -1;
+    if (!(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0)) return -1;
+    return launch_adam_flat(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step,
+                            static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -14,6 +14,7 @@
 // the BCE gradient (p - y) / max(p (1 - p), 1e-12)) so that losses and gradients agree with autograd through the
 // reference's helpers to fp32 rounding (tests/test_gpu_training.py, golden G11).
 #include <hip/hip_runtime.h>
+#include <cmath>
 
 namespace giga {
 
@@ -121,6 +122,48 @@ int launch_train_loss_backward(const float* qual, const float* rot, const float*
                                hipStream_t s) {
     hipLaunchKernelGGL(loss_grad_kernel, dim3(B), dim3(256), 0, s, qual, rot, width, occ, label, rot_t, width_t, occ_t, gout,
                        B, M, dqual, drot, dwidth, docc);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Adam over ONE flat fp32 parameter buffer (the module's flattened parameters, 581 863 elements): torch.optim.Adam's update
+// (scripts/train_giga.py:49 builds `torch.optim.Adam(net.parameters(), lr)`; no amsgrad, not maximize) in one launch that
+// uses the whole chip.  torch's fused multi-tensor kernel gives one tensor one workgroup per 65 536 elements: nine workgroups
+// for this buffer, 98 us per step (tools/gpu_train_kernels.py); this takes ~5 us.  Same formulas in the same order as
+// torch/optim/adam.py (_single_tensor_adam): m = lerp(m, g, 1 - b1); v = b2 v + (1 - b2) g g;
+// p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps); L2 weight decay adds wd * p to g first.
+__global__ __launch_bounds__(256) void adam_flat_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+                                                        float4* __restrict__ v, size_t n4, size_t n, float step_size, float b2,
+                                                        float omb1, float omb2, float eps, float wd, float bc2_sqrt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        if (wd != 0.f) gg = fmaf(wd, pp, gg);
+        mm = mm + (gg - mm) * omb1;                            // exp_avg.lerp_(grad, 1 - beta1)
+        vv = vv * b2 + omb2 * gg * gg;                         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        pp = pp - step_size * (mm / denom);                    // param.addcdiv_(exp_avg, denom, value=-step_size)
+    };
+    if (i < n4) {
+        float4 P = p[i], M = m[i], V = v[i];
+        const float4 G = g[i];
+        upd(P.x, G.x, M.x, V.x); upd(P.y, G.y, M.y, V.y); upd(P.z, G.z, M.z, V.z); upd(P.w, G.w, M.w, V.w);
+        p[i] = P; m[i] = M; v[i] = V;
+    } else if (i == n4) {                                      // the (n % 4) tail elements
+        float* ps = reinterpret_cast<float*>(p); const float* gs = reinterpret_cast<const float*>(g);
+        float* ms = reinterpret_cast<float*>(m); float* vs = reinterpret_cast<float*>(v);
+        for (size_t k = 4 * n4; k < n; ++k) upd(ps[k], gs[k], ms[k], vs[k]);
+    }
+}
+
+int launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps, double wd,
+                     int step, hipStream_t s) {
+    if (n == 0) return 0;
+    const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);     // (hyper-parameters stay double on the host, as in torch)
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((n4 + 1 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<float4*>(p),
+                       reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v), n4, n,
+                       (float)(lr / bc1), (float)b2, (float)(1.0 - b1), (float)(1.0 - b2), (float)eps, (float)wd, (float)sqrt(bc2));
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 

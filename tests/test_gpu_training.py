@@ -403,3 +403,29 @@ def test_training_steps_do_not_accumulate_device_memory(sd7):
     finally:
         gc.enable()
     assert seen[5] - seen[1] < (1 << 20), seen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_flat_adam_matches_torch_adam(wd):
+    """giga_amd.optim.FlatAdam (one HIP launch, giga_adam_step) = torch.optim.Adam (scripts/train_giga.py:49) step for step on
+    a buffer of the model's size (581 863 elements: exercises the n % 4 tail); same state-dict layout."""
+    from giga_amd.optim import FlatAdam
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n = 581863
+    p0 = torch.randn(n, generator=g) * 0.1
+    a = torch.nn.Parameter(p0.clone().to(dev))
+    b = torch.nn.Parameter(p0.clone().to(dev))
+    oa = torch.optim.Adam([a], lr=2e-4, weight_decay=wd)
+    ob = FlatAdam([b], lr=2e-4, weight_decay=wd)
+    for it in range(6):
+        grad = (torch.randn(n, generator=g) * (10.0 ** (it % 3 - 1))).to(dev)
+        a.grad = grad.clone(); b.grad = grad.clone()
+        oa.step(); ob.step()
+        assert (a.detach() - b.detach()).abs().max().item() < 2e-7, it        # steps are <= lr = 2e-4: 1e-3 relative of a step
+    sa, sb = oa.state_dict()["state"][0], ob.state_dict()["state"][0]
+    assert set(sa) == set(sb) and float(sa["step"]) == float(sb["step"]) == 6.0
+    # moments: fp32 rounding of two formulations of the same update (lerp vs b1 m + (1 - b1) g)
+    assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-8)
