@@ -1,5 +1,5 @@
 """Per-launch kernel durations of ONE training step (rocprofv3 --kernel-trace csv -> table in launch order).
-   cd /tmp && rocprofv3 --kernel-trace -d /tmp/pt -o t --output-format csv -- python tools/gpu_train_kernels.py run [bf16]
+   cd /tmp && rocprofv3 --kernel-trace -d /tmp/pt -o t --output-format csv -- python tools/gpu_train_kernels.py run [bf16] [detach]
    python tools/gpu_train_kernels.py table /tmp/pt"""
 import sys
 if sys.argv[1] == "run":
@@ -8,7 +8,8 @@ if sys.argv[1] == "run":
     from giga_amd.training import giga_loss
     dev = torch.device("cuda:0")
     net = networks.get_network("giga"); net.load_state_dict(weights.make_state_dict(7)); net = net.to(dev).train()
-    net.set_train_precision("bf16" if len(sys.argv) > 2 and sys.argv[2] == "bf16" else "fp32")
+    net.set_train_precision("bf16" if "bf16" in sys.argv[2:] else "fp32")
+    net.detach_tsdf = "detach" in sys.argv[2:]      # occupancy head detached from the planes: no scatter in its backward
     B, M = 32, 2048
     x = torch.from_numpy(synth.tsdf_batch(0, B)).to(dev)
     pos = torch.from_numpy(synth.query_points(0, B, 1, stream=2)).to(dev)
