@@ -114,6 +114,7 @@ const char* giga_strerror(int code) {
         case -4: return "workspace too small";
         case -5: return "unsupported precision";
         case -6: return "null pointer for a requested output";
+        case -7: return "more than GIGA_MAX_SCENES scenes in one call";
         case -10: return "HIP launch failed";
         default: return "unknown error";
     }
@@ -165,6 +166,7 @@ int giga_encoder_forward_probe(const float* tsdf, const void* packed, void* plan
                                int B, int precision, void* workspace, size_t workspace_bytes, void* stream,
                                int probe_stage, void* ev_start, void* ev_stop) {
     if (B < 0 || (B > 0 && (!tsdf || !packed || !planes_nhwc || !workspace))) return -1;
+    if (B > GIGA_MAX_SCENES) return -7;
     const bool fold = (precision & GIGA_FOLD_FINAL) != 0;     // stop before conv_final (folded decoder images)
     const int persist = precision & GIGA_PERSIST_UNET;        // one persistent U-Net launch (caller's contract: see the header)
     precision &= ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET);
@@ -322,6 +324,7 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
     if (!tsdf || !packed || !bwd_packed || !enc_workspace_fwd || !planes_nhwc || !outs || !douts || !grads ||
         !workspace)
         return -1;
+    if (B > GIGA_MAX_SCENES) return -7;
     const bool detach_occ = (head_present & GIGA_DETACH_OCC) != 0;     // detach_tsdf, models/__init__.py:61-63
     const bool bf16_convs = (head_present & GIGA_BF16_CONVS) != 0;     // data-gradient convolutions on bf16 MFMA
     head_present &= 15;

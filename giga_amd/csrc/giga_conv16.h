@@ -1,6 +1,7 @@
 // conv16: the LDS-staged implicit-GEMM convolution used by every U-Net layer (forward) and by the
 // data-gradient convolutions of the training path (giga_encoder_bwd.hip).
 #pragma once
+#include <type_traits>
 #include "giga_dev.h"
 
 namespace giga {
@@ -163,7 +164,7 @@ __device__ __forceinline__ void conv16_run(const ConvArgs& a, uint8_t* smem, int
     int a_off = (KIND == DOWN ? (2 * ay * LW + 2 * ax) : (ay * LW + ax)) * PS + g * AG;      // LIN: set per unit below
 
     // staging geometry of this lane's NLD vectors (fixed for the whole kernel)
-    int st_lds[NLD], st_ly[NLD], st_lx[NLD], st_v[NLD];
+    int st_lds[NLD], st_ly[NLD], st_lx[NLD], st_v[NLD], st_pl[NLD];
 #pragma unroll
     for (int q = 0; q < NLD; ++q) {
         const int i = lane + 64 * q;
@@ -171,51 +172,162 @@ __device__ __forceinline__ void conv16_run(const ConvArgs& a, uint8_t* smem, int
         st_v[q] = i % VPP;
         st_ly[q] = pix / LW; st_lx[q] = pix % LW;
         st_lds[q] = i < NVEC ? pix * PS + st_v[q] * 16 : -1;
+        st_pl[q] = st_ly[q] * (KIND == DOWN ? 2 * W : W) + st_lx[q];       // pixel offset from the patch origin in the input image
     }
     auto unit_coords = [&](int u, int& tx, int& ty, int& img) {
         tx = u % TX; ty = (u / TX) % TY; img = u / (TX * TY);
     };
+    // Patch loads.  fp32-input MFMAs do not co-execute with VALU work of any wave of the SIMD (DESIGN "fp32 MFMA and the
+    // VALU"), so every VALU instruction of the loop is paid in MFMA time: the bounds tests and the pixel -> byte-offset
+    // arithmetic are done ONCE PER UNIT (unit_setup: 32-bit offsets from the tensor base; launch_conv refuses tensors of
+    // 2 GiB and more), a chunk's loads are `uniform base + per-lane offset` with no arithmetic at all, out-of-image lanes load
+    // from offset 0 and are simply not written to the patch, whose out-of-image cells are zeroed once per unit.
     uint4 stg[NLD];
-    auto issue_loads = [&](int u, int cc) {
+    uint32_t st_b0[NLD], st_b1[C1 > 0 ? NLD : 1];      // byte offsets of this lane's vectors from in0 / in1 (0 if outside)
+    bool st_ok[NLD];                                   // inside the image (and inside the patch)
+    const uint32_t rowb0 = (uint32_t)(a.cs0 ? a.cs0 : C0) * ES, rowb1 = (uint32_t)(a.cs1 ? a.cs1 : C1) * ES;
+    auto unit_setup = [&](int u) {
         int tx, ty, img;
         unit_coords(u, tx, ty, img);
-        const bool first = cc * 32 < C0;
-        const T* src = reinterpret_cast<const T*>(first ? a.in0 : a.in1);
-        const int csrc = first ? (a.cs0 ? a.cs0 : C0) : (a.cs1 ? a.cs1 : C1);
-        const int coff = first ? a.co0 + cc * 32 : a.co1 + cc * 32 - C0;
         constexpr int IH = KIND == DOWN ? 2 * H : H, IW = KIND == DOWN ? 2 * W : W;   // input grid
         constexpr int TS = KIND == DOWN ? 8 : 4;                                        // input pixels per tile edge
+        const int y0 = (LIN ? (16 * tx) / W : TS * ty) - HALO, x0 = (LIN ? 0 : TS * tx) - HALO;
+        const int pix0 = (img * IH + y0) * IW + x0;                                     // (uniform)
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
-            const int gy = LIN ? (16 * tx) / W + st_ly[q] - HALO : TS * ty + st_ly[q] - HALO;
-            const int gx = LIN ? st_lx[q] - HALO : TS * tx + st_lx[q] - HALO;
-            uint4 val = make_uint4(0, 0, 0, 0);
-            if (st_lds[q] >= 0 && gy >= 0 && gy < IH && gx >= 0 && gx < IW)
-                val = *reinterpret_cast<const uint4*>(src + ((size_t)(img * IH + gy) * IW + gx) * csrc + coff +
-                                                      st_v[q] * (16 / ES));
-            stg[q] = val;
+            const int gy = y0 + st_ly[q], gx = x0 + st_lx[q];
+            const bool ok = st_lds[q] >= 0 && (unsigned)gy < (unsigned)IH && (unsigned)gx < (unsigned)IW;
+            const uint32_t pix = (uint32_t)(pix0 + st_pl[q]);            // < 2^24 (launch_conv)
+            st_ok[q] = ok;
+            st_b0[q] = ok ? __umul24(pix, rowb0) + st_v[q] * 16 : 0u;
+            if constexpr (C1 > 0) st_b1[q] = ok ? __umul24(pix, rowb1) + st_v[q] * 16 : 0u;
+        }
+    };
+    auto issue_loads = [&](int cc) {
+        const bool first = C1 == 0 || cc * 32 < C0;
+        const char* base = first ? reinterpret_cast<const char*>(a.in0) + (size_t)(a.co0 + cc * 32) * ES
+                                 : reinterpret_cast<const char*>(a.in1) + (size_t)(a.co1 + cc * 32 - C0) * ES;
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            uint32_t off = st_b0[q];
+            if constexpr (C1 > 0) off = first ? st_b0[q] : st_b1[q];
+            stg[q] = *reinterpret_cast<const uint4*>(base + off);
         }
     };
 
-    // global wave index = wave * (#workgroups) + workgroup: remainder units spread over all CUs/SIMDs
+    // global wave index = wave * (#workgroups) + workgroup: remainder units spread over all CUs/SIMDs.
+    // TAIL SPLIT (fp32 3x3 layers): with U units over nwaves waves the last round holds only U mod nwaves units, i.e. one
+    // lone wave on one or two SIMDs of every CU walks a whole unit -- NCHUNK dependent load -> stage -> MFMA rounds, each a
+    // global-load latency long because nobody shares its SIMD -- while the other SIMDs idle (at 32 scenes, 3.125 rounds: up to
+    // 15 % of the layer).  When the remainder is at most NWV/TPARTS units per workgroup, each of them is cut into TPARTS parts that
+    // run side by side on TPARTS waves (wave = TPARTS*slot + part, i.e. different SIMDs): one part per 32-channel chunk, or, for
+    // the 32-channel layers, one part per kernel row.  Parts > 0 hand their partial sums over through their own (dead) patch
+    // regions; part 0 adds them in order, ((p0 + p1) + p2) + p3, and runs the epilogue.  One workgroup barrier, taken by
+    // every wave of the workgroup.
+    constexpr int TPARTS = NCHUNK == 1 ? 3 : NCHUNK;  // parts of a split unit
+    constexpr bool TSPLIT_OK = KIND == CONV3 && MATH == MATH_NATIVE && ES == 4 && NB * 1024 <= REGION && NWV >= TPARTS && TPARTS <= 4;
+    const int full_end = (units / nwaves) * nwaves, rem = units - full_end;
+    const int smax = (rem + wgs_per_grp - 1) / wgs_per_grp;
+    const bool tsplit = TSPLIT_OK && rem > 0 && TPARTS * smax <= NWV;
+    const int lim = tsplit ? full_end : units;       // units below `lim` are walked as whole units
+    int tail_u = -1, part = 0;
+    if (tsplit) {
+        const int slot = wave / TPARTS, ru = slot * wgs_per_grp + wg_in_grp;
+        part = wave - TPARTS * slot;
+        if (active && ru < rem) tail_u = full_end + ru;
+    }
+    const int tail_cc = NCHUNK == 1 ? 0 : part;      // the chunk a part works on
     int u = wave * wgs_per_grp + wg_in_grp;
-    const bool work = active && u < units;
+    bool tail = false;
+    int cc = 0;
+    if (u >= lim) { u = tail_u; tail = true; cc = tail_cc; }
+    const bool work = active && u >= 0;
     // the first patch and the biases are requested while the weight fill is still in flight
-    if (work) issue_loads(u, 0);
+    if (work) { unit_setup(u); issue_loads(cc); }
+    bool fresh = true;                                 // the staged vectors belong to a unit whose patch is not zero-padded yet
     float bias_r[NB];
 #pragma unroll
     for (int n = 0; n < NB; ++n) bias_r[n] = a.bias ? a.bias[(nb0 + n) * 16 + j] : 0.f;
     __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): weights (LDS-DMA), patch and biases landed
     __syncthreads();
     CONV_T(1);
-    if (!work) return;                                 // (no workgroup barrier below this point)
-    int cc = 0;
+    if (!work) {                                       // (no workgroup barrier below this point, except the tail split's)
+        if (tsplit) __syncthreads();
+        return;
+    }
     constexpr int NACC = NB == 1 ? 2 : 1;          // independent accumulator chains per channel block
     f32x4v acc[NB][NACC];
 #pragma unroll
     for (int n = 0; n < NB; ++n)
 #pragma unroll
         for (int c = 0; c < NACC; ++c) acc[n][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    // Epilogue addressing is 32-bit (byte offsets from the uniform tensor bases; launch_conv bounds the tensors) and uses
+    // 24-bit multiplies: like the patch loads, its VALU instructions are paid in MFMA time.
+    auto epilogue = [&](const int u) {
+        int tx, ty, img;
+        unit_coords(u, tx, ty, img);
+        char* out = reinterpret_cast<char*>(a.out);
+        const int qy = 4 * ty + 2 * (g >> 1), qx = 4 * tx + 2 * (g & 1);
+        const int lp0 = 16 * tx + 4 * g;               // LIN: this lane's registers are pixels lp0 .. lp0+3 of the image
+        const bool qok = LIN ? lp0 < H * W : (qy < H && qx < W);   // (H, W even / H*W % 4 == 0: all four in or out)
+        // pixel index (in the output tensor) of register e
+        uint32_t pe[4];
+        constexpr int OW = KIND == UPCONV ? 2 * W : W, OHW = KIND == UPCONV ? 4 * H * W : H * W;
+        const uint32_t img_pix = (uint32_t)img * OHW;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (LIN) {
+                if constexpr (KIND == UPCONV) {
+                    const int y = (lp0 + e) / W, x = (lp0 + e) % W;
+                    pe[e] = img_pix + __umul24(2 * y + (sub >> 1), OW) + 2 * x + (sub & 1);
+                } else {
+                    pe[e] = img_pix + lp0 + e;
+                }
+            } else if constexpr (KIND == UPCONV) {
+                pe[e] = img_pix + __umul24(2 * qy + (sub >> 1), OW) + 2 * qx + (sub & 1) + (e >> 1) * 2 * OW + (e & 1) * 2;
+            } else {
+                pe[e] = img_pix + __umul24(qy, OW) + qx + (e >> 1) * OW + (e & 1);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int co = (nb0 + n) * 16 + j;
+            const float bv = bias_r[n];
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float sacc = acc[n][0][e];
+                if (NACC == 2) sacc += acc[n][NACC - 1][e];
+                v[e] = sacc + bv;
+                if (RELU) v[e] = relu(v[e]);
+                acc[n][0][e] = 0.f;
+                acc[n][NACC - 1][e] = 0.f;
+            }
+            if (qok) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t idx = pe[e] * COUT + co;
+                    if constexpr (KIND != UPCONV) {
+                        if (a.mask && !(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.mask) + idx * 4u) > 0.f))
+                            v[e] = 0.f;
+                    }
+                    *reinterpret_cast<T*>(out + idx * (uint32_t)ES) = (T)v[e];
+                    if constexpr (KIND == CONV1) {
+                        if (a.out_nchw) {
+                            const uint32_t pin = pe[e] - img_pix;                      // y * W + x
+                            a.out_nchw[((size_t)img * COUT + co) * H * W + pin] = v[e];
+                        }
+                    }
+                }
+                if (POOL) {
+                    const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                    const uint32_t pidx = ((uint32_t)img * (H / 2 * (W / 2)) + __umul24(qy >> 1, W / 2) + (qx >> 1)) * COUT + co;
+                    *reinterpret_cast<T*>(reinterpret_cast<char*>(a.out_pool) + pidx * (uint32_t)ES) = (T)mx;
+                }
+            }
+        }
+    };
 
     while (true) {
         if constexpr (LIN) {           // row i of the A operand is pixel 16*tile + i of the image (clamped past the end)
@@ -225,50 +337,65 @@ __device__ __forceinline__ void conv16_run(const ConvArgs& a, uint8_t* smem, int
             a_off = ((p / W - t16 / W) * LW + p % W) * PS + g * AG;
         }
         // ---- registers -> wave-private LDS patch (DS ops of one wave execute in order) -----------
+        auto put = [&](int q, const uint4 val) {
+            if constexpr (BF) {                       // channels 4v..4v+3 -> four bf16 (round to nearest even), 8 bytes
+                const f32x4v x = __builtin_bit_cast(f32x4v, val);
+                const bf16x4 b4 = {(__bf16)x[0], (__bf16)x[1], (__bf16)x[2], (__bf16)x[3]};
+                *reinterpret_cast<bf16x4*>(region + (st_lds[q] - st_v[q] * 16) + st_v[q] * 8) = b4;
+            } else if constexpr (SPLIT) {
+                // vector v = channels 4v..4v+3 of the pixel: hi halfs at group (v>>1), slot 4*(v&1); lo 16 bytes further
+                const f32x4v x = __builtin_bit_cast(f32x4v, val);
+                half4 hi4, lo4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const half_t h = (half_t)x[e];
+                    hi4[e] = h;
+                    lo4[e] = (half_t)__builtin_fmaf((float)h, -1.0f, x[e]);
+                }
+                uint8_t* dst = region + (st_lds[q] - st_v[q] * 16) + (st_v[q] >> 1) * 32 + (st_v[q] & 1) * 8;
+                *reinterpret_cast<half4*>(dst) = hi4;
+                *reinterpret_cast<half4*>(dst + 16) = lo4;
+            } else {
+                *reinterpret_cast<uint4*>(region + st_lds[q]) = val;
+            }
+        };
+        if (fresh) {                                   // first chunk of a unit: zero its out-of-image cells (border tiles only)
+#pragma unroll
+            for (int q = 0; q < NLD; ++q)
+                if (st_lds[q] >= 0 && !st_ok[q]) put(q, make_uint4(0, 0, 0, 0));
+        }
 #pragma unroll
         for (int q = 0; q < NLD; ++q)
-            if (st_lds[q] >= 0) {
-                if constexpr (BF) {                       // channels 4v..4v+3 -> four bf16 (round to nearest even), 8 bytes
-                    const f32x4v x = __builtin_bit_cast(f32x4v, stg[q]);
-                    const bf16x4 b4 = {(__bf16)x[0], (__bf16)x[1], (__bf16)x[2], (__bf16)x[3]};
-                    *reinterpret_cast<bf16x4*>(region + (st_lds[q] - st_v[q] * 16) + st_v[q] * 8) = b4;
-                } else if constexpr (SPLIT) {
-                    // vector v = channels 4v..4v+3 of the pixel: hi halfs at group (v>>1), slot 4*(v&1); lo 16 bytes further
-                    const f32x4v x = __builtin_bit_cast(f32x4v, stg[q]);
-                    half4 hi4, lo4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const half_t h = (half_t)x[e];
-                        hi4[e] = h;
-                        lo4[e] = (half_t)__builtin_fmaf((float)h, -1.0f, x[e]);
-                    }
-                    uint8_t* dst = region + (st_lds[q] - st_v[q] * 16) + (st_v[q] >> 1) * 32 + (st_v[q] & 1) * 8;
-                    *reinterpret_cast<half4*>(dst) = hi4;
-                    *reinterpret_cast<half4*>(dst + 16) = lo4;
-                } else {
-                    *reinterpret_cast<uint4*>(region + st_lds[q]) = stg[q];
-                }
-            }
+            if (st_ok[q]) put(q, stg[q]);
         CONV_T(tcount); ++tcount;          // patch chunk in LDS (includes the wait for its global loads)
         // ---- prefetch the next chunk / next unit ---------------------------------------------------
         int un = u, ccn = cc + 1;
-        if (ccn == NCHUNK) { un = u + nwaves; ccn = 0; }
-        const bool more = un < units;
-        if (more) issue_loads(un, ccn);
+        bool tailn = tail, more = !tail;             // (a part is one chunk and always a wave's last item)
+        if (more && ccn == NCHUNK) {
+            ccn = 0;
+            un = u + nwaves;
+            if (un >= lim) { un = tail_u; tailn = true; ccn = tail_cc; more = un >= 0; }
+        }
+        fresh = more && un != u;
+        if (more) {
+            if (fresh) unit_setup(un);
+            issue_loads(ccn);
+        }
         // ---- MFMA over taps x k-groups of this chunk: A from the patch, B from the resident weights.  The
         // operands of step i+3 are read from LDS right after the MFMAs of step i are issued (software pipeline), so a
         // wave keeps the MFMA pipe fed on its own instead of relying on its two SIMD siblings to cover the
         // LDS round trip (they are gone in the ragged last round).
-        constexpr int NIT = TAPS * KGC;
+        auto mfma_block = [&](auto nt_tag, const int a_base, const int wtap0) {
+        constexpr int NT = decltype(nt_tag)::value, NIT = NT * KGC;
         auto read_ops = [&](int it, uint4 (&av)[WPF], uint4 (&bw)[NB][WPF]) {
             const int tap = it / KGC, kg = it % KGC;
-            const int toff = (KIND == DOWN ? ((tap >> 1) * LW + (tap & 1)) : ((tap / 3) * LW + (tap % 3))) * PS;
+            const int toff = (KIND == DOWN ? ((tap >> 1) * LW + (tap & 1)) : ((tap / 3) * LW + (tap % 3))) * PS;   // (tap < NT)
 #pragma unroll
-            for (int w = 0; w < WPF; ++w) av[w] = *reinterpret_cast<const uint4*>(region + a_off + toff + kg * 64 + w * 16);
+            for (int w = 0; w < WPF; ++w) av[w] = *reinterpret_cast<const uint4*>(region + a_base + toff + kg * 64 + w * 16);
 #pragma unroll
             for (int n = 0; n < NB; ++n)
 #pragma unroll
-                for (int w = 0; w < WPF; ++w) bw[n][w] = wl[(((n * TAPS + tap) * KGT + cc * KGC + kg) * WPF + w) * 64 + lane];
+                for (int w = 0; w < WPF; ++w) bw[n][w] = wl[(((n * TAPS + wtap0 + tap) * KGT + cc * KGC + kg) * WPF + w) * 64 + lane];
         };
         // ring of PD operand sets: the LDS round trip of a 1 KiB ds_read_b128 is ~300 cycles, i.e. more than two
         // groups of four 32-cycle MFMAs
@@ -312,53 +439,47 @@ __device__ __forceinline__ void conv16_run(const ConvArgs& a, uint8_t* smem, int
             if (it + PD < NIT) read_ops(it + PD, av_q[sl], bw_q[sl]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        };
+        if constexpr (TSPLIT_OK && NCHUNK == 1) {
+            if (tail) mfma_block(std::integral_constant<int, 3>{}, a_off + part * LW * PS, 3 * part);
+            else mfma_block(std::integral_constant<int, TAPS>{}, a_off, 0);
+        } else {
+            mfma_block(std::integral_constant<int, TAPS>{}, a_off, 0);
+        }
         CONV_T(tcount); ++tcount;          // MFMAs of this chunk issued
         // ---- epilogue after the last chunk: lane holds cout j of quad g (4 pixels) ------------------
-        if (cc == NCHUNK - 1) {
-            int tx, ty, img;
-            unit_coords(u, tx, ty, img);
-            T* out = reinterpret_cast<T*>(a.out);
-            const int qy = 4 * ty + 2 * (g >> 1), qx = 4 * tx + 2 * (g & 1);
-            const int lp0 = 16 * tx + 4 * g;               // LIN: this lane's registers are pixels lp0 .. lp0+3 of the image
-            const bool qok = LIN ? lp0 < H * W : (qy < H && qx < W);   // (H, W even / H*W % 4 == 0: all four in or out)
+        if (cc == NCHUNK - 1 && !tail) epilogue(u);
+        if (!more) break;
+        u = un; cc = ccn; tail = tailn;
+    }
+    if constexpr (TSPLIT_OK) {
+        if (tsplit) {
+            float4* mine = reinterpret_cast<float4*>(region);
+            if (tail && part != 0) {
 #pragma unroll
-            for (int n = 0; n < NB; ++n) {
-                const int co = (nb0 + n) * 16 + j;
-                const float bv = bias_r[n];
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float sacc = acc[n][0][e];
-                    if (NACC == 2) sacc += acc[n][NACC - 1][e];
-                    v[e] = sacc + bv;
-                    if (RELU) v[e] = relu(v[e]);
-                    acc[n][0][e] = 0.f;
-                    acc[n][NACC - 1][e] = 0.f;
-                }
-                if (qok) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int y = LIN ? (lp0 + e) / W : qy + (e >> 1), x = LIN ? (lp0 + e) % W : qx + (e & 1);
-                        if (KIND == UPCONV) {
-                            const int oy = 2 * y + (sub >> 1), ox = 2 * x + (sub & 1);
-                            out[((size_t)(img * 2 * H + oy) * (2 * W) + ox) * COUT + co] = (T)v[e];
-                        } else {
-                            if (a.mask && !(a.mask[((size_t)(img * H + y) * W + x) * COUT + co] > 0.f)) v[e] = 0.f;
-                            out[((size_t)(img * H + y) * W + x) * COUT + co] = (T)v[e];
-                            if (KIND == CONV1 && a.out_nchw)
-                                a.out_nchw[((size_t)img * COUT + co) * H * W + y * W + x] = v[e];
-                        }
-                    }
-                    if (POOL) {
-                        const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                        T* op = reinterpret_cast<T*>(a.out_pool);
-                        op[((size_t)(img * (H / 2) + qy / 2) * (W / 2) + qx / 2) * COUT + co] = (T)mx;
-                    }
+                for (int n = 0; n < NB; ++n) {
+                    f32x4v sacc = acc[n][0];
+                    if (NACC == 2) sacc += acc[n][NACC - 1];
+                    mine[n * 64 + lane] = make_float4(sacc[0], sacc[1], sacc[2], sacc[3]);
                 }
             }
+            __syncthreads();
+            if (tail && part == 0) {
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    f32x4v sacc = acc[n][0];
+                    if (NACC == 2) sacc += acc[n][NACC - 1];
+#pragma unroll
+                    for (int t = 1; t < TPARTS; ++t) {
+                        const float4 o = reinterpret_cast<const float4*>(region + t * REGION)[n * 64 + lane];
+                        sacc += f32x4v{o.x, o.y, o.z, o.w};
+                    }
+                    acc[n][0] = sacc;
+                    if (NACC == 2) acc[n][NACC - 1] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                }
+                epilogue(u);
+            }
         }
-        if (!more) break;
-        u = un; cc = ccn;
     }
     CONV_T(63);
 }
@@ -406,6 +527,12 @@ inline int launch_conv(const ConvArgs& a, hipStream_t s) {
     static_assert(lds <= 160 * 1024, "LDS budget");
     static_assert(!(LIN && POOL), "the in-lane 2x2 max-pool needs the quad tiling");
     static_assert(256 % NGRP == 0, "weight groups must divide the CU count");
+    // patch loads address their sources with 32-bit byte offsets (conv16_run::unit_setup)
+    // and 24-bit pixel indices; the epilogue stores likewise
+    const size_t in_pix = (size_t)a.nimg * (KIND == DOWN ? 4 : 1) * H * W, out_pix = (size_t)a.nimg * (KIND == UPCONV ? 4 : 1) * H * W;
+    if (in_pix >= (1u << 24) || in_pix * (size_t)((a.cs0 ? a.cs0 : C0) * ES) >= (1ull << 32) ||
+        (C1 > 0 && in_pix * (size_t)((a.cs1 ? a.cs1 : C1) * ES) >= (1ull << 32)) ||
+        out_pix * COUT * 4 >= (1ull << 32)) return -7;
     const int units = a.nimg * (LIN ? (H * W + 15) / 16 : ((H + 3) / 4) * ((W + 3) / 4));   // per weight group
     int wgs = (units + NWV - 1) / NWV;                                // workgroups per weight group
     if (wgs > 256 / NGRP) wgs = 256 / NGRP;                           // one persistent workgroup per CU

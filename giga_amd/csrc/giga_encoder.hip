@@ -691,7 +691,11 @@ extern "C" int giga_debug_convin_trace(long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(giga::g_ci_trace), sizeof(long long) * 8 * 64) == hipSuccess ? 0 : -10;
 }
 extern "C" int giga_debug_conv_trace(int layer, long long* host_out) {
-    if (!host_out) return hipMemcpyToSymbol(HIP_SYMBOL(giga::g_conv_trace_layer), &layer, sizeof(int)) == hipSuccess ? 0 : -10;
+    if (!host_out) {                                  // select the layer and clear the previous layer's timeline
+        static const long long zeros[giga::CONV_NW * 64] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(giga::g_conv_trace), zeros, sizeof(zeros)) != hipSuccess) return -10;
+        return hipMemcpyToSymbol(HIP_SYMBOL(giga::g_conv_trace_layer), &layer, sizeof(int)) == hipSuccess ? 0 : -10;
+    }
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(giga::g_conv_trace), sizeof(long long) * giga::CONV_NW * 64) == hipSuccess ? 0 : -10;
 }
 #endif

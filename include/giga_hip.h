@@ -12,6 +12,8 @@
  *     re-entrant per (stream, workspace);
  *   - every launch is asynchronous on the caller's HIP stream `stream` (a hipStream_t);
  *   - return value 0 = success, negative = error (giga_strerror); nothing throws across the ABI;
+ *   - at most GIGA_MAX_SCENES scenes per encoder / training call (the convolution kernels address activations with
+ *     24-bit pixel indices and 32-bit byte offsets); larger batches return -7, split them;
  *   - `precision`: 0 = exact fp32 (v_mfma_f32_32x32x2_f32, bitwise fp32 fma chains),
  *                  1 = f16 operands / fp32 accumulate (v_mfma_f32_32x32x16_f16);
  *                  2 = f16x3 split operands / fp32 accumulate: every operand is the pair hi = f16(v), lo = f16(v - hi)
@@ -27,6 +29,8 @@
  */
 #ifndef GIGA_HIP_H_
 #define GIGA_HIP_H_
+
+#define GIGA_MAX_SCENES 3072
 
 #include <stddef.h>
 #include <stdint.h>
