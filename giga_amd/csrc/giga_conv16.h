@@ -308,11 +308,11 @@ __device__ __forceinline__ void conv16_run(const ConvArgs& a, uint8_t* smem, int
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t idx = pe[e] * COUT + co;
-                    if constexpr (KIND != UPCONV) {
+                    if constexpr (KIND != UPCONV && !RELU) {      // (the data-gradient convolutions have no activation of their own)
                         if (a.mask && !(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.mask) + idx * 4u) > 0.f))
                             v[e] = 0.f;
                     }
-                    *reinterpret_cast<T*>(out + idx * (uint32_t)ES) = (T)v[e];
+                    store_saddr(reinterpret_cast<T*>(out), idx * (uint32_t)ES, (T)v[e]);
                     if constexpr (KIND == CONV1) {
                         if (a.out_nchw) {
                             const uint32_t pin = pe[e] - img_pix;                      // y * W + x
@@ -323,7 +323,7 @@ __device__ __forceinline__ void conv16_run(const ConvArgs& a, uint8_t* smem, int
                 if (POOL) {
                     const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
                     const uint32_t pidx = ((uint32_t)img * (H / 2 * (W / 2)) + __umul24(qy >> 1, W / 2) + (qx >> 1)) * COUT + co;
-                    *reinterpret_cast<T*>(reinterpret_cast<char*>(a.out_pool) + pidx * (uint32_t)ES) = (T)mx;
+                    store_saddr(reinterpret_cast<T*>(a.out_pool), pidx * (uint32_t)ES, (T)mx);
                 }
             }
         }

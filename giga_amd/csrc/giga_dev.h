@@ -66,6 +66,12 @@ __device__ __forceinline__ void store_f32_saddr(float* uniform_base, unsigned by
     asm volatile("global_store_dword %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(uniform_base) : "memory");
 }
 
+__device__ __forceinline__ void store_f16_saddr(_Float16* uniform_base, unsigned byte_off, _Float16 v) {
+    asm volatile("global_store_short %0, %1, %2" : : "v"(byte_off), "v"(v), "s"(uniform_base) : "memory");
+}
+__device__ __forceinline__ void store_saddr(float* b, unsigned o, float v) { store_f32_saddr(b, o, v); }
+__device__ __forceinline__ void store_saddr(_Float16* b, unsigned o, _Float16 v) { store_f16_saddr(b, o, v); }
+
 // v_permlane32_swap / v_permlane16_swap (gfx950): a's upper half (odd 16-lane rows) <-> b's lower half (even rows); plain VALU,
 // no LDS.  Inline asm: the builtin's second result is mis-assigned by this compiler (both results alias the first operand).
 // The leading s_nop covers the VALU-write -> permlane-read hazard the compiler cannot see through the asm.
