@@ -44,6 +44,11 @@ def test_argument_validation_without_gpu():
     assert lib.giga_decoder_forward(None, None, None, 7, None, None, None, None, 0, 5, 0, 1, None) == 0
     assert lib.giga_decoder_forward(None, None, None, 7, None, None, None, None, 1, 5, 3, 1, None) == -5
     assert lib.giga_pack_weights(None, 0, 15, None, 0) == -1
+    # more than GIGA_MAX_SCENES scenes per call: refused before anything is enqueued (fake host addresses, never dereferenced)
+    fake = torch.zeros(4)
+    assert _capi.MAX_SCENES == 3072 and lib.giga_strerror(-7).startswith(b"more than GIGA_MAX_SCENES")
+    assert lib.giga_encoder_forward(_capi.ptr(fake), _capi.ptr(fake), _capi.ptr(fake), None, _capi.MAX_SCENES + 1, 0,
+                                    _capi.ptr(fake), 1 << 60, None) == -7
     flat = torch.zeros(10)
     with pytest.raises(_capi.GigaHipError):
         _capi.pack_weights(flat, 15)
