@@ -1,4 +1,4 @@
-"""Diagnostic: issue timeline of workgroup 0 of one U-Net layer (GIGA_TRACE build: GIGA_DIAG_LIB=giga_amd/lib/abl_trace.so).
+"""Diagnostic: issue timeline of workgroup 0 of one U-Net layer (GIGA_TRACE build: `make -C giga_amd/csrc trace`, GIGA_DIAG_LIB=giga_amd/lib/diag/libgiga_trace.so).
    python tools/gpu_conv_trace.py <layer 0..12> [...]"""
 import ctypes, os, sys
 import numpy as np
