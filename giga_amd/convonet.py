@@ -513,7 +513,7 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
         return self
 
     def set_persistent_unet(self, enabled=True):
-        """Opt in to the one-launch U-Net (GIGA_PERSIST_UNET, include/giga_hip.h): same results bit for bit, no launch gaps
+        """Opt in to the one-launch U-Net (GIGA_PERSIST_UNET, include/giga_hip.h): same results (bit for bit in the f16-class modes, to fp32 rounding in fp32), no launch gaps
         between the layers (-10 % encoder time in the f16-class modes at 8-32 scenes; nothing in fp32).  Only for processes
         that drive the device from ONE stream at a time: the kernel's per-XCD spin barriers need all of its workgroups
         co-resident, and two such launches in flight on two streams (or from two processes) can deadlock until the barrier

@@ -116,7 +116,8 @@ int giga_decoder_forward(const void* planes_nhwc, const float* p, const void* pa
 #define GIGA_FOLD_FINAL 16
 /* GIGA_PERSIST_UNET, OR-ed into `precision` of giga_encoder_forward*: run the U-Net layers as ONE persistent launch whose
  * layer boundaries are barriers among the 32 workgroups of each XCD (applies when 3 * B is a multiple of 8 on a 256-CU device;
- * ignored otherwise).  Same results bit for bit; removes the launch gaps between the layers (f16-class modes: -10 % encoder time
+ * ignored otherwise).  Same results bit for bit in the f16-class modes and to fp32 rounding (<= 2e-6 relative) in precision 0, where
+ * the summation order of a layer's ragged last round follows the work distribution; removes the launch gaps between the layers (f16-class modes: -10 % encoder time
  * at 8-32 scenes; fp32: nothing).  CALLER'S CONTRACT: no other launch carrying this flag may be in flight on the device at the
  * same time (other streams, other processes) -- the spin barriers need all 256 workgroups of the launch co-resident, and a
  * barrier that cannot complete traps after about a second.  One stream per device satisfies it trivially. */
