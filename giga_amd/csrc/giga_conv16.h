@@ -179,8 +179,8 @@ __device__ __forceinline__ void conv16_run(const ConvArgs& a, uint8_t* smem, int
     };
     // Patch loads.  fp32-input MFMAs do not co-execute with VALU work of any wave of the SIMD (DESIGN "fp32 MFMA and the
     // VALU"), so every VALU instruction of the loop is paid in MFMA time: the bounds tests and the pixel -> byte-offset
-    // arithmetic are done ONCE PER UNIT (unit_setup: 32-bit offsets from the tensor base; launch_conv refuses tensors of
-    // 2 GiB and more), a chunk's loads are `uniform base + per-lane offset` with no arithmetic at all, out-of-image lanes load
+    // arithmetic are done ONCE PER UNIT (unit_setup: 24-bit pixel indices, 32-bit byte offsets from the tensor base; launch_conv
+    // refuses tensors beyond that, GIGA_MAX_SCENES keeps callers inside), a chunk's loads are `uniform base + per-lane offset` with no arithmetic at all, out-of-image lanes load
     // from offset 0 and are simply not written to the patch, whose out-of-image cells are zeroed once per unit.
     uint4 stg[NLD];
     uint32_t st_b0[NLD], st_b1[C1 > 0 ? NLD : 1];      // byte offsets of this lane's vectors from in0 / in1 (0 if outside)
