@@ -193,6 +193,9 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
+    n0 = L.giga_launch_count()
+    step()
+    launches_per_step = int(L.giga_launch_count() - n0)       # kernels the library enqueues for one step (no profiler needed)
     ms = ctypes.c_float()
 
     def elapsed(a, b):
@@ -264,7 +267,7 @@ def main():
     def finish():                          # every rank leaves together: no rank tears the communicator down early
         if dist is not None:
             import threading
-            t = threading.Timer(60.0, lambda: os._exit(0))   # (a rank that died must not keep the others here for ever)
+            t = threading.Timer(60.0, lambda: os._exit(3))   # (a rank that died must not keep the others here for ever; rc != 0)
             t.daemon = True
             t.start()
             dist.barrier()
@@ -273,7 +276,8 @@ def main():
 
     # The contract line is assembled BEFORE the multi-GPU extras run, and a watchdog prints it if they hang: a collective
     # that one rank never enters (an exception elsewhere, a wedged RCCL ring) must not cost the scaling run its numbers.
-    out = core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, dec_occ_ms, dom, dom_ms, step_ms, named_ms, bracket_ms) if rank == 0 else None
+    out = core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, dec_occ_ms, dom, dom_ms, step_ms, named_ms, bracket_ms,
+                      launches_per_step) if rank == 0 else None
     extra = dict(multi)
     if dist is not None and not args.no_extra:
         import threading
@@ -282,8 +286,9 @@ def main():
             if rank == 0:
                 extra["multi_gpu_extras"] = "timed out after 240 s (a collective did not complete); core numbers are unaffected"
                 out["extra"] = extra
+                out["error"] = "watchdog: a multi-GPU extra (c3 gather / data-parallel step) hung; the process exits with rc 4"
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(4)                                      # a hang is a failure: never report rc 0
 
         dog = threading.Timer(240.0, bail)
         dog.daemon = True
@@ -337,7 +342,8 @@ def main():
     finish()
 
 
-def core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, dec_occ_ms, dom, dom_ms, step_ms, named_ms, bracket_ms):
+def core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, dec_occ_ms, dom, dom_ms, step_ms, named_ms, bracket_ms,
+                launches_per_step=None):
     """The contract keys + roofline of the timed region (rank 0)."""
     # HBM bytes per launch: PMC counters cannot be collected from inside this process, so they come from the committed
     # rocprofv3 PMC table of the same workload (tools/gpu_traffic.sh -> profiles/*traffic_c2.json), stamped with the commit
@@ -361,6 +367,14 @@ def core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, d
                       ("decoder.occupancy(2048 queries)", dec_occ_ms, B * M * FLOP_HEAD["tsdf"])):
         stages[nm] = {"ms": round(v, 4), "gflop": round(fl / 1e9, 3), "share_of_step": round(v / step_total, 3),
                       "frac_of_fp32_mfma_peak": round(fl / (v * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 3)}
+    named = [(k, v) for k, v in stages.items() if v["frac_of_fp32_mfma_peak"] is not None]
+    big = [(k, v) for k, v in named if v["share_of_step"] >= 0.08]
+    wk, wv = min(big or named, key=lambda kv: kv[1]["frac_of_fp32_mfma_peak"])
+    worst_stage = {"kernel": wk, "frac": wv["frac_of_fp32_mfma_peak"], "share_of_step": wv["share_of_step"], "ms": wv["ms"],
+                   "note": "lowest fraction of the fp32-MFMA peak among the stages with >= 8 % of the step"}
+    ak, av = max(stages.items(), key=lambda kv: kv[1]["ms"])
+    argmax_stage = {"kernel": ak, "ms": av["ms"], "frac": av["frac_of_fp32_mfma_peak"]}
+    step_flops = sum(v["gflop"] for v in stages.values()) * 1e9
     out = {
         "metric": "scenes/sec",
         "value": scenes_per_s,
@@ -397,7 +411,13 @@ def core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, d
                            "median_launch_ms": float(np.median(named_ms)), "flops_per_launch": named_flops,
                            "traffic": named_traffic, "traffic_source": named_src},
             "stages": stages,
+            # The roofline kernel above is the LONGEST launch, which is also the best-tuned one.  Beside it: the true argmax
+            # of the measured stage times, the stage FURTHEST below the roofline among those that take >= 8 % of the step,
+            # and the FLOP-weighted fraction of the whole step (sum of algorithmic FLOPs / sum of stage times).
+            "argmax_stage": argmax_stage, "worst_stage": worst_stage,
+            "step_frac_flop_weighted": step_flops / (step_total * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS,
         },
+        "launches_per_step": launches_per_step,
         "stage_note": "unet.conv_final is not launched in this call: the 1x1 convolution is folded into the heads' fc_c weights "
                       "(GIGA_FOLD_FINAL); its entry is the empty event bracket",
     }
@@ -490,8 +510,9 @@ def _time_steps(fn, steps, warm):
 
 
 def bench_c4(net, dev, L, _capi, synth, decode_heads, prec, Bc=32, steps=10):
-    """c4: Bc scenes x the 64 000-point inference lattice, three grasp heads, decoder precision `prec` ('fp16': f16
-    encoder + f16 decoder; 'fp16x3': fp32 encoder + split-operand f16 decoder, fp32-grade results)."""
+    """c4: Bc scenes x the 64 000-point inference lattice, three grasp heads, encoder AND decoder in precision `prec`
+    ('fp16': f16 operands; 'fp16x3': split-operand f16 MFMA in conv_in, the U-Net and the decoder, fp32-grade results).
+    After the timed region the first scene of the step's own output is checked against the CPU oracle."""
     N = 64000
     net.set_precision(prec)
     blob = net.packed_blob(dev)
@@ -523,6 +544,7 @@ def bench_c4(net, dev, L, _capi, synth, decode_heads, prec, Bc=32, steps=10):
         dms.append(ms.value)
         L.giga_event_destroy(a); L.giga_event_destroy(b)
     dec_ms = float(np.median(dms))
+    checked = check_c4_scene(step(), prec, synth)           # (untimed) this leg's own output, scene 0, against the oracle
     bracket_ms = empty_bracket_ms(L, _capi, dev)
     flops = Bc * N * FLOP_GRASP3
     ach = flops / (dec_ms * 1e-3) / 1e12
@@ -543,13 +565,37 @@ def bench_c4(net, dev, L, _capi, synth, decode_heads, prec, Bc=32, steps=10):
                         "tile and head instead of 58, so the matrix pipe is busy with issued_mfma_tflops")
     return {
         "workload": f"c4: batch={Bc} scenes x the 64000-point inference lattice, 3 grasp heads, "
-                    + ("f16x3 split-operand f16-MFMA decoder (fp32-grade, <= 6e-6 vs oracle) + fp32 encoder" if split else
+                    + ("f16x3 split-operand f16-MFMA encoder and decoder (fp32-grade, <= 6e-6 vs oracle)" if split else
                        "f16 MFMA decoder (lattice path) + f16 encoder"),
+        "checked_vs_oracle": checked,
         "scenes_per_sec": Bc * steps / el, "query_points_per_sec": Bc * steps * N / el,
         "ms_per_step": el / steps * 1e3, "step_ms_median": float(np.median(per_step)), "step_ms_max": float(np.max(per_step)),
         "dtype": "f16x3 split operands / f32 accumulate" if split else "f16 operands / f32 accumulate",
         "roofline": roof,
     }
+
+
+_C4_ORACLE = {}
+C4_TOL = {"fp32": 1e-4, "fp16x3": 1e-4, "fp16": 1e-2}       # the tolerances of tests/test_gpu_c4_shapes.py (width: x2)
+
+
+def check_c4_scene(out, prec, synth):
+    """The oracle as the CHECKER of what the c4 legs time: scene 0 of the batch (synthetic scene 1000) on the 64 000-point
+    lattice, qual / rot / width of the step's own output against `O.model_forward`.  Raises if out of tolerance."""
+    from oracle import giga_oracle as O
+    from giga_amd import weights
+    if "ref" not in _C4_ORACLE:
+        with torch.no_grad():
+            _C4_ORACLE["ref"] = O.model_forward(weights.make_state_dict(7), torch.from_numpy(synth.tsdf_batch(1000, 1)),
+                                                O.inference_lattice())
+    errs = {}
+    for name, key, scale in (("qual", "decoder_qual", 1.0), ("rot", "decoder_rot", 1.0), ("width", "decoder_width", 2.0)):
+        got = out[key][0:1].float().cpu()
+        e = float((got - _C4_ORACLE["ref"][("qual", "rot", "width").index(name)]).abs().max())
+        errs[name] = e
+        if not e < C4_TOL[prec] * scale:
+            raise AssertionError(f"c4 {prec}: {name} of scene 0 is {e:.3e} off the oracle (tolerance {C4_TOL[prec] * scale:.0e})")
+    return {"scene": 1000, "points": 64000, "max_abs_err": errs, "tolerance": C4_TOL[prec]}
 
 
 def bench_c4_all(net, dev, L, _capi, synth, decode_heads):
@@ -570,7 +616,8 @@ def bench_c4_all(net, dev, L, _capi, synth, decode_heads):
                           "decoder_ms": r["roofline"]["avg_launch_ms"], "decoder_tflops": r["roofline"]["achieved"],
                           "decoder_frac_of_f16_mfma_peak": r["roofline"]["frac"],
                           "empty_event_bracket_ms": r["roofline"]["empty_event_bracket_ms"],
-                          "decoder_frac_net_of_bracket": r["roofline"]["frac_net_of_bracket"]})
+                          "decoder_frac_net_of_bracket": r["roofline"]["frac_net_of_bracket"],
+                          "checked_vs_oracle_max_abs_err": r["checked_vs_oracle"]["max_abs_err"]})
         out[key + "_sweep"] = sweep
     return out
 

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "giga_adam_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                       ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int,
                                       ctypes.c_void_p]),
+    "giga_launch_count": (ctypes.c_ulonglong, []),
     "giga_event_create": (ctypes.c_void_p, []),
     "giga_event_destroy": (None, [ctypes.c_void_p]),
     "giga_event_record": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

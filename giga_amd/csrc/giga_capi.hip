@@ -1,5 +1,6 @@
 // extern "C" entry points of libgiga_hip.so (declared in include/giga_hip.h).
 #include <hip/hip_runtime.h>
+#include "giga_launch.h"
 
 #include "../../include/giga_hip.h"
 #include "giga_layout.h"
@@ -47,6 +48,8 @@ int launch_planes_unpack(const void* src, float* dst, int B, int precision, hipS
 }  // namespace giga
 
 using namespace giga;
+
+std::atomic<unsigned long long> giga::g_launch_count{0};
 
 // byte offset of head h's weight image for a precision (0 fp32, 1 f16, 2 f16x3 split), plain or with conv_final folded in
 static size_t head_image_offset(const PackOff& ko, int h, int precision, bool fold) {
@@ -98,7 +101,7 @@ int giga_derive_bf16_fragments(void* packed_dev, void* bwd_packed_dev, void* str
     }
     r.first[2 * NCONV] = at;
     r.n = 2 * NCONV;
-    hipLaunchKernelGGL(derive_bf16_kernel, dim3(at), dim3(64), 0, static_cast<hipStream_t>(stream),
+    GIGA_LAUNCH(derive_bf16_kernel, dim3(at), dim3(64), 0, static_cast<hipStream_t>(stream),
                        static_cast<uint8_t*>(packed_dev), static_cast<uint8_t*>(bwd_packed_dev), r);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
@@ -140,7 +143,7 @@ int giga_repack_device(const float* params_dev, const int32_t* map_dev, void* pa
                        void* stream) {
     if (!params_dev || !map_dev || !packed_dev) return -1;
     if (nwords == 0) return 0;
-    hipLaunchKernelGGL(repack_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0,
+    GIGA_LAUNCH(repack_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), params_dev, map_dev, static_cast<float*>(packed_dev), nwords);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
@@ -184,6 +187,8 @@ int giga_encoder_forward(const float* tsdf, const void* packed, void* planes_nhw
     return giga_encoder_forward_probe(tsdf, packed, planes_nhwc, planes_nchw, B, precision, workspace,
                                       workspace_bytes, stream, -1, nullptr, nullptr);
 }
+
+unsigned long long giga_launch_count(void) { return g_launch_count.load(std::memory_order_relaxed); }
 
 void* giga_event_create(void) {
     hipEvent_t e = nullptr;
@@ -415,6 +420,9 @@ int giga_adam_step(float* params, const float* grads, float* exp_avg, float* exp
     if (n == 0) return 0;
     if (!params || !grads || !exp_avg || !exp_avg_sq || step < 1) return -1;
     if (!(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0)) return -1;
+    // the kernel moves float4: all four buffers must be 16-byte aligned (whole torch allocations are; a view at an odd offset is not)
+    if ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(exp_avg) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) return -1;
     return launch_adam_flat(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step,
                             static_cast<hipStream_t>(stream));
 }

@@ -538,8 +538,8 @@ inline int launch_conv(const ConvArgs& a, hipStream_t s) {
     if (wgs > 256 / NGRP) wgs = 256 / NGRP;                           // one persistent workgroup per CU
     auto kern = conv16_kernel<T, KIND, C0, C1, COUT, H, W, NB, POOL, RELU, MATH>;
     if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(wgs * NGRP), dim3(NWV * 64), lds, s, a);
+        giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
+    GIGA_LAUNCH(kern, dim3(wgs * NGRP), dim3(NWV * 64), lds, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 

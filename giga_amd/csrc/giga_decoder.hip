@@ -923,8 +923,8 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
             if (slots > cap) slots = tiles >= 8LL * cap * per_round ? cap8 : cap;
             else if (slots >= 8 && tiles >= 8LL * slots) slots &= ~7;
             a.nbatch = slots;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, dim3(slots * a.nheads), dim3(NW * 64), lds, s, a);
+            giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
+            GIGA_LAUNCH(kern, dim3(slots * a.nheads), dim3(NW * 64), lds, s, a);
         };
         if (precision == 2) {
             constexpr int NW = 8;
@@ -943,17 +943,15 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
         a.nbatch = (int)((tiles + NW * T - 1) / (NW * T));
         const int grid = a.nbatch < 256 ? a.nbatch : 256;      // one persistent workgroup per CU
         auto kern = decoder_f16_kernel<T, true, NW>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(2 * DEC16_BYTES));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), 2 * DEC16_BYTES, s, a);
+        giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)(2 * DEC16_BYTES));
+        GIGA_LAUNCH(kern, dim3(grid), dim3(NW * 64), 2 * DEC16_BYTES, s, a);
     } else if (precision == 1) {
         constexpr int T = 2, NW = 8;
         a.nbatch = (int)((tiles + NW * T - 1) / (NW * T));
         const int grid = a.nbatch < 256 ? a.nbatch : 256;      // one persistent workgroup per CU
         auto kern = decoder_f16_kernel<T, false, NW>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(2 * DEC16_BYTES));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), 2 * DEC16_BYTES, s, a);
+        giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)(2 * DEC16_BYTES));
+        GIGA_LAUNCH(kern, dim3(grid), dim3(NW * 64), 2 * DEC16_BYTES, s, a);
     } else if (tiles >= 2 * 4 * 256) {
         // enough work for two tiles per wave on every CU: the 111 KiB weight image is staged half as often
         constexpr int T = 2;
@@ -961,9 +959,8 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
         const int grid = a.nbatch < 256 ? a.nbatch : 256;
         auto kern = lat ? decoder_f32_kernel<T, true> : decoder_f32_kernel<T, false>;
         a.heads_per_wg = a.nheads;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)DEC32_LDS);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), DEC32_LDS, s, a);
+        giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)DEC32_LDS);
+        GIGA_LAUNCH(kern, dim3(grid), dim3(256), DEC32_LDS, s, a);
     } else {
         constexpr int T = 1;
         a.nbatch = (int)((tiles + 4 * T - 1) / (4 * T));
@@ -972,9 +969,8 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
         // when the point batches cannot fill the chip, give every head its own workgroups
         const bool split = grid * a.nheads <= 256;
         a.heads_per_wg = split ? 1 : a.nheads;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)DEC32_LDS);
-        hipLaunchKernelGGL(kern, dim3(grid, split ? a.nheads : 1), dim3(256), DEC32_LDS, s, a);
+        giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)DEC32_LDS);
+        GIGA_LAUNCH(kern, dim3(grid, split ? a.nheads : 1), dim3(256), DEC32_LDS, s, a);
     }
     if (ev0 && ev1) (void)hipEventRecord(static_cast<hipEvent_t>(ev1), s);
     return hipGetLastError() == hipSuccess ? 0 : -10;
@@ -986,13 +982,13 @@ int launch_lattice_resample(const void* planes, const float* lin, void* out, int
     if (total <= 0) return 0;
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (precision == 2)
-        hipLaunchKernelGGL(lattice_resample_split_kernel, dim3(grid), dim3(256), 0, s,
+        GIGA_LAUNCH(lattice_resample_split_kernel, dim3(grid), dim3(256), 0, s,
                            reinterpret_cast<const float*>(planes), lin, reinterpret_cast<half_t*>(out), B, R);
     else if (precision == 1)
-        hipLaunchKernelGGL(lattice_resample_kernel<half_t>, dim3(grid), dim3(256), 0, s,
+        GIGA_LAUNCH(lattice_resample_kernel<half_t>, dim3(grid), dim3(256), 0, s,
                            reinterpret_cast<const half_t*>(planes), lin, reinterpret_cast<half_t*>(out), B, R);
     else
-        hipLaunchKernelGGL(lattice_resample_kernel<float>, dim3(grid), dim3(256), 0, s,
+        GIGA_LAUNCH(lattice_resample_kernel<float>, dim3(grid), dim3(256), 0, s,
                            reinterpret_cast<const float*>(planes), lin, reinterpret_cast<float*>(out), B, R);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
@@ -1001,10 +997,10 @@ int launch_planes_pack(const float* xz, const float* xy, const float* yz, void* 
                        hipStream_t s) {
     if (B <= 0) return 0;
     if (precision == 1)
-        hipLaunchKernelGGL(planes_nchw_to_nhwc_kernel<half_t>, dim3(3 * B * RES), dim3(256), 0, s, xz, xy, yz,
+        GIGA_LAUNCH(planes_nchw_to_nhwc_kernel<half_t>, dim3(3 * B * RES), dim3(256), 0, s, xz, xy, yz,
                            reinterpret_cast<half_t*>(dst), B);
     else
-        hipLaunchKernelGGL(planes_nchw_to_nhwc_kernel<float>, dim3(3 * B * RES), dim3(256), 0, s, xz, xy, yz,
+        GIGA_LAUNCH(planes_nchw_to_nhwc_kernel<float>, dim3(3 * B * RES), dim3(256), 0, s, xz, xy, yz,
                            reinterpret_cast<float*>(dst), B);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
@@ -1012,10 +1008,10 @@ int launch_planes_pack(const float* xz, const float* xy, const float* yz, void* 
 int launch_planes_unpack(const void* src, float* dst, int B, int precision, hipStream_t s) {
     if (B <= 0) return 0;
     if (precision == 1)
-        hipLaunchKernelGGL(planes_nhwc_to_nchw_kernel<half_t>, dim3(3 * B * RES), dim3(256), 0, s,
+        GIGA_LAUNCH(planes_nhwc_to_nchw_kernel<half_t>, dim3(3 * B * RES), dim3(256), 0, s,
                            reinterpret_cast<const half_t*>(src), dst);
     else
-        hipLaunchKernelGGL(planes_nhwc_to_nchw_kernel<float>, dim3(3 * B * RES), dim3(256), 0, s,
+        GIGA_LAUNCH(planes_nhwc_to_nchw_kernel<float>, dim3(3 * B * RES), dim3(256), 0, s,
                            reinterpret_cast<const float*>(src), dst);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }

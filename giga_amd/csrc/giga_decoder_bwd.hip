@@ -425,9 +425,8 @@ int launch_decoder_backward(const float* planes, const float* p, const uint8_t* 
     const bool split = grid * a.nheads <= 256;                  // the point batches alone cannot fill the chip
     a.heads_per_wg = split ? 1 : a.nheads;
     const size_t lds = DEC32_BYTES > DECB_BYTES ? DEC32_BYTES : DECB_BYTES;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    hipLaunchKernelGGL(decoder_bwd_kernel, dim3(grid, split ? a.nheads : 1), dim3(256), lds, s, a);
+    giga::dyn_lds_once(reinterpret_cast<const void*>(decoder_bwd_kernel), (int)lds);
+    GIGA_LAUNCH(decoder_bwd_kernel, dim3(grid, split ? a.nheads : 1), dim3(256), lds, s, a);
     // weight / bias gradients: one launch per head
     for (int hh = 0; hh < a.nheads; ++hh) {
         const int h = a.head_id[hh];
@@ -458,7 +457,7 @@ int launch_decoder_backward(const float* planes, const float* p, const uint8_t* 
         L.pts_per_block = (int)ppb;
         ksplit = (int)((P + ppb - 1) / ppb);
         L.ksplit = ksplit;
-        hipLaunchKernelGGL(linear_wgrad_kernel, dim3(L.nb_total * ksplit), dim3(256), 0, s, L);
+        GIGA_LAUNCH(linear_wgrad_kernel, dim3(L.nb_total * ksplit), dim3(256), 0, s, L);
     }
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "giga_layout.h"
+#include "giga_launch.h"
 
 namespace giga {
 

@@ -505,6 +505,11 @@ template <typename T, int MATH>
 __global__ __launch_bounds__(MEGA_NW * 64) void unet_mega_kernel(MegaArgs m) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int xcd = (int)blockIdx.x & 7, block = (int)blockIdx.x >> 3, nblocks = (int)gridDim.x >> 3;
+    // The barriers below are XCD-local (workgroup-scope atomics, no agent-scope release / acquire): they are only correct if
+    // the workgroups that share a counter share an L2, i.e. if workgroup i really runs on XCD i % 8.  That is the observed
+    // dispatch order, not a contract (CU masks, partition modes, a new dispatcher): check it against the hardware register and
+    // fail loudly instead of returning stale activations.
+    if ((__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15) != xcd) __builtin_trap();      // HW_REG_XCC_ID[3:0]
     const int per = m.layer[0].nimg >> 3, img0 = xcd * per;                 // (the host guarantees nimg % 8 == 0)
     unsigned* counter = m.sync + xcd * 32;
     unsigned epoch = 0;
@@ -581,18 +586,18 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     if (nxp == 1) {
         auto kern = convin_project_kernel<T, RES / NW, CI_F16, NW, CI_LO>;
         constexpr size_t lds = ci_lds_bytes(RES, NW);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(8 * B), dim3(NW * 64), lds, s, tsdf, cw, cb, P0, XZP, YZP, B);
+        giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
+        GIGA_LAUNCH(kern, dim3(8 * B), dim3(NW * 64), lds, s, tsdf, cw, cb, P0, XZP, YZP, B);
     } else {
         auto kern = convin_project_kernel<T, 8 / NW, CI_F16, NW, CI_LO>;
         constexpr size_t lds = ci_lds_bytes(8, NW);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(5, 8, B), dim3(NW * 64), lds, s, tsdf, cw, cb, P0, XZP, YZP, B);
+        giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
+        GIGA_LAUNCH(kern, dim3(5, 8, B), dim3(NW * 64), lds, s, tsdf, cw, cb, P0, XZP, YZP, B);
     }
     post();
     {
         pre();
-        hipLaunchKernelGGL(plane_finalize_kernel<T>, dim3((unsigned)((per / 4 + 255) / 256)), dim3(256), 0, s, XZP, YZP, P0, B,
+        GIGA_LAUNCH(plane_finalize_kernel<T>, dim3((unsigned)((per / 4 + 255) / 256)), dim3(256), 0, s, XZP, YZP, P0, B,
                            nxp);
         post();
     }
@@ -634,7 +639,7 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     // need all 256 workgroups co-resident: two such kernels started concurrently from two streams can each hold part of the CUs
     // and wait for the rest (the barrier then traps after ~1 s); whoever sets the flag vouches that this cannot happen.
     static const bool env_persist = [] { const char* e = getenv("GIGA_UNET_PERSIST"); return e && atoi(e) != 0; }();
-    static const bool full_device = [] {
+    const bool full_device = [] {                             // per call: the CURRENT device (a process may drive several)
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess) return false;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
@@ -651,10 +656,10 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
         auto kern = unet_mega_kernel<T, MATH>;
         constexpr size_t lds = mega_lds_bytes<T, MATH>();
         static_assert(lds <= 160 * 1024, "LDS budget of the persistent U-Net kernel");
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
         stage_no = 15;                                        // probe stage 15 = the whole U-Net
         pre();
-        hipLaunchKernelGGL(kern, dim3(256), dim3(MEGA_NW * 64), lds, s, m);
+        GIGA_LAUNCH(kern, dim3(256), dim3(MEGA_NW * 64), lds, s, m);
         post();
         return hipGetLastError() == hipSuccess ? 0 : -10;
     }

@@ -161,7 +161,7 @@ static int launch_wgrad(WgradArgs a, hipStream_t s) {
     if (ppb < 32) ppb = 32;
     a.pix_per_block = (int)ppb;
     ksplit = (int)((a.npix + ppb - 1) / ppb);
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(blocks_wn * ksplit), dim3(256), 0, s, a);
+    GIGA_LAUNCH(conv_wgrad_kernel, dim3(blocks_wn * ksplit), dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
@@ -417,10 +417,10 @@ static int launch_wgrad3(const Wgrad3Args& a, hipStream_t s) {
     int gx = 256 / NY;
     if (gx > nstrips) gx = nstrips;
     auto kern = conv3_wgrad_kernel<C0, C1, COUT, H, RS>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(gx, NY), dim3(512), lds, s, a);
+    giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
+    GIGA_LAUNCH(kern, dim3(gx, NY), dim3(512), lds, s, a);
     constexpr int NZ = NBLK >= 8 ? 1 : 8 / NBLK;                 // >= 288 reducing workgroups for every layer
-    hipLaunchKernelGGL((wgrad3_reduce_kernel<CIN, BPG, NZ>), dim3(9 * 1024 / 256 + 1, NBLK, NZ), dim3(256), 0, s, a.partial, gx,
+    GIGA_LAUNCH((wgrad3_reduce_kernel<CIN, BPG, NZ>), dim3(9 * 1024 / 256 + 1, NBLK, NZ), dim3(256), 0, s, a.partial, gx,
                        a.dW, a.db, COUT, NY);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
@@ -607,10 +607,10 @@ static int launch_wgrad3_bf16(const Wgrad3Args& a, hipStream_t s) {
     int gx = 256 / NY;
     if (gx > nstrips) gx = nstrips;
     auto kern = conv3_wgrad_bf16_kernel<C0, C1, COUT, H, RS>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(gx, NY), dim3(512), lds, s, a);
+    giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
+    GIGA_LAUNCH(kern, dim3(gx, NY), dim3(512), lds, s, a);
     constexpr int NZ = NBLK >= 8 ? 1 : 8 / NBLK;
-    hipLaunchKernelGGL((wgrad3_reduce_kernel<CIN, BPG, NZ>), dim3(9 * 1024 / 256 + 1, NBLK, NZ), dim3(256), 0, s, a.partial, gx,
+    GIGA_LAUNCH((wgrad3_reduce_kernel<CIN, BPG, NZ>), dim3(9 * 1024 / 256 + 1, NBLK, NZ), dim3(256), 0, s, a.partial, gx,
                        a.dW, a.db, COUT, NY);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
@@ -818,7 +818,7 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
     auto G = [&](size_t off) { return reinterpret_cast<float*>(gws + off); };
     int rc = 0;
     auto colsum = [&](const float* grad, int cs, int coff, int C, size_t rows, int layer) {
-        hipLaunchKernelGGL(colsum_kernel, dim3(128), dim3(256), 0, s, grad, cs, coff, C, rows, grads + po.conv_b[layer]);
+        GIGA_LAUNCH(colsum_kernel, dim3(128), dim3(256), 0, s, grad, cs, coff, C, rows, grads + po.conv_b[layer]);
     };
     // weight gradient of layer l: R = dPre (channels = cout), columns = layer input (in0 [, in1])
     auto wgrad3 = [&](int l, const float* dpre, const float* in0, const float* in1, int H) {
@@ -902,7 +902,7 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
     // pool1 + skip: dS1 = gC0[..., 64:128] + unpool(dQ1)
     {
         const size_t tot = n20 * 64;
-        hipLaunchKernelGGL(pool_bwd_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, G(g.gS1),
+        GIGA_LAUNCH(pool_bwd_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, G(g.gS1),
                            G(g.gC0), 128, 64, G(g.gQ1), F(f.S1), F(f.Q1), nimg, 20, 20, 64);
     }
     // L3 down1.conv2: A1 -> S1
@@ -914,7 +914,7 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
     // pool0 + skip: dS0 = gC1[..., 32:64] + unpool(dQ0)
     {
         const size_t tot = n40 * 32;
-        hipLaunchKernelGGL(pool_bwd_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, G(g.gS0),
+        GIGA_LAUNCH(pool_bwd_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, G(g.gS0),
                            G(g.gC1), 64, 32, G(g.gQ0), F(f.S0), F(f.Q0), nimg, 40, 40, 32);
     }
     // L1 down0.conv2: A0 -> S0
@@ -931,16 +931,14 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
         float* part = G(g.WG);                        // free again: the 3x3 weight gradients are done
         if (nxp == 1) {
             auto kern = convin_bwd_kernel<5>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)cb_lds_bytes(5));
-            hipLaunchKernelGGL(kern, dim3(1, 8, B), dim3(512), cb_lds_bytes(5), s, tsdf, cw, cb, G(g.gP0), part, B);
+            giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)cb_lds_bytes(5));
+            GIGA_LAUNCH(kern, dim3(1, 8, B), dim3(512), cb_lds_bytes(5), s, tsdf, cw, cb, G(g.gP0), part, B);
         } else {
             auto kern = convin_bwd_kernel<1>;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)cb_lds_bytes(1));
-            hipLaunchKernelGGL(kern, dim3(5, 8, B), dim3(512), cb_lds_bytes(1), s, tsdf, cw, cb, G(g.gP0), part, B);
+            giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)cb_lds_bytes(1));
+            GIGA_LAUNCH(kern, dim3(5, 8, B), dim3(512), cb_lds_bytes(1), s, tsdf, cw, cb, G(g.gP0), part, B);
         }
-        hipLaunchKernelGGL(convin_bwd_reduce_kernel, dim3(CB_PART, 2), dim3(256), 0, s, part, B, nxp, grads + po.conv_in_w,
+        GIGA_LAUNCH(convin_bwd_reduce_kernel, dim3(CB_PART, 2), dim3(256), 0, s, part, B, nxp, grads + po.conv_in_w,
                            grads + po.conv_in_b);
     }
     if (hipGetLastError() != hipSuccess) rc |= -10;

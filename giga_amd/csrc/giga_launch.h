@@ -1,0 +1,41 @@
+// Every kernel launch of the library goes through GIGA_LAUNCH, which also counts it: `giga_launch_count()` (C ABI,
+// measurement hook) lets bench.py report launches per step without a profiler attached.  The counter is the library's only
+// process-wide mutable word; it is never read by the compute path.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdint>
+
+namespace giga {
+extern std::atomic<unsigned long long> g_launch_count;      // defined in giga_capi.hip
+}
+namespace giga {
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) ONCE per (kernel, device) instead of before every launch: the call takes a
+// runtime lock and a code-object lookup, host time that a launch-bound caller (a single-scene plan: ~17 launches of a few
+// microseconds each) pays on every kernel.  Lock-free table keyed by the kernel's host address and the current device.
+inline void dyn_lds_once(const void* kern, int bytes) {
+    constexpr unsigned N = 1024;                             // >> number of kernel instantiations x devices
+    static std::atomic<uintptr_t> keys[N];
+    static std::atomic<int> vals[N];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uintptr_t key = reinterpret_cast<uintptr_t>(kern) * 64u + (uintptr_t)(dev & 63) + 1u;
+    unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 54) & (N - 1);
+    for (unsigned probe = 0; probe < N; ++probe, h = (h + 1) & (N - 1)) {
+        uintptr_t k = keys[h].load(std::memory_order_acquire);
+        if (k == key) {
+            if (vals[h].load(std::memory_order_relaxed) >= bytes) return;
+            break;                                           // a larger request than recorded: set again below
+        }
+        if (k == 0) {
+            uintptr_t expect = 0;
+            if (keys[h].compare_exchange_strong(expect, key, std::memory_order_acq_rel) || expect == key) break;
+        }
+    }
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (keys[h].load(std::memory_order_relaxed) == key) vals[h].store(bytes, std::memory_order_relaxed);
+}
+}  // namespace giga
+#define GIGA_LAUNCH(...) \
+    do { ::giga::g_launch_count.fetch_add(1, std::memory_order_relaxed); hipLaunchKernelGGL(__VA_ARGS__); } while (0)

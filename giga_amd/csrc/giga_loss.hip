@@ -14,6 +14,7 @@
 // the BCE gradient (p - y) / max(p (1 - p), 1e-12)) so that losses and gradients agree with autograd through the
 // reference's helpers to fp32 rounding (tests/test_gpu_training.py, golden G11).
 #include <hip/hip_runtime.h>
+#include "giga_launch.h"
 #include <cmath>
 
 namespace giga {
@@ -110,9 +111,9 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
 int launch_train_loss(const float* qual, const float* rot, const float* width, const float* occ, const float* label,
                       const float* rot_t, const float* width_t, const float* occ_t, int B, int M, float* losses,
                       float* scene_loss, hipStream_t s) {
-    hipLaunchKernelGGL(loss_scene_kernel, dim3(B), dim3(256), 0, s, qual, rot, width, occ, label, rot_t, width_t, occ_t, M,
+    GIGA_LAUNCH(loss_scene_kernel, dim3(B), dim3(256), 0, s, qual, rot, width, occ, label, rot_t, width_t, occ_t, M,
                        scene_loss);
-    hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(64), 0, s, scene_loss, B, losses);
+    GIGA_LAUNCH(loss_mean_kernel, dim3(1), dim3(64), 0, s, scene_loss, B, losses);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
@@ -120,7 +121,7 @@ int launch_train_loss_backward(const float* qual, const float* rot, const float*
                                const float* label, const float* rot_t, const float* width_t, const float* occ_t,
                                const float* gout, int B, int M, float* dqual, float* drot, float* dwidth, float* docc,
                                hipStream_t s) {
-    hipLaunchKernelGGL(loss_grad_kernel, dim3(B), dim3(256), 0, s, qual, rot, width, occ, label, rot_t, width_t, occ_t, gout,
+    GIGA_LAUNCH(loss_grad_kernel, dim3(B), dim3(256), 0, s, qual, rot, width, occ, label, rot_t, width_t, occ_t, gout,
                        B, M, dqual, drot, dwidth, docc);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
@@ -161,7 +162,7 @@ int launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, dou
     if (n == 0) return 0;
     const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);     // (hyper-parameters stay double on the host, as in torch)
     const size_t n4 = n / 4;
-    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((n4 + 1 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<float4*>(p),
+    GIGA_LAUNCH(adam_flat_kernel, dim3((unsigned)((n4 + 1 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<float4*>(p),
                        reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v), n4, n,
                        (float)(lr / bc1), (float)b2, (float)(1.0 - b1), (float)(1.0 - b2), (float)eps, (float)wd, (float)sqrt(bc2));
     return hipGetLastError() == hipSuccess ? 0 : -10;

@@ -12,6 +12,7 @@
 // accumulation in the symmetric-pair order, rounding to float32 after every axis) so that the thresholded
 // selection is reproducible against the reference.
 #include <hip/hip_runtime.h>
+#include "giga_launch.h"
 
 #include "../../include/giga_hip.h"
 
@@ -192,9 +193,9 @@ extern "C" int giga_grasp_select(const float* tsdf, const float* qual, const flo
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemsetAsync(counters, 0, sizeof(int) * 2 * B, s) != hipSuccess) return -10;
     const dim3 grid((R * R * R + 255) / 256, B);
-    hipLaunchKernelGGL(post_gauss_kernel<0>, grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(post_gauss_kernel<1>, grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(post_mask_kernel, grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(post_nms_kernel, grid, dim3(256), 0, s, a);
+    GIGA_LAUNCH(post_gauss_kernel<0>, grid, dim3(256), 0, s, a);
+    GIGA_LAUNCH(post_gauss_kernel<1>, grid, dim3(256), 0, s, a);
+    GIGA_LAUNCH(post_mask_kernel, grid, dim3(256), 0, s, a);
+    GIGA_LAUNCH(post_nms_kernel, grid, dim3(256), 0, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }

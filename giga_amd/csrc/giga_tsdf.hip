@@ -8,6 +8,7 @@
 // cell the highest list position that targets it (atomicMax on an int32 grid), pass 2 lets exactly that voxel write.
 // Indices outside [0, R) are ignored on the device (numpy would raise; the Python wrapper checks host-side inputs).
 #include <hip/hip_runtime.h>
+#include "giga_launch.h"
 #include <cstdint>
 
 namespace giga {
@@ -51,8 +52,8 @@ int launch_tsdf_scatter(const int* index, const float* value, const int* offsets
     if (n <= 0) return 0;
     if (hipMemsetAsync(winner, 0xFF, cells * sizeof(int), s) != hipSuccess) return -10;      // -1 everywhere
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(tsdf_claim_kernel, dim3(blocks), dim3(256), 0, s, index, offsets, B, R, n, winner);
-    hipLaunchKernelGGL(tsdf_write_kernel, dim3(blocks), dim3(256), 0, s, index, value, offsets, B, R, n, winner, grid);
+    GIGA_LAUNCH(tsdf_claim_kernel, dim3(blocks), dim3(256), 0, s, index, offsets, B, R, n, winner);
+    GIGA_LAUNCH(tsdf_write_kernel, dim3(blocks), dim3(256), 0, s, index, value, offsets, B, R, n, winner, grid);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 

@@ -276,10 +276,10 @@ def _ring_worker(ds, buffers, tasks, done):
             x, (lab, rot, wid), pos, op, occ = ds.batch(idx, rng=np.random.default_rng([seed, epoch, k]))
             for dst, src in zip(buffers[slot], (x, lab, rot, wid, pos, op, occ)):
                 np.copyto(dst.numpy()[:len(idx)], src, casting="same_kind")
-            done.put((k, slot, len(idx), None))
+            done.put((epoch, k, slot, len(idx), None))
         except BaseException as e:  # noqa: BLE001
             import traceback
-            done.put((k, slot, 0, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
+            done.put((epoch, k, slot, 0, f"{type(e).__name__}: {e}\n{traceback.format_exc()}"))
 
 
 class GraspOccRing:
@@ -349,25 +349,51 @@ class GraspOccRing:
         if self.drop_last and chunks and len(chunks[-1]) < self.bs:
             chunks.pop()
         self.epoch += 1
-        submitted, delivered, ready = 0, 0, {}
-        while delivered < len(chunks):
-            # hand out as many tasks as there are free slots (the consumer's release() refills the list)
-            with self._room:
-                while submitted < len(chunks) and self._free_slots:
-                    slot = self._free_slots.pop()
-                    self._tasks.put((slot, self.seed, self.epoch, submitted, chunks[submitted]))
-                    submitted += 1
-                if delivered not in ready and submitted == delivered:
-                    self._room.wait(timeout=0.05)             # every slot is out with the consumer: wait for a release
-                    continue
-            while delivered not in ready:
-                k, slot, n, err = self._done.get()
-                if err is not None:
-                    raise RuntimeError("reader process failed: " + err)
-                ready[k] = (slot, n)
-            slot, n = ready.pop(delivered)
-            delivered += 1
-            yield RingBatch(self, slot, n)
+        epoch = self.epoch
+        submitted, received, delivered, ready = 0, 0, 0, {}
+        failed = False
+        try:
+            while delivered < len(chunks):
+                # hand out as many tasks as there are free slots (the consumer's release() refills the list)
+                with self._room:
+                    while submitted < len(chunks) and self._free_slots:
+                        slot = self._free_slots.pop()
+                        self._tasks.put((slot, self.seed, epoch, submitted, chunks[submitted]))
+                        submitted += 1
+                    if delivered not in ready and received == submitted:
+                        self._room.wait(timeout=0.05)         # every slot is out with the consumer: wait for a release
+                        continue
+                while delivered not in ready:
+                    ep, k, slot, n, err = self._done.get()
+                    if ep != epoch:                           # a straggler of an abandoned pass: only its slot matters
+                        self._free(slot)
+                        continue
+                    received += 1
+                    if err is not None:
+                        failed = True
+                        self._free(slot)
+                        raise RuntimeError("reader process failed: " + err)
+                    ready[k] = (slot, n)
+                slot, n = ready.pop(delivered)
+                delivered += 1
+                yield RingBatch(self, slot, n)
+        finally:
+            # The consumer may stop mid-epoch (break, an exception, TSDFFeed's stop path): every task already handed to a
+            # reader still completes into its slot.  Collect those results here and give their slots -- and the slots of
+            # assembled but undelivered batches -- back, so that the next pass neither sees an old batch under a new index
+            # nor starves for slots.  Results are tagged with the epoch; anything from another pass is discarded above.
+            for slot, _n in ready.values():
+                self._free(slot)
+            ready.clear()
+            import queue as _queue
+            while received < submitted and self._procs:
+                try:
+                    ep, _k, slot, _n, _err = self._done.get(timeout=30.0 if not failed else 5.0)
+                except _queue.Empty:
+                    break                                     # a reader died: its slot is lost, the ring keeps the others
+                self._free(slot)
+                if ep == epoch:
+                    received += 1
 
 
 def network_inputs(batch):

@@ -91,7 +91,12 @@ class TSDFFeed:
                     L = _capi.lib()
                     ring(lambda ptr, nbytes: L.giga_host_register(ptr, nbytes))
                 for item in self._batches:
-                    if stop.is_set():
+                    if stop.is_set():                         # the consumer left: hand every host slot we still hold back
+                        if hasattr(item, "release"):
+                            item.release()
+                        for ev, rb in pending:
+                            ev.synchronize()
+                            rb.release()
                         return
                     while pending and (pending[0][0].query() or len(pending) >= 2):   # hand host slots back early: the ring must not run dry
                         ev, rb = pending.pop(0)

@@ -36,6 +36,8 @@ class FlatAdam(torch.optim.Optimizer):
                 if p.dtype != torch.float32 or not p.is_contiguous():
                     raise TypeError("FlatAdam updates contiguous fp32 tensors (net.flatten_parameters())")
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if g.data_ptr() % 16:                        # (a gradient view at an odd offset of a larger bucket)
+                    g = g.clone()
                 st = self.state[p]
                 if not st:
                     st["step"] = torch.zeros((), dtype=torch.float32)       # (a CPU scalar tensor, as torch's Adam keeps it)
@@ -47,4 +49,9 @@ class FlatAdam(torch.optim.Optimizer):
                                                  p.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                                  float(group["weight_decay"]), int(st["step"]), _capi.stream_ptr(p.device)),
                                 "giga_adam_step")
+                # the update went through a raw pointer: tell autograd's version counter, so that caches and stale-graph
+                # checks keyed on (storage, version) see it (giga_amd.training, _PackedWeights)
+                bump = getattr(torch.autograd.graph, "increment_version", None)
+                if bump is not None:
+                    bump(p)
         return loss

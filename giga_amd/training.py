@@ -276,9 +276,17 @@ def giga_loss(out, y):
     qual, rot, width, occ = out
     label, rot_t, width_t, occ_t = y
     _capi.require_device(qual, rot, width, occ, label, rot_t, width_t, occ_t)
-    B = occ.shape[0]
+    if occ.dim() != 2:
+        raise ValueError(f"expected occupancy logits of shape (B, M), got {tuple(occ.shape)}")
+    B, M = occ.shape
     if qual.numel() != B or rot.numel() != 4 * B or width.numel() != B:
         raise ValueError("giga_loss is the fused form of the literal train_giga call: one grasp query per scene")
+    for name, t, shape in (("label", label, (B,)), ("rotations", rot_t, (B, 2, 4)), ("width", width_t, (B,)), ("occ", occ_t, (B, M))):
+        if tuple(t.shape) != shape:                          # (the kernels index the targets by these shapes)
+            raise ValueError(f"giga_loss: target `{name}` has shape {tuple(t.shape)}, expected {shape}")
+    if B == 0:                                               # F.*_loss(...).mean() of an empty batch
+        nan = occ.new_full((), float("nan")) + 0.0 * occ.sum()
+        return nan, {k: nan.detach() for k in LOSS_KEYS}
     loss, parts = _GigaLoss.apply(qual, rot, width, occ, label, rot_t, width_t, occ_t)
     d = {k: parts[i] for i, k in enumerate(LOSS_KEYS[:4])}
     d["loss_all"] = loss.detach()

@@ -210,7 +210,8 @@ int giga_train_loss_backward(const float* qual, const float* rot, const float* w
  * torch.optim.Adam (the reference's optimiser, scripts/train_giga.py:49; no amsgrad), formulas and order of torch/optim/adam.py:
  * m = lerp(m, g, 1 - beta1); v = beta2 v + (1 - beta2) g^2; p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps);
  * weight_decay (L2) adds weight_decay * p to g first.  `step` counts from 1.  One launch over the whole chip: torch's fused
- * multi-tensor kernel gives a single tensor one workgroup per 65 536 elements (98 us for these 581 863 parameters, this: ~5 us). */
+ * multi-tensor kernel gives a single tensor one workgroup per 65 536 elements (98 us for these 581 863 parameters, this: ~5 us).
+ * All four buffers must be 16-byte aligned (-1 otherwise). */
 int giga_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
                    double beta2, double eps, double weight_decay, int step, void* stream);
 
@@ -251,6 +252,9 @@ int giga_grasp_select(const float* tsdf, const float* qual, const float* rot, co
  * after ONE kernel launch, so the kernel's duration is measured live on the stream it runs on.
  * probe_stage: 0 conv_in+project, 1 plane_finalize, 2..14 = U-Net layers 0..12 (giga_layout.h kConv).
  * The decoder variant brackets the single fused decoder launch. */
+/* Number of kernel launches the library has enqueued in this process so far (all streams): the difference around a call is
+ * that call's launch count.  Diagnostic only. */
+unsigned long long giga_launch_count(void);
 void* giga_event_create(void);
 void giga_event_destroy(void* ev);
 int giga_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises on ev_stop */

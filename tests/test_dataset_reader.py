@@ -97,6 +97,43 @@ def test_shared_memory_ring_delivers_the_same_batches(tmp_path):
         ring.close()
 
 
+def test_shared_memory_ring_survives_an_abandoned_epoch(tmp_path):
+    """A consumer that stops mid-epoch (break / exception / TSDFFeed's stop path) leaves submitted tasks behind: their results
+    must not surface as batches of the NEXT pass, and their slots (and those of assembled but undelivered batches) must not
+    starve the ring.  Three abandoned passes, then two complete ones that equal
+    GraspOccBatches for the same seed and epoch count."""
+    root, raw = str(tmp_path / "data"), str(tmp_path / "raw")
+    n = make_dataset.write_dataset(root, raw, n_scenes=6, grasps_per_scene=6, seed=8)
+    ds = dataset.GraspOccDataset(root, raw, num_point_occ=40, workers=2)
+    ring = dataset.GraspOccRing(ds, 4, workers=3, shuffle=True, seed=21, slots=4)
+    ref = dataset.GraspOccBatches(ds, 4, shuffle=True, seed=21, workers=2)
+    try:
+        for stop_after in (1, 2, 0):                          # abandoned passes (the reference iterator advances its epoch too)
+            want = [(b[0], *b[1], b[2], b[3], b[4]) for b in ref]
+            it = iter(ring)
+            for k in range(stop_after):
+                rb = next(it)
+                assert torch.equal(rb.host()[0], want[k][0])
+                rb.release()
+            if stop_after == 0:
+                next(it).release()
+            it.close()                                        # GeneratorExit: the ring collects what is still in flight
+            assert sorted(ring._free_slots) == [0, 1, 2, 3]
+        for _ in range(2):
+            want = [(b[0], *b[1], b[2], b[3], b[4]) for b in ref]
+            got = []
+            for rb in ring:
+                got.append(tuple(t.clone() for t in (rb.host()[0], *rb.host()[1], *rb.host()[2:])))
+                rb.release()
+            assert len(got) == len(want) == (n + 3) // 4
+            for g, w in zip(got, want):
+                for a, b in zip(g, w):
+                    assert a.dtype == b.dtype and torch.equal(a, b)
+            assert sorted(ring._free_slots) == [0, 1, 2, 3]
+    finally:
+        ring.close()
+
+
 @pytest.mark.reference
 @pytest.mark.skipif(not ref_bootstrap.reference_available(), reason="/root/reference not present")
 def test_items_match_live_reference_class(tmp_path):

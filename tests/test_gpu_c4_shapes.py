@@ -1,0 +1,94 @@
+"""GPU parity at exactly the shapes bench.py times for BASELINE config c4 (`sim_grasp_multiple.py`'s path:
+detection_implicit.py:28-31,99-113): 8 / 32 / 128 scenes x the 64 000-point inference lattice, three grasp heads, in every
+arithmetic mode.  At these sizes the decoders run their multi-round persistent paths (`decoder_f16_kernel<2,true,12>` with ~10
+rounds per workgroup, `decoder_f16s_kernel<2,true,8,true>` with the XCD-contiguous slot layout) and conv_in its one-x-part
+kernels -- code that batches of 1-3 scenes never reach.
+
+Held to
+  * the oracle (`O.model_forward`, decoder.py:133-176 / voxels.py:89-121 restated) on three scenes of every batch: fp32 and
+    fp16x3 at 1e-4 (fp32 tolerance), plain fp16 at its stated bound (1e-2 on raw outputs: the floor of 11-bit operands,
+    tests/test_f16_error_budget.py);
+  * EVERY scene of the batch against the same scene run alone (scene independence; the small-batch kernels): 1e-5 in the
+    fp32-grade modes, the f16 bound in plain fp16 (conv_in's summation order depends on the batch size, which flips f16
+    roundings of the planes);
+  * the 128-scene batch against the same scenes run as four batches of 32, BIT FOR BIT in the f16-class modes (same kernels,
+    per-point / per-image arithmetic does not depend on the work distribution); fp32 to rounding (its tail split does).
+"""
+import pytest
+import torch
+
+from giga_amd import networks, synth
+from oracle import giga_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FIRST = 1000                     # bench_c4's first scene: the batches here ARE bench.py's inputs
+TOL_REF = {"fp32": 1e-4, "fp16x3": 1e-4, "fp16": 1e-2}
+TOL_ALONE = {"fp32": 1e-5, "fp16x3": 1e-5, "fp16": 1e-2}
+
+
+@pytest.fixture(scope="module")
+def net(sd7):
+    n = networks.get_network("giga")
+    n.load_state_dict(sd7)
+    return n.to(torch.device("cuda:0")).eval()
+
+
+@pytest.fixture(scope="module")
+def oracle_scene(sd7):
+    """Oracle outputs (qual, rot, width) on the lattice for scene FIRST + k, computed once per scene."""
+    cache = {}
+    lat = O.inference_lattice()
+
+    def get(k):
+        if k not in cache:
+            with torch.no_grad():
+                cache[k] = O.model_forward(sd7, torch.from_numpy(synth.tsdf_batch(FIRST + k, 1)), lat)
+        return cache[k]
+
+    return get
+
+
+def _err(a, b):
+    return (a.float().cpu() - b.float().cpu()).abs().max().item()
+
+
+@pytest.mark.parametrize("B", [8, 32, 128])
+def test_c4_bench_shapes_against_oracle_and_single_scene_runs(net, oracle_scene, B):
+    from giga_amd.detection import predict_batch, query_lattice
+    dev = torch.device("cuda:0")
+    lat = query_lattice(40, dev)
+    x = torch.from_numpy(synth.tsdf_batch(FIRST, B)).to(dev)
+    picks = sorted({0, min(17, B - 1), B - 1})
+    try:
+        for prec in ("fp16", "fp16x3", "fp32"):
+            net.set_precision(prec)
+            full = predict_batch(x, lat, net)
+            assert full[0].shape == (B, 64000) and full[1].shape == (B, 64000, 4) and full[2].shape == (B, 64000)
+            for v in full:
+                assert torch.isfinite(v).all()
+            # (1) three scenes against the oracle
+            for k in picks:
+                ref = oracle_scene(k)
+                for name, got, want, scale in zip(("qual", "rot", "width"), full, ref, (1.0, 1.0, 2.0)):
+                    e = _err(got[k:k + 1], want)
+                    assert e < TOL_REF[prec] * scale, (prec, B, k, name, e)
+            # (2) every scene against the same scene run alone
+            worst = 0.0
+            for k in range(B):
+                one = predict_batch(x[k:k + 1].contiguous(), lat, net)
+                for got, alone in zip(full, one):
+                    worst = max(worst, _err(got[k:k + 1], alone))
+            assert worst < TOL_ALONE[prec], (prec, B, worst)
+            # (3) the batch as chunks of 32 scenes: the same kernels on a different work distribution
+            if B > 32:
+                for c0 in range(0, B, 32):
+                    part = predict_batch(x[c0:c0 + 32].contiguous(), lat, net)
+                    for got, chunk in zip(full, part):
+                        if prec == "fp32":
+                            assert _err(got[c0:c0 + 32], chunk) < 1e-5, (prec, c0)
+                        else:
+                            assert torch.equal(got[c0:c0 + 32], chunk), (prec, c0)
+            del full
+    finally:
+        net.set_precision("fp32")

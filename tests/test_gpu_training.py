@@ -194,6 +194,41 @@ def test_bf16_training_step(sd7, monkeypatch):
     assert loss.item() < 0.7 * first
 
 
+def test_bf16_training_step_at_the_c5_shape(sd7):
+    """BASELINE config c5 at its full shape (B = 32 scenes, 1 grasp query + M = 2048 occupancy queries): the whole bf16 step
+    against fp32 autograd through the oracle -- joint loss within 1 %, every loss term within 2 %, gradient direction preserved
+    (cosine > 0.97 over all 581 863 parameters, and per head / encoder) -- and bit-for-bit repeatable forward outputs.  The
+    per-kernel bf16 parity (operand-rounded oracle, layer by layer) is test_bf16_training_step (a); per-tensor gradients of a
+    whole bf16 step differ from fp32 by the format's 10-30 % (see there), so they are not compared tensor by tensor."""
+    dev = torch.device("cuda:0")
+    x, pos, pos_occ, y = _batch(300, 32, 2048)
+    ref_loss, ref_grads, ref_d = _oracle_grads(sd7, x, pos, pos_occ, y)
+    net = networks.get_network("giga"); net.load_state_dict(sd7); net = net.to(dev).train().set_train_precision("bf16")
+    yd = tuple(t.to(dev) for t in y)
+    out = net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev))
+    loss, d = giga_loss(out, yd)
+    assert abs(loss.item() - ref_loss) < 1e-2 * abs(ref_loss), (loss.item(), ref_loss)
+    for k in ("loss_qual", "loss_rot", "loss_width", "loss_occ"):
+        assert abs(d[k].item() - ref_d[k].item()) <= 2e-2 * max(abs(ref_d[k].item()), 1e-3), (k, d[k].item(), ref_d[k].item())
+    loss.backward()
+    names = [n for n, _ in net.named_parameters()]
+    got = {n: p.grad.detach().reshape(-1).cpu() for n, p in net.named_parameters()}
+    cos = lambda sel: torch.nn.functional.cosine_similarity(torch.cat([got[n] for n in sel]),  # noqa: E731
+                                                            torch.cat([ref_grads[n].reshape(-1) for n in sel]), dim=0).item()
+    total = cos(names)
+    print("bf16 step at B=32, M=2048: loss", loss.item(), "vs fp32", ref_loss, "gradient cosine", total)
+    assert total > 0.97
+    for part in ("decoder_qual", "decoder_rot", "decoder_width", "decoder_tsdf", "encoder"):
+        c = cos([n for n in names if n.startswith(part)])
+        print("   gradient cosine,", part, c)
+        assert c > (0.90 if part == "encoder" else 0.95), (part, c)
+    for n in names:
+        assert torch.isfinite(got[n]).all(), n
+    out2 = net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev))
+    for a, b in zip(out, out2):
+        assert torch.equal(a.detach(), b.detach())
+
+
 def maxerr_t(a, b):
     return (a.detach().float().cpu() - b.detach().float()).abs().max().item()
 
