@@ -569,6 +569,222 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16s_kernel(DecArgs a) {
     DEC_T(15);
 }
 
+
+// =============================== lattice decoder with separable fc_c ("G lines") ====================
+// The inference lattice (detection_implicit.py:28-31) is a product grid, and the three planes each see only two of its three
+// coordinates: point (ix, iy, iz) reads pixel (iz, ix) of plane xz, (iy, ix) of plane xy and (iz, iy) of plane yz.  fc_c is
+// LINEAR in the concatenated feature (decoder.py:169) and so is fc_p in p (decoder.py:165), hence for every block b
+//     fc_c[b](c) + bias  =  G_xz[b][iz]  +  G_xy[b][iy]  +  Wc_b[:, 64:96] f_yz(iz, iy)          at fixed (scene, ix)
+//     G_xz[b][iz] = Wc_b[:, 0:32] f_xz(iz, ix) (+ the z term of fc_p for b = 0),   G_xy[b][iy] = Wc_b[:, 32:64] f_xy(iy, ix) + biases
+//                   (+ the x and y terms of fc_p for b = 0)
+// A workgroup takes a SLAB = (scene, ix): R*R points.  It first evaluates the two "lines" G_xz[.][0..R) and G_xy[.][0..R) of all
+// five blocks with a few dozen MFMAs (22 jobs of 3-7 MFMAs spread over the waves; operands straight from L2) into LDS as fp32,
+// and then every point of the slab needs, per block, two 32-vector ADDS (VALU, co-executing with the matrix pipe) and the two
+// MFMAs of the yz part instead of the seven MFMAs of the whole fc_c: 32 MFMAs per 32-point tile and head instead of 58 (f16x3:
+// 96 instead of 162), with the xz / xy contributions -- two thirds of fc_c -- carried in fp32 instead of through f16 operands.
+// Same fragments as the other f16 kernels (the head image of giga_pack.cpp; nothing new is packed): the tile phase keeps only
+// what it uses resident in LDS (yz chunks of fc_c, fc_0, fc_1, fc_out, the C table: 33 KiB, f16x3 65 KiB), the line phase reads
+// its weight fragments from the image in L2.  Head-resident persistent workgroups as decoder_f16s_kernel; slabs are handed out
+// so that an XCD owns a contiguous eighth of the scenes.
+constexpr int LAT_GS = 36;                 // floats per line pixel: 32 features + 4 pad (144-byte stride: conflict-free ds_read_b128)
+constexpr int LAT_ROWS = 2 * NBLK + 1;     // line rows: G_xz[0..4], G_xy[0..4], and the bias of the last fc_1 as G_xy[5]
+constexpr int LAT_MAX_R = 40;
+template <bool SPLIT>
+constexpr size_t lat_lds_bytes(int R) { return (size_t)(32 * (SPLIT ? 2 : 1) + 1) * FRAG + (size_t)LAT_ROWS * R * LAT_GS * sizeof(float); }
+
+template <bool SPLIT, int NW>
+__global__ __launch_bounds__(NW * 64) void decoder_lat_kernel(DecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int PR = SPLIT ? 2 : 1;                          // fragments per weight chunk ([hi, lo] pair or single)
+    constexpr int BLK = SPLIT ? DEC16S_BLK : 11;               // fragments per block in the head image
+    constexpr int NFR = SPLIT ? DEC16S_FRAGS : DEC16_FRAGS;
+    constexpr int F_AUX = 6 * PR, F_TAIL = NBLK * BLK, F_OUT = F_TAIL + 1;
+    constexpr int WF = 32 * PR;                                // resident fragments: per block [yz c0, yz c1, fc_0 x2, fc_1 x2], then fc_out x2
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, hi = lane >> 5;
+    const int slots = gridDim.x / a.nheads;
+    int hsel = blockIdx.x % a.nheads, slot = blockIdx.x / a.nheads;
+    if (gridDim.x % (8 * a.nheads) == 0) {                     // XCD-contiguous slab ranges (workgroup i runs on XCD i % 8)
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3, spx = slots >> 3;
+        hsel = k % a.nheads;
+        slot = xcd * spx + k / a.nheads;
+    }
+    const int R = a.R, R2 = R * R;
+    const int nslab = a.B * R;
+    const int slab_lo = (int)((long long)nslab * slot / slots), slab_hi = (int)((long long)nslab * (slot + 1) / slots);
+    if (slab_lo >= slab_hi) return;
+    const uint8_t* img = a.blob + a.head_off[hsel];
+    for (int d = wave; d <= WF; d += NW) {                     // the resident part of the head image (+ the C table chunk)
+        int src;
+        if (d < 30 * PR) {
+            const int b = d / (6 * PR), e = d - b * 6 * PR;
+            src = e < 2 * PR ? BLK * b + 4 * PR + e : BLK * b + F_AUX + 1 + (e - 2 * PR);
+        } else if (d < WF) {
+            src = F_OUT + (d - 30 * PR);
+        } else {
+            src = NFR;
+        }
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(img + (size_t)src * FRAG + lane * 16),
+            (__attribute__((address_space(3))) void*)(smem + d * FRAG), 16, 0, 0);
+    }
+    const half8* W = reinterpret_cast<const half8*>(smem);
+    const float* ctab = reinterpret_cast<const float*>(smem + (size_t)WF * FRAG);
+    float* G = reinterpret_cast<float*>(smem + (size_t)(WF + 1) * FRAG);
+    const half8* Wg = reinterpret_cast<const half8*>(img);
+    const half_t* planes = reinterpret_cast<const half_t*>(a.planes);
+    const size_t plane_stride = (size_t)a.B * R2 * CD;         // features per plane
+    const int ntile = (R2 + 31) >> 5;
+    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // features of pixel `off` of plane `pl`, scene b: chunk hf (16 channels; this lane's 8) as B operands
+    auto load_feat = [&](int b, int pl, int off, int hf, half8& fh, half8& fl) {
+        if constexpr (SPLIT) {
+            const half_t* q = planes + 2 * ((size_t)b * R2 * CD + pl * plane_stride + (size_t)off * CD) + 16 * hi + 32 * hf;
+            fh = *reinterpret_cast<const half8*>(q);
+            fl = *reinterpret_cast<const half8*>(q + 8);
+        } else {
+            fh = *reinterpret_cast<const half8*>(planes + (size_t)b * R2 * CD + pl * plane_stride + (size_t)off * CD + 16 * hf + 8 * hi);
+            fl = zero8;
+        }
+    };
+    // acc += W(frag) * x : three MFMAs on [hi, lo] pairs, one on single operands
+    auto mm1 = [&](const half8* Wsrc, int frag, const half8& xh, const half8& xl, f32x16& acc) {
+        const half8 Ah = Wsrc[frag * 64 + lane];
+        if constexpr (SPLIT) {
+            const half8 Al = Wsrc[(frag + 1) * 64 + lane];
+            acc = mfma16(Al, xh, acc);
+            acc = mfma16(Ah, xl, acc);
+            acc = mfma16(Ah, xh, acc);
+        } else {
+            acc = mfma16(Ah, xh, acc);
+        }
+    };
+    auto ctab_regs = [&](int row) {
+        f32x16 c0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(ctab + row * 32 + 8 * q + 4 * hi);
+            c0[4 * q + 0] = v.x; c0[4 * q + 1] = v.y; c0[4 * q + 2] = v.z; c0[4 * q + 3] = v.w;
+        }
+        return c0;
+    };
+    // net += line row `row` at pixel px  (this lane's 16 features: 8q + 4hi + j)
+    auto add_line = [&](int row, int px, f32x16& net) {
+        const float* g = G + ((size_t)row * R + px) * LAT_GS + 4 * hi;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(g + 8 * q);
+            net[4 * q + 0] += v.x; net[4 * q + 1] += v.y; net[4 * q + 2] += v.z; net[4 * q + 3] += v.w;
+        }
+    };
+    // dst += W(frag0 + PR*c) * relu(src), c = 0, 1 (resident fragments)
+    auto dense = [&](int frag0, const f32x16& src, f32x16& dst) {
+        half8 xh[2], xl[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if constexpr (SPLIT) split_relu8(src, c, xh[c], xl[c]);
+            else { xh[c] = pack_relu8(src, c); xl[c] = zero8; }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) mm1(W, frag0 + PR * c, xh[c], xl[c], dst);
+    };
+
+    bool first = true;
+    for (int slab = slab_lo; slab < slab_hi; ++slab) {
+        const int b = slab / R, ix = slab - b * R;             // (uniform)
+        const float px_ = a.lin[ix];
+        // ---------------- line phase: G rows of this slab -> LDS
+        if (!first) __syncthreads();                            // everyone has left the previous slab's lines
+        for (int job = wave; job < 2 * LAT_ROWS; job += NW) {
+            const int row = job >> 1, ct = job & 1;
+            if (32 * ct >= R) continue;
+            const bool xy = row >= NBLK;
+            const int blk = xy ? row - NBLK : row;
+            int px = 32 * ct + n;
+            const bool pvalid = px < R;
+            px = pvalid ? px : R - 1;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if (blk < NBLK) {
+                const int pl = xy ? 1 : 0;                      // plane xz: pixel (H = iz, W = ix); plane xy: (H = iy, W = ix)
+                half8 fh[2], fl[2];
+                load_feat(b, pl, px * R + ix, 0, fh[0], fl[0]);
+                load_feat(b, pl, px * R + ix, 1, fh[1], fl[1]);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) mm1(Wg, BLK * blk + PR * (2 * pl + c), fh[c], fl[c], acc);
+            }
+            if (xy || blk == 0) {
+                // aux fragment: k-slots [p_hi(3), 1, p_lo(3), 1] on hi = 0 lanes, [p_hi(3), 0...] on hi = 1 lanes.  fc_p is linear
+                // in p: the xy line carries the x and y terms and the constant-one slots (the biases), the xz line the z term.
+                const float pc = a.lin[px];
+                const half_t ch = (half_t)pc, xh_ = (half_t)px_;
+                half8 av = zero8;
+                if (xy) {
+                    av[0] = xh_; av[1] = ch;
+                    if (hi == 0) { av[3] = (half_t)1.0f; av[4] = (half_t)(px_ - (float)xh_); av[5] = (half_t)(pc - (float)ch); av[7] = (half_t)1.0f; }
+                } else {
+                    av[2] = ch;
+                    if (hi == 0) av[6] = (half_t)(pc - (float)ch);
+                }
+                acc = mfma16(Wg[(blk < NBLK ? BLK * blk + F_AUX : F_TAIL) * 64 + lane], av, acc);
+            }
+            if (pvalid) {
+                float* g = G + ((size_t)row * R + px) * LAT_GS + 4 * hi;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(g + 8 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            }
+        }
+        if (first) __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): my share of the resident image has landed
+        first = false;
+        __syncthreads();
+        // ---------------- tile phase: 32 points (iy, iz) of the slab per wave and step
+        for (int t = wave; t < ntile; t += NW) {
+            // (compiler barrier: the weight fragments are loop-invariant LDS reads, and hoisting all of them out of this loop --
+            //  130-260 registers -- spills the whole chain)
+            asm volatile("" ::: "memory");
+            int rr = 32 * t + n;
+            const bool valid = rr < R2;
+            rr = valid ? rr : R2 - 1;
+            const int iy = div_magic(rr, a.mR), iz = rr - iy * R;
+            const long long gidx = (long long)b * a.N + (long long)ix * R2 + rr;
+            half8 cfh[2], cfl[2];
+            load_feat(b, 2, iz * R + iy, 0, cfh[0], cfl[0]);    // plane yz: pixel (H = iz, W = iy)
+            load_feat(b, 2, iz * R + iy, 1, cfh[1], cfl[1]);
+            f32x16 net, hh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) net[r] = 0.f;
+            add_line(0, iz, net);
+            add_line(NBLK, iy, net);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) mm1(W, PR * c, cfh[c], cfl[c], net);
+#pragma unroll
+            for (int blk = 0; blk < NBLK; ++blk) {
+                const int wb = 6 * PR * blk;
+                hh = ctab_regs(blk);
+                dense(wb + 2 * PR, net, hh);                    // hh = fc_0(relu(net)) + b0
+                // every term of the residual stream is an accumulation: the next block's fc_c (lines + yz part) goes here, where
+                // it covers the conversion of hh
+                if (blk + 1 < NBLK) {
+                    add_line(blk + 1, iz, net);
+                    add_line(NBLK + blk + 1, iy, net);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) mm1(W, wb + 6 * PR + PR * c, cfh[c], cfl[c], net);
+                } else {
+                    add_line(2 * NBLK, iy, net);                // bias of the last fc_1
+                }
+                dense(wb + 4 * PR, hh, net);                    // net += fc_1(relu(hh))
+            }
+            f32x16 o = ctab_regs(NBLK);
+            dense(30 * PR, net, o);                             // fc_out(relu(net))
+            if (hi == 0 && valid) store_head(a, hsel, gidx, o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 #ifdef GIGA_TRACE
 }  // namespace giga
 extern "C" int giga_debug_dec_trace(long long* host_out) {
@@ -909,6 +1125,27 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
     // up the shared-feature kernel is the faster one, 297 vs 323 us at 32 scenes).  grid = slots x nheads <= 256 (one workgroup per CU).  Two tiles per wave (the weight fragments
     // are read from LDS once per two tiles) when every workgroup gets at least two such rounds, else one tile per wave.
     // (tuning knob, read once: GIGA_DEC16_RESIDENT=0/1 forces the choice for plain f16; measurements in DESIGN.md)
+    // Lattice launches of the f16-class modes from 4 scenes up: the separable-fc_c kernel (decoder_lat_kernel); smaller ones are
+    // latency-bound and keep the head-resident kernel below.  (tuning knob: GIGA_DEC_LAT=0/1 forces the choice)
+    const int force_lat = [] { const char* e = getenv("GIGA_DEC_LAT"); return e ? atoi(e) : -1; }();   // (per call: A/B runs in one process)
+    if (lat && (precision == 1 || precision == 2) && a.R <= LAT_MAX_R && (force_lat >= 0 ? force_lat != 0 : a.B >= 4)) {
+        constexpr int NW = 12;
+        const int nslab = a.B * a.R;
+        const int cap = 256 / a.nheads, cap8 = 256 / (8 * a.nheads) * 8;
+        int slots = nslab < cap ? nslab : (nslab >= 2 * cap8 && cap8 > 0 ? cap8 : cap);
+        a.nbatch = slots;
+        if (precision == 2) {
+            const size_t lds = lat_lds_bytes<true>(a.R);
+            giga::dyn_lds_once(reinterpret_cast<const void*>(decoder_lat_kernel<true, NW>), (int)lds);
+            GIGA_LAUNCH((decoder_lat_kernel<true, NW>), dim3(slots * a.nheads), dim3(NW * 64), lds, s, a);
+        } else {
+            const size_t lds = lat_lds_bytes<false>(a.R);
+            giga::dyn_lds_once(reinterpret_cast<const void*>(decoder_lat_kernel<false, NW>), (int)lds);
+            GIGA_LAUNCH((decoder_lat_kernel<false, NW>), dim3(slots * a.nheads), dim3(NW * 64), lds, s, a);
+        }
+        if (ev0 && ev1) (void)hipEventRecord(static_cast<hipEvent_t>(ev1), s);
+        return hipGetLastError() == hipSuccess ? 0 : -10;
+    }
     static const int force_resident = [] { const char* e = getenv("GIGA_DEC16_RESIDENT"); return e ? atoi(e) : -1; }();
     const bool resident = precision == 2 ||
                           (precision == 1 && (force_resident >= 0 ? force_resident != 0 : tiles * a.nheads < (lat ? 16000 : 6000)));
