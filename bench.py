@@ -47,7 +47,10 @@ MEASURED_F16_MFMA_TFLOPS = 2350.6     # v_mfma_f32_32x32x16_f16 (94 % of spec: t
 FLOP_ENCODER = 1_132_953_600          # SURVEY.md 8d / BASELINE.md section 4
 FLOP_HEAD = {"qual": 51_456, "rot": 51_648, "width": 51_456, "tsdf": 51_456}
 FLOP_GRASP3 = 154_560
-SPLIT_MFMA_PER_PLAIN = 162.0 / 58.0   # f16x3: MFMA instructions per tile and head relative to the plain f16 chain
+# Lattice decoder (decoder_lat_kernel): f16 MFMA instructions (32x32x16: 32 768 FLOP) ISSUED per 32-point tile and head -- 43 in the
+# plain mode, 107 in f16x3, plus the slab's line jobs (22 jobs of 3 / 7 (9 / 19) MFMAs per 50 tiles) -- against the 1 648 640
+# ALGORITHMIC FLOP of that tile and head: two thirds of fc_c are evaluated once per plane pixel, not per point.
+ISSUED_PER_ALGORITHMIC = {"fp16": (43 + 1.8) * 32768 / (32 * 51_520.0), "fp16x3": (107 + 5.3) * 32768 / (32 * 51_520.0)}
 
 # U-Net layer table (kind, cin, cout, H, W): algorithmic FLOPs per image = 2*H*W*taps*cin*cout
 _CONV = [(9, 32, 32, 40), (9, 32, 32, 40), (9, 32, 64, 20), (9, 64, 64, 20), (9, 64, 128, 10), (9, 128, 128, 10),
@@ -550,19 +553,22 @@ def bench_c4(net, dev, L, _capi, synth, decode_heads, prec, Bc=32, steps=10):
     ach = flops / (dec_ms * 1e-3) / 1e12
     net.set_precision("fp32")
     split = prec == "fp16x3"
-    tr, tr_src = traffic_lookup("c4step_x3" if split else "c4step", "decoder_f16s_kernel<2, true, 8, true>" if split else
-                                "decoder_f16_kernel<2, true, 12>") if Bc == 32 else (None, None)
-    roof = {"kernel": "decoder_f16s_kernel" if split else "decoder_f16_kernel", "bound": "mfma", "achieved": ach,
+    tr, tr_src = traffic_lookup("c4step_x3" if split else "c4step", "decoder_lat_kernel") if Bc == 32 else (None, None)
+    kname = "decoder_lat_kernel" if (split or Bc >= 4) else "decoder_f16s_kernel"
+    roof = {"kernel": kname, "bound": "mfma", "achieved": ach,
             "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": tr, "traffic_source": tr_src,
             "frac_of_measured_peak": ach / MEASURED_F16_MFMA_TFLOPS, "avg_launch_ms": dec_ms, "flops_per_launch": flops,
             # the HIP-event bracket itself (two records with nothing between them); `frac` above is NOT corrected for it
             "empty_event_bracket_ms": bracket_ms,
             "frac_net_of_bracket": flops / (max(dec_ms - bracket_ms, 1e-6) * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS}
-    if split:
-        roof["issued_mfma_tflops"] = ach * SPLIT_MFMA_PER_PLAIN
-        roof["issued_mfma_frac_of_peak"] = ach * SPLIT_MFMA_PER_PLAIN / PEAK_F16_MFMA_TFLOPS
-        roof["note"] = ("`achieved`/`frac` count ALGORITHMIC FLOPs (154 560 per point); the split chain issues 162 f16 MFMAs per "
-                        "tile and head instead of 58, so the matrix pipe is busy with issued_mfma_tflops")
+    if kname == "decoder_lat_kernel":
+        r = ISSUED_PER_ALGORITHMIC[prec]
+        roof["issued_mfma_tflops"] = ach * r
+        roof["issued_mfma_frac_of_peak"] = ach * r / PEAK_F16_MFMA_TFLOPS
+        roof["note"] = ("`achieved`/`frac` count ALGORITHMIC FLOPs (154 560 per point, SURVEY 8d).  The kernel evaluates the xz / xy thirds of "
+                        "fc_c, fc_p and the stream's biases once per plane pixel of a (scene, ix) slab instead of once per point and injects "
+                        "them through one-hot K = 16 MFMAs: it ISSUES %d f16 MFMAs per 32-point tile and head (%s), i.e. issued_mfma_tflops "
+                        "keeps the matrix pipe busy" % ((107, "f16x3: three per operand pair") if split else (43, "58 before")))
     return {
         "workload": f"c4: batch={Bc} scenes x the 64000-point inference lattice, 3 grasp heads, "
                     + ("f16x3 split-operand f16-MFMA encoder and decoder (fp32-grade, <= 6e-6 vs oracle)" if split else

@@ -24,6 +24,7 @@ struct DecArgs {
     int R;                   // lattice mode: points per axis; planes = lattice-resampled planes [3][B][R][R][32]
     float invN;              // 1 / N
     unsigned mR, mR2;        // ceil(2^32 / R), ceil(2^32 / R^2)   (lattice mode)
+    int lat_parts;           // decoder_lat_kernel: a slab (scene, ix) is handed out in this many parts (tile ranges): small batches
 };
 
 // Byte offsets of the encoder's activations inside its caller-allocated workspace (giga_encoder.hip::enc_workspace).

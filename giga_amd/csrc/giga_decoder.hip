@@ -577,22 +577,38 @@ __global__ __launch_bounds__(NW * 64) void decoder_f16s_kernel(DecArgs a) {
 //     fc_c[b](c) + bias  =  G_xz[b][iz]  +  G_xy[b][iy]  +  Wc_b[:, 64:96] f_yz(iz, iy)          at fixed (scene, ix)
 //     G_xz[b][iz] = Wc_b[:, 0:32] f_xz(iz, ix) (+ the z term of fc_p for b = 0),   G_xy[b][iy] = Wc_b[:, 32:64] f_xy(iy, ix) + biases
 //                   (+ the x and y terms of fc_p for b = 0)
-// A workgroup takes a SLAB = (scene, ix): R*R points.  It first evaluates the two "lines" G_xz[.][0..R) and G_xy[.][0..R) of all
-// five blocks with a few dozen MFMAs (22 jobs of 3-7 MFMAs spread over the waves; operands straight from L2) into LDS as fp32,
-// and then every point of the slab needs, per block, two 32-vector ADDS (VALU, co-executing with the matrix pipe) and the two
-// MFMAs of the yz part instead of the seven MFMAs of the whole fc_c: 32 MFMAs per 32-point tile and head instead of 58 (f16x3:
-// 96 instead of 162), with the xz / xy contributions -- two thirds of fc_c -- carried in fp32 instead of through f16 operands.
-// Same fragments as the other f16 kernels (the head image of giga_pack.cpp; nothing new is packed): the tile phase keeps only
-// what it uses resident in LDS (yz chunks of fc_c, fc_0, fc_1, fc_out, the C table: 33 KiB, f16x3 65 KiB), the line phase reads
-// its weight fragments from the image in L2.  Head-resident persistent workgroups as decoder_f16s_kernel; slabs are handed out
-// so that an XCD owns a contiguous eighth of the scenes.
-constexpr int LAT_GS = 36;                 // floats per line pixel: 32 features + 4 pad (144-byte stride: conflict-free ds_read_b128)
+// A workgroup takes a SLAB = (scene, ix): R*R points.  LINE PHASE: it evaluates the two "lines" G_xz[.][0..R) and G_xy[.][0..R) of
+// all five blocks (22 jobs of 3-7 MFMAs spread over the waves; operands straight from L2) and parks them in LDS as [hi, lo] f16
+// pairs (hi + lo carries 22 bits: fp32-grade).  TILE PHASE: a tile is 4 iy x 8 iz points, and a line value enters the residual
+// stream through the MATRIX pipe, not the VALU: A operand = the line values of the tile's 4 iy (8 iz) for the lane's feature --
+// one ds_read_b128 --, B operand = a constant one-hot selector "is this point's iy (iz) the k-slot's?", so that
+//     net += A_xz(blk) * SEL_z ;  net += A_xy(blk) * SEL_y          (two K = 16 MFMAs, no VALU instruction, no per-point data)
+// and only the yz part of fc_c is still a product with per-point features: 4 MFMAs per block instead of 7 for fc_c (+ aux), 43
+// per tile and head instead of 58 (f16x3: 107 instead of 162), with the xz / xy contributions -- two thirds of fc_c, all of fc_p
+// and every bias of the stream -- exact to 2^-22 in every f16-class mode.  Same fragments as the other f16 kernels (the head
+// image of giga_pack.cpp; nothing new is packed): the tile phase keeps only what it uses resident in LDS (yz chunks of fc_c, fc_0,
+// fc_1, fc_out, the C table: 33 KiB, f16x3 65 KiB), the line phase reads its weight fragments from the image in L2.
+// Head-resident persistent workgroups as decoder_f16s_kernel; slabs are handed out so that an XCD owns a contiguous eighth of
+// the scenes.  Needs R % 8 == 0 (R = 40: 50 tiles per slab, none ragged).
 constexpr int LAT_ROWS = 2 * NBLK + 1;     // line rows: G_xz[0..4], G_xy[0..4], and the bias of the last fc_1 as G_xy[5]
 constexpr int LAT_MAX_R = 40;
-template <bool SPLIT>
-constexpr size_t lat_lds_bytes(int R) { return (size_t)(32 * (SPLIT ? 2 : 1) + 1) * FRAG + (size_t)LAT_ROWS * R * LAT_GS * sizeof(float); }
+// the low half of a line value is stored scaled by 2^11 and its selector slot carries 2^-11: hi and lo then have the same
+// magnitude class, so lo is a NORMAL f16 number whenever the value itself is above 2^-13 (unscaled it would be subnormal for
+// every |value| < 2^-3), and the product lo * 2^-11 is exact
+constexpr float LAT_LO_SCALE = 2048.0f, LAT_LO_INV = 1.0f / 2048.0f;
+template <bool SPLIT, bool DBUF>
+constexpr size_t lat_lds_bytes(int R) {
+    return (size_t)(32 * (SPLIT ? 2 : 1) + 1) * FRAG + (size_t)(DBUF ? 2 : 1) * LAT_ROWS * (R / 4) * 32 * 16 + 16;
+}
 
-template <bool SPLIT, int NW>
+// WORK DISTRIBUTION inside a workgroup is DYNAMIC: tiles (and, with two line buffers, the next slab's line jobs) are items of a
+// pool that the waves drain through one LDS counter.  A static tile -> wave map loses a third of the slab: the SIMD arbiter
+// favours its older waves (s_memtime trace, profiles/r03: per tile 4.8 k clocks on waves 0-3, 5.5 k on 4-7, 7.6 k on 8-11), so
+// the old waves idle at the slab barrier while the young ones still owe two tiles.
+// DBUF: two line buffers (fits beside the 33-KiB image of the plain mode, not beside the 65 KiB of f16x3).  Pool s = the tiles of
+// slab s + the line jobs of slab s + 1 (they fill the other buffer); ONE workgroup barrier per slab.  Single buffer: pool s = the
+// tiles of slab s; barrier, line phase of slab s + 1 (all waves), barrier.
+template <bool SPLIT, int NW, bool DBUF>
 __global__ __launch_bounds__(NW * 64) void decoder_lat_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int PR = SPLIT ? 2 : 1;                          // fragments per weight chunk ([hi, lo] pair or single)
@@ -600,6 +616,7 @@ __global__ __launch_bounds__(NW * 64) void decoder_lat_kernel(DecArgs a) {
     constexpr int NFR = SPLIT ? DEC16S_FRAGS : DEC16_FRAGS;
     constexpr int F_AUX = 6 * PR, F_TAIL = NBLK * BLK, F_OUT = F_TAIL + 1;
     constexpr int WF = 32 * PR;                                // resident fragments: per block [yz c0, yz c1, fc_0 x2, fc_1 x2], then fc_out x2
+    constexpr int NJOB = 2 * LAT_ROWS;                         // line jobs of a slab: (row, half of the line)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, hi = lane >> 5;
@@ -610,10 +627,14 @@ __global__ __launch_bounds__(NW * 64) void decoder_lat_kernel(DecArgs a) {
         hsel = k % a.nheads;
         slot = xcd * spx + k / a.nheads;
     }
-    const int R = a.R, R2 = R * R;
-    const int nslab = a.B * R;
+    const int R = a.R, R2 = R * R, RG = R >> 2;                // RG: groups of 4 line pixels
+    // work units: a slab (scene, ix), or for small launches one of NP equal tile ranges of it (a.lat_parts divides the tile count);
+    // a unit has its own pool and its own copy of the slab's lines
+    const int NP = a.lat_parts;
+    const int nslab = a.B * R * NP;                            // (units)
     const int slab_lo = (int)((long long)nslab * slot / slots), slab_hi = (int)((long long)nslab * (slot + 1) / slots);
     if (slab_lo >= slab_hi) return;
+    DEC_T(0);
     const uint8_t* img = a.blob + a.head_off[hsel];
     for (int d = wave; d <= WF; d += NW) {                     // the resident part of the head image (+ the C table chunk)
         int src;
@@ -631,12 +652,29 @@ __global__ __launch_bounds__(NW * 64) void decoder_lat_kernel(DecArgs a) {
     }
     const half8* W = reinterpret_cast<const half8*>(smem);
     const float* ctab = reinterpret_cast<const float*>(smem + (size_t)WF * FRAG);
-    float* G = reinterpret_cast<float*>(smem + (size_t)(WF + 1) * FRAG);
+    // lines: [row][group of 4 pixels][feature 0..31][pixel % 4] x (hi, lo * 2^11) halfs = 16 bytes per (row, group, feature)
+    uint8_t* G0 = smem + (size_t)(WF + 1) * FRAG;
+    const size_t gbytes = (size_t)LAT_ROWS * RG * 32 * 16;
+    unsigned* counter = reinterpret_cast<unsigned*>(G0 + (DBUF ? 2 : 1) * gbytes);
     const half8* Wg = reinterpret_cast<const half8*>(img);
     const half_t* planes = reinterpret_cast<const half_t*>(a.planes);
     const size_t plane_stride = (size_t)a.B * R2 * CD;         // features per plane
-    const int ntile = (R2 + 31) >> 5;
+    const int tz_n = R >> 3, ntile = (R >> 2) * tz_n;          // tiles of 4 iy x 8 iz
+    const int tcount = ntile / NP;                             // tiles per unit
     const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    // one-hot selectors (B operands; constant): this lane's point sits at (dy, dz) = (n >> 3, n & 7) of its tile.  k-slot pair
+    // j of SEL_y (hi = 0 lanes only) is iy0 + j; k-slot pair j of SEL_z is iz0 + 4 hi + j.  The halves of a pair carry
+    // (1, 2^-11): the A operand holds (hi, 2^11 lo) of the line value there.
+    half8 sel_y = zero8, sel_z = zero8;
+    {
+        const int dy = n >> 3, dz = n & 7;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool my = hi == 0 && dy == j, mz = dz == 4 * hi + j;
+            sel_y[2 * j] = my ? (half_t)1.0f : (half_t)0.0f; sel_y[2 * j + 1] = my ? (half_t)LAT_LO_INV : (half_t)0.0f;
+            sel_z[2 * j] = mz ? (half_t)1.0f : (half_t)0.0f; sel_z[2 * j + 1] = mz ? (half_t)LAT_LO_INV : (half_t)0.0f;
+        }
+    }
 
     // features of pixel `off` of plane `pl`, scene b: chunk hf (16 channels; this lane's 8) as B operands
     auto load_feat = [&](int b, int pl, int off, int hf, half8& fh, half8& fl) {
@@ -670,15 +708,6 @@ __global__ __launch_bounds__(NW * 64) void decoder_lat_kernel(DecArgs a) {
         }
         return c0;
     };
-    // net += line row `row` at pixel px  (this lane's 16 features: 8q + 4hi + j)
-    auto add_line = [&](int row, int px, f32x16& net) {
-        const float* g = G + ((size_t)row * R + px) * LAT_GS + 4 * hi;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(g + 8 * q);
-            net[4 * q + 0] += v.x; net[4 * q + 1] += v.y; net[4 * q + 2] += v.z; net[4 * q + 3] += v.w;
-        }
-    };
     // dst += W(frag0 + PR*c) * relu(src), c = 0, 1 (resident fragments)
     auto dense = [&](int frag0, const f32x16& src, f32x16& dst) {
         half8 xh[2], xl[2];
@@ -690,75 +719,154 @@ __global__ __launch_bounds__(NW * 64) void decoder_lat_kernel(DecArgs a) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) mm1(W, frag0 + PR * c, xh[c], xl[c], dst);
     };
-
-    bool first = true;
-    for (int slab = slab_lo; slab < slab_hi; ++slab) {
+    // ---- one line job of slab `slab`: row (job >> 1), pixels 32 (job & 1) .. + 31, into line buffer G
+    auto line_job = [&](int unit, int job, uint8_t* G) {
+        const int slab = unit / NP;
         const int b = slab / R, ix = slab - b * R;             // (uniform)
         const float px_ = a.lin[ix];
-        // ---------------- line phase: G rows of this slab -> LDS
-        if (!first) __syncthreads();                            // everyone has left the previous slab's lines
-        for (int job = wave; job < 2 * LAT_ROWS; job += NW) {
-            const int row = job >> 1, ct = job & 1;
-            if (32 * ct >= R) continue;
-            const bool xy = row >= NBLK;
-            const int blk = xy ? row - NBLK : row;
-            int px = 32 * ct + n;
-            const bool pvalid = px < R;
-            px = pvalid ? px : R - 1;
-            f32x16 acc;
+        const int row = job >> 1, ct = job & 1;
+        if (32 * ct >= R) return;
+        const bool xy = row >= NBLK;
+        const int blk = xy ? row - NBLK : row;
+        int px = 32 * ct + n;
+        const bool pvalid = px < R;
+        px = pvalid ? px : R - 1;
+        f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            if (blk < NBLK) {
-                const int pl = xy ? 1 : 0;                      // plane xz: pixel (H = iz, W = ix); plane xy: (H = iy, W = ix)
-                half8 fh[2], fl[2];
-                load_feat(b, pl, px * R + ix, 0, fh[0], fl[0]);
-                load_feat(b, pl, px * R + ix, 1, fh[1], fl[1]);
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (blk < NBLK) {
+            const int pl = xy ? 1 : 0;                          // plane xz: pixel (H = iz, W = ix); plane xy: (H = iy, W = ix)
+            half8 fh[2], fl[2];
+            load_feat(b, pl, px * R + ix, 0, fh[0], fl[0]);
+            load_feat(b, pl, px * R + ix, 1, fh[1], fl[1]);
 #pragma unroll
-                for (int c = 0; c < 2; ++c) mm1(Wg, BLK * blk + PR * (2 * pl + c), fh[c], fl[c], acc);
+            for (int c = 0; c < 2; ++c) mm1(Wg, BLK * blk + PR * (2 * pl + c), fh[c], fl[c], acc);
+        }
+        if (xy || blk == 0) {
+            // aux fragment: k-slots [p_hi(3), 1, p_lo(3), 1] on hi = 0 lanes, [p_hi(3), 0...] on hi = 1 lanes.  fc_p is linear in p:
+            // the xy line carries the x and y terms and the constant-one slots (the biases), the xz line the z term.
+            const float pc = a.lin[px];
+            const half_t ch = (half_t)pc, xh_ = (half_t)px_;
+            half8 av = zero8;
+            if (xy) {
+                av[0] = xh_; av[1] = ch;
+                if (hi == 0) { av[3] = (half_t)1.0f; av[4] = (half_t)(px_ - (float)xh_); av[5] = (half_t)(pc - (float)ch); av[7] = (half_t)1.0f; }
+            } else {
+                av[2] = ch;
+                if (hi == 0) av[6] = (half_t)(pc - (float)ch);
             }
-            if (xy || blk == 0) {
-                // aux fragment: k-slots [p_hi(3), 1, p_lo(3), 1] on hi = 0 lanes, [p_hi(3), 0...] on hi = 1 lanes.  fc_p is linear
-                // in p: the xy line carries the x and y terms and the constant-one slots (the biases), the xz line the z term.
-                const float pc = a.lin[px];
-                const half_t ch = (half_t)pc, xh_ = (half_t)px_;
-                half8 av = zero8;
-                if (xy) {
-                    av[0] = xh_; av[1] = ch;
-                    if (hi == 0) { av[3] = (half_t)1.0f; av[4] = (half_t)(px_ - (float)xh_); av[5] = (half_t)(pc - (float)ch); av[7] = (half_t)1.0f; }
-                } else {
-                    av[2] = ch;
-                    if (hi == 0) av[6] = (half_t)(pc - (float)ch);
-                }
-                acc = mfma16(Wg[(blk < NBLK ? BLK * blk + F_AUX : F_TAIL) * 64 + lane], av, acc);
-            }
-            if (pvalid) {
-                float* g = G + ((size_t)row * R + px) * LAT_GS + 4 * hi;
+            acc = mfma16(Wg[(blk < NBLK ? BLK * blk + F_AUX : F_TAIL) * 64 + lane], av, acc);
+        }
+        if (pvalid) {                                           // this lane: pixel px, features 8q + 4hi + j  ->  (hi, 2^11 lo) pairs
+            uint8_t* g = G + ((size_t)(row * RG + (px >> 2)) * 32) * 16 + (px & 3) * 4;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(g + 8 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            for (int r = 0; r < 16; ++r) {
+                const half_t h = (half_t)acc[r];
+                const half_t l = (half_t)((acc[r] - (float)h) * LAT_LO_SCALE);
+                const half2v pr = {h, l};
+                *reinterpret_cast<half2v*>(g + (8 * (r >> 2) + 4 * hi + (r & 3)) * 16) = pr;
             }
         }
-        if (first) __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0): my share of the resident image has landed
-        first = false;
-        __syncthreads();
-        // ---------------- tile phase: 32 points (iy, iz) of the slab per wave and step
-        for (int t = wave; t < ntile; t += NW) {
+    };
+    // yz features of tile t of slab `slab_` (this lane's point): requested one item AHEAD -- the L2 / HBM round trip of a tile's
+    // features (a few thousand clocks) otherwise stalls every chain at its third MFMA
+    auto tile_feat = [&](int unit_, int tl_, half8 (&fh)[2], half8 (&fl)[2]) {
+        const int slab_ = unit_ / NP, t_ = (unit_ - slab_ * NP) * tcount + tl_;
+        const int b_ = slab_ / R;                              // (uniform)
+        const int ty = t_ / tz_n, tz = t_ - ty * tz_n;
+        const int iy = 4 * ty + (n >> 3), iz = 8 * tz + (n & 7);
+        load_feat(b_, 2, iz * R + iy, 0, fh[0], fl[0]);         // plane yz: pixel (H = iz, W = iy)
+        load_feat(b_, 2, iz * R + iy, 1, fh[1], fl[1]);
+    };
+    // next item of the workgroup's stream (one LDS atomic per item; the value is wave-uniform)
+    auto grab = [&]() -> int {
+        unsigned g = 0;
+        if (lane == 0) g = atomicAdd(counter, 1u);
+        return __builtin_amdgcn_readfirstlane((int)g);
+    };
+
+    DEC_T(1);
+    if (threadIdx.x == 0) *counter = 0u;
+    for (int job = wave; job < NJOB; job += NW) line_job(slab_lo, job, G0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): my share of the resident image has landed
+    DEC_T(3);
+    __syncthreads();
+    DEC_T(4);
+    const int npool = slab_hi - slab_lo;
+    const int POOL = DBUF ? tcount + NJOB : tcount;            // items per pool: the unit's tiles (+ the next unit's line jobs)
+    // position k of a pool -> tile index (>= 0) or line job (-1 - job).  With two buffers every third position (2, 5, 8, ...) is a
+    // line job of the next slab until the NJOB jobs are out: a line job is a chain of L2 round trips with a handful of MFMAs, and
+    // spread like this it runs under the tiles of the SIMD's other waves instead of 22 of them idling the matrix pipes together at
+    // the end of the pool; the pool's last positions are tiles.
+    const bool mix = tcount >= 2 * NJOB;                       // (small units: the jobs simply follow the tiles)
+    auto pool_tile = [&](int k) -> int {
+        if constexpr (!DBUF) return k;
+        if (!mix) return k < tcount ? k : -1 - (k - tcount);
+        if (k < 3 * NJOB) { const int j = (k + 1) / 3; return (k % 3 == 2) ? -j : k - j; }    // (k % 3 == 2: job j - 1 = k / 3)
+        return k - NJOB;
+    };
+    int cur = 0;                                               // the pool whose barrier this wave has not passed yet
+    int item = grab();
+    half8 nfh[2], nfl[2];
+    {
+        const int p0 = item / POOL, t0 = pool_tile(item - p0 * POOL);
+        if (p0 < npool && t0 >= 0) tile_feat(slab_lo + p0, t0, nfh, nfl);
+    }
+    int ntiles_done = 0;
+    while (true) {
+        const int pool = item / POOL, k = item - pool * POOL;
+        // slab boundaries between this wave's previous item and this one (every wave passes each of them exactly once)
+        const int upto = pool < npool ? pool : npool - 1;
+        while (cur < upto) {
+            if (cur < 2) DEC_T(8 + 3 * cur);
+            __syncthreads();                                    // pool `cur` is drained: its tiles are done (DBUF: and the next lines complete)
+            if constexpr (!DBUF) {
+                for (int job = wave; job < NJOB; job += NW) line_job(slab_lo + cur + 1, job, G0);
+                __syncthreads();
+            }
+            if (cur < 2) DEC_T(10 + 3 * cur);
+            ++cur;
+        }
+        if (pool >= npool) break;
+        const int slab = slab_lo + pool;
+        const int nxt = grab();                                 // the item after this one: its features are requested now
+        const int t = pool_tile(k);
+        if (t < 0) {                                            // (DBUF) a line job of the next slab, into the other buffer
+            if (slab + 1 < slab_hi) line_job(slab + 1, -1 - t, G0 + (size_t)((pool + 1) & 1) * gbytes);
+            const int pn = nxt / POOL, tn = pool_tile(nxt - pn * POOL);
+            if (pn < npool && tn >= 0) tile_feat(slab_lo + pn, tn, nfh, nfl);
+            item = nxt;
+            continue;
+        }
+        const int sl = slab / NP, t_g = (slab - sl * NP) * tcount + t;      // the unit's slab; the tile's index inside the slab
+        const int b = sl / R, ix = sl - b * R;                 // (uniform)
+        const uint8_t* G = G0 + (DBUF ? (size_t)(pool & 1) * gbytes : 0);
+        // net += line row `row`, pixel group `grp` (this lane: feature n, the group's 4 pixels as (hi, lo) pairs) through `sel`
+        auto add_line = [&](int row, int grp, const half8& sel, f32x16& net) {
+            const half8 A = *reinterpret_cast<const half8*>(G + ((size_t)(row * RG + grp) * 32 + n) * 16);
+            net = mfma16(A, sel, net);
+        };
+        {
+            // ---------------- one tile: 4 iy x 8 iz points of the slab
             // (compiler barrier: the weight fragments are loop-invariant LDS reads, and hoisting all of them out of this loop --
             //  130-260 registers -- spills the whole chain)
             asm volatile("" ::: "memory");
-            int rr = 32 * t + n;
-            const bool valid = rr < R2;
-            rr = valid ? rr : R2 - 1;
-            const int iy = div_magic(rr, a.mR), iz = rr - iy * R;
-            const long long gidx = (long long)b * a.N + (long long)ix * R2 + rr;
+            const int ty = t_g / tz_n, tz = t_g - ty * tz_n;    // (uniform)
+            const int iy = 4 * ty + (n >> 3), iz = 8 * tz + (n & 7);
+            const long long gidx = (long long)b * a.N + (long long)ix * R2 + iy * R + iz;
+            const int gy = ty, gz = 2 * tz + hi;                // line groups: SEL_y's four iy; this lane half's four iz
             half8 cfh[2], cfl[2];
-            load_feat(b, 2, iz * R + iy, 0, cfh[0], cfl[0]);    // plane yz: pixel (H = iz, W = iy)
-            load_feat(b, 2, iz * R + iy, 1, cfh[1], cfl[1]);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { cfh[c] = nfh[c]; cfl[c] = nfl[c]; }
+            {
+                const int pn = nxt / POOL, tn = pool_tile(nxt - pn * POOL);
+                if (pn < npool && tn >= 0) tile_feat(slab_lo + pn, tn, nfh, nfl);
+            }
             f32x16 net, hh;
 #pragma unroll
             for (int r = 0; r < 16; ++r) net[r] = 0.f;
-            add_line(0, iz, net);
-            add_line(NBLK, iy, net);
+            add_line(0, gz, sel_z, net);
+            add_line(NBLK, gy, sel_y, net);
 #pragma unroll
             for (int c = 0; c < 2; ++c) mm1(W, PR * c, cfh[c], cfl[c], net);
 #pragma unroll
@@ -769,20 +877,24 @@ __global__ __launch_bounds__(NW * 64) void decoder_lat_kernel(DecArgs a) {
                 // every term of the residual stream is an accumulation: the next block's fc_c (lines + yz part) goes here, where
                 // it covers the conversion of hh
                 if (blk + 1 < NBLK) {
-                    add_line(blk + 1, iz, net);
-                    add_line(NBLK + blk + 1, iy, net);
+                    add_line(blk + 1, gz, sel_z, net);
+                    add_line(NBLK + blk + 1, gy, sel_y, net);
 #pragma unroll
                     for (int c = 0; c < 2; ++c) mm1(W, wb + 6 * PR + PR * c, cfh[c], cfl[c], net);
                 } else {
-                    add_line(2 * NBLK, iy, net);                // bias of the last fc_1
+                    add_line(2 * NBLK, gy, sel_y, net);         // bias of the last fc_1
                 }
                 dense(wb + 4 * PR, hh, net);                    // net += fc_1(relu(hh))
             }
             f32x16 o = ctab_regs(NBLK);
             dense(30 * PR, net, o);                             // fc_out(relu(net))
-            if (hi == 0 && valid) store_head(a, hsel, gidx, o[0], o[1], o[2], o[3]);
+            if (hi == 0) store_head(a, hsel, gidx, o[0], o[1], o[2], o[3]);
+            if (pool == 0 && ntiles_done < 3) DEC_T(5 + ntiles_done);   // (diagnostic builds: end of this wave's 1st / 2nd / 3rd tile)
+            ++ntiles_done;
         }
+        item = nxt;
     }
+    DEC_T(15);
 }
 
 #ifdef GIGA_TRACE
@@ -1125,23 +1237,43 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
     // up the shared-feature kernel is the faster one, 297 vs 323 us at 32 scenes).  grid = slots x nheads <= 256 (one workgroup per CU).  Two tiles per wave (the weight fragments
     // are read from LDS once per two tiles) when every workgroup gets at least two such rounds, else one tile per wave.
     // (tuning knob, read once: GIGA_DEC16_RESIDENT=0/1 forces the choice for plain f16; measurements in DESIGN.md)
-    // Lattice launches of the f16-class modes from 4 scenes up: the separable-fc_c kernel (decoder_lat_kernel); smaller ones are
-    // latency-bound and keep the head-resident kernel below.  (tuning knob: GIGA_DEC_LAT=0/1 forces the choice)
+    // Lattice launches of the f16-class modes with R % 8 == 0 (the inference lattice: R = 40): the separable-fc_c kernel
+    // (decoder_lat_kernel) -- f16x3 always (1 scene 31.8 -> 27.8 us, 32 scenes 0.754 -> 0.583 ms), plain f16 from 4 scenes up (32 scenes
+    // 0.279 -> 0.260 ms; a single scene is latency-bound and 1 us faster on the head-resident kernel below, which also serves other
+    // lattices).  (tuning knob: GIGA_DEC_LAT=0 / 1 forces the choice)
     const int force_lat = [] { const char* e = getenv("GIGA_DEC_LAT"); return e ? atoi(e) : -1; }();   // (per call: A/B runs in one process)
-    if (lat && (precision == 1 || precision == 2) && a.R <= LAT_MAX_R && (force_lat >= 0 ? force_lat != 0 : a.B >= 4)) {
-        constexpr int NW = 12;
-        const int nslab = a.B * a.R;
+    if (lat && (precision == 1 || precision == 2) && a.R <= LAT_MAX_R && a.R % 8 == 0 && (force_lat >= 0 ? force_lat != 0 : (precision == 2 || a.B >= 4))) {
         const int cap = 256 / a.nheads, cap8 = 256 / (8 * a.nheads) * 8;
+        // small launches: hand a slab out in parts (NP divides the tile count), so that a single scene still covers the chip; a
+        // part costs its tiles plus one line phase (~ the time of 12 tiles on a workgroup)
+        const int ntile = (a.R / 4) * (a.R / 8);
+        int np = 1;
+        {
+            double best = 1e30;
+            for (int c : {1, 2, 5}) {
+                if (ntile % c) continue;
+                const long long units = (long long)a.B * a.R * c;
+                const long long rounds = (units + cap - 1) / cap;
+                const double cost = (double)rounds * ((double)ntile / c + 12.0);
+                if (cost < best - 1e-9) { best = cost; np = c; }
+            }
+        }
+        a.lat_parts = np;
+        const int nslab = a.B * a.R * np;
         int slots = nslab < cap ? nslab : (nslab >= 2 * cap8 && cap8 > 0 ? cap8 : cap);
         a.nbatch = slots;
+        // (tuning knob: GIGA_LAT_NW = 12 | 16 waves per workgroup; 16 = four per SIMD, the default: 0.267 -> 0.257 ms at 32 scenes)
+        const int nw = [] { const char* e = getenv("GIGA_LAT_NW"); return e ? atoi(e) : 16; }();
+        auto go = [&](auto kern, int NWv, size_t lds) {
+            giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
+            GIGA_LAUNCH(kern, dim3(slots * a.nheads), dim3(NWv * 64), lds, s, a);
+        };
         if (precision == 2) {
-            const size_t lds = lat_lds_bytes<true>(a.R);
-            giga::dyn_lds_once(reinterpret_cast<const void*>(decoder_lat_kernel<true, NW>), (int)lds);
-            GIGA_LAUNCH((decoder_lat_kernel<true, NW>), dim3(slots * a.nheads), dim3(NW * 64), lds, s, a);
+            if (nw == 16) go(decoder_lat_kernel<true, 16, false>, 16, lat_lds_bytes<true, false>(a.R));
+            else go(decoder_lat_kernel<true, 12, false>, 12, lat_lds_bytes<true, false>(a.R));
         } else {
-            const size_t lds = lat_lds_bytes<false>(a.R);
-            giga::dyn_lds_once(reinterpret_cast<const void*>(decoder_lat_kernel<false, NW>), (int)lds);
-            GIGA_LAUNCH((decoder_lat_kernel<false, NW>), dim3(slots * a.nheads), dim3(NW * 64), lds, s, a);
+            if (nw == 16) go(decoder_lat_kernel<false, 16, true>, 16, lat_lds_bytes<false, true>(a.R));
+            else go(decoder_lat_kernel<false, 12, true>, 12, lat_lds_bytes<false, true>(a.R));
         }
         if (ev0 && ev1) (void)hipEventRecord(static_cast<hipEvent_t>(ev1), s);
         return hipGetLastError() == hipSuccess ? 0 : -10;

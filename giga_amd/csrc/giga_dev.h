@@ -83,6 +83,12 @@ __device__ __forceinline__ void lane16_swap(float& a, float& b) {
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
+// f16x3 split of relu(D registers 8c..8c+7): hi = f16(x) (round to nearest), lo = f16(x - hi); hi + lo carries x to ~2^-22
+// relative.  Compiles to v_cvt_pk_f16_f32 (hi pairs) + v_cvt_f32_f16 / v_sub_f32 / v_cvt_f16_f32 per element (~4 VALU per
+// element).  MEASURED DEAD END (round 3): the two-instruction form with v_fma_mixlo/hi_f16 in inline asm (2.5 VALU per element)
+// is only 1.5-5 % faster on the f16x3 decoders (they wait on barriers and latency, not on VALU issue) and is unsafe without a
+// hand-placed `s_nop 1`: the compiler keeps two wait states between a VALU write and an MFMA that reads the register, and does
+// not see through the asm -- the separable-fc_c decoder read stale lo halves (6e-5 errors; profiles/r03_notes).
 __device__ __forceinline__ void split_relu8(const f32x16& d, int c, half8& hi, half8& lo) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

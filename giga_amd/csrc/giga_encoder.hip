@@ -506,10 +506,17 @@ __global__ __launch_bounds__(MEGA_NW * 64) void unet_mega_kernel(MegaArgs m) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int xcd = (int)blockIdx.x & 7, block = (int)blockIdx.x >> 3, nblocks = (int)gridDim.x >> 3;
     // The barriers below are XCD-local (workgroup-scope atomics, no agent-scope release / acquire): they are only correct if
-    // the workgroups that share a counter share an L2, i.e. if workgroup i really runs on XCD i % 8.  That is the observed
-    // dispatch order, not a contract (CU masks, partition modes, a new dispatcher): check it against the hardware register and
-    // fail loudly instead of returning stale activations.
-    if ((__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15) != xcd) __builtin_trap();      // HW_REG_XCC_ID[3:0]
+    // the workgroups that share a counter share an L2, i.e. if the workgroups i with equal i % 8 really run on one XCD.  That is
+    // the observed dispatch order, not a contract (CU masks, partition modes, a new dispatcher): check it against the hardware
+    // register and fail loudly instead of returning stale activations.
+    // (NOT "XCC_ID == blockIdx % 8": the dispatcher's round-robin pointer carries over from the previous launch, so after a grid
+    //  that is not a multiple of 8 the map is rotated -- still one XCD per residue class, which is all the barriers need.  Each
+    //  class therefore agrees on ONE XCC_ID through a tag word next to its counter, zeroed with the counters before the launch.)
+    if (threadIdx.x == 0) {
+        const unsigned mine = (unsigned)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15) + 1u;     // HW_REG_XCC_ID[3:0] + 1
+        const unsigned seen = atomicCAS(m.sync + xcd * 32 + 1, 0u, mine);
+        if (seen != 0u && seen != mine) __builtin_trap();
+    }
     const int per = m.layer[0].nimg >> 3, img0 = xcd * per;                 // (the host guarantees nimg % 8 == 0)
     unsigned* counter = m.sync + xcd * 32;
     unsigned epoch = 0;

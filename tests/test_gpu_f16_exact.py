@@ -44,9 +44,14 @@ def assert_within_one_ulp(got, want, what):
     """`want` is the fp32 value before the final rounding to f16, `got` the kernel's f16 result."""
     w16 = h16(want)
     diff = (got - w16).abs()
-    tol = ulp16(torch.maximum(got.abs(), w16.abs())) * 1.001 + 1e-7
+    # one f16 ulp at the value, plus the fp32 accumulation noise of a sum of O(1) terms that cancels (2e-6 of the layer's range:
+    # near zero -- ReLU outputs of 1e-5 -- the f16 grid is finer than that noise, 6e-8 in the subnormal range)
+    tol = ulp16(torch.maximum(got.abs(), w16.abs())) * 1.001 + 2e-6 * max(1.0, float(want.abs().max()))
     bad = diff > tol
-    assert not bool(bad.any()), (what, float(diff.max()), int(bad.sum()))
+    if bool(bad.any()):
+        idx = bad.flatten().nonzero().flatten()[:6]
+        rows = [(float(got.flatten()[i]), float(want.flatten()[i]), float(w16.flatten()[i])) for i in idx]
+        raise AssertionError((what, "more than one f16 ulp", int(bad.sum()), "of", bad.numel(), "(got, want fp32, want f16):", rows))
     frac = float((diff > 0).float().mean())
     assert frac < 0.02, (what, "fraction of flipped roundings", frac)
     return frac
@@ -96,8 +101,10 @@ def test_f16_unet_and_conv_in_layer_by_layer(sd7):
         for q, s in (("Q0", "S0"), ("Q1", "S1")):            # the fused 2x2 max-pool: max then round == round then max
             assert torch.equal(stage(q), F.max_pool2d(stage(s), 2, 2)), q
         final = F.conv2d(stage("A6"), W("conv_final"), Bi("conv_final"))
-        planes = torch.cat([got[k] for k in O.PLANES]).cpu()[keep]
+        planes = got.nhwc.reshape(3 * Bs, 40, 40, 32)[keep].permute(0, 3, 1, 2).float().cpu()     # the f16 image the decoders read
         assert_within_one_ulp(planes, final, ("conv_final", Bs))
+        nchw = torch.cat([got[k] for k in O.PLANES]).cpu()[keep]        # the reference-layout copy: the same values before rounding
+        assert float((nchw - final).abs().max()) <= 2e-6 * max(1.0, float(final.abs().max())) + 1e-6
 
 
 def _decoder_f16_operands(sd, head, p, c, dt=torch.float32):

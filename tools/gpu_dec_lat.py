@@ -26,6 +26,7 @@ with torch.no_grad():
     ref = O.model_forward(sd, torch.from_numpy(synth.tsdf_batch(1000, 1)), O.inference_lattice())
 ms = ctypes.c_float()
 rows = []
+MODES = tuple(os.environ.get("DEC_LAT_MODES", "0,1").split(","))
 sizes = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "4,8,32,128".split(","))]
 for prec in ("fp16", "fp16x3"):
     net.set_precision(prec)
@@ -34,31 +35,42 @@ for prec in ("fp16", "fp16x3"):
         x = torch.from_numpy(synth.tsdf_batch(1000, B)).to(dev)
         with torch.no_grad():
             nhwc, _ = net.encoder.encode_nhwc(x, blob=blob, precision=prec, fold_final=True)
-        res = {}
-        for mode in ("0", "1"):
-            os.environ["GIGA_DEC_LAT"] = mode
-            evs = [(L.giga_event_create(), L.giga_event_create()) for _ in range(12)]
-            with torch.no_grad():
-                for _ in range(3):
-                    out = decode_heads(nhwc, lat, blob, 7, prec, True, folded=True)
-                torch.cuda.synchronize()
-                for e in evs:
-                    out = decode_heads(nhwc, lat, blob, 7, prec, True, probe=e, folded=True)
+        res, times = {}, {m: [] for m in MODES}
+
+        def setmode(mode):
+            os.environ["GIGA_DEC_LAT"] = mode.split("n")[0]     # "1n16": separable kernel with 16 waves per workgroup
+            os.environ["GIGA_LAT_NW"] = mode.split("n")[1] if "n" in mode else "12"
+
+        with torch.no_grad():
+            setmode(MODES[-1])
+            for _ in range(max(4, int(30.0 / (0.01 * B + 0.05)))):      # ~30 ms of work: clocks up before anything is timed
+                decode_heads(nhwc, lat, blob, 7, prec, True, folded=True)
             torch.cuda.synchronize()
-            t = []
-            for a, b in evs:
-                _capi.check(L.giga_event_elapsed_ms(a, b, ctypes.byref(ms)), "event"); t.append(ms.value)
-                L.giga_event_destroy(a); L.giga_event_destroy(b)
-            res[mode] = (float(np.median(t)), {k: v.clone() for k, v in out.items()})
-        os.environ.pop("GIGA_DEC_LAT", None)
-        t0, o0 = res["0"]; t1, o1 = res["1"]
-        d_ab = {k: float((o0[k] - o1[k]).abs().max()) for k in o0}
-        e_old = {k: float((o0[k][:1].cpu() - r).abs().max()) for k, r in zip(("decoder_qual", "decoder_rot", "decoder_width"), ref)}
-        e_new = {k: float((o1[k][:1].cpu() - r).abs().max()) for k, r in zip(("decoder_qual", "decoder_rot", "decoder_width"), ref)}
+            for rnd in range(4):                                 # modes interleaved: clock / thermal drift hits all of them alike
+                for mode in MODES:
+                    setmode(mode)
+                    evs = [(L.giga_event_create(), L.giga_event_create()) for _ in range(6)]
+                    out = decode_heads(nhwc, lat, blob, 7, prec, True, folded=True)
+                    for e in evs:
+                        out = decode_heads(nhwc, lat, blob, 7, prec, True, probe=e, folded=True)
+                    torch.cuda.synchronize()
+                    for a, b in evs:
+                        _capi.check(L.giga_event_elapsed_ms(a, b, ctypes.byref(ms)), "event"); times[mode].append(ms.value)
+                        L.giga_event_destroy(a); L.giga_event_destroy(b)
+                    res[mode] = (0.0, {k: v.clone() for k, v in out.items()})
+        for mode in MODES:
+            res[mode] = (float(np.median(times[mode])), res[mode][1])
+        os.environ.pop("GIGA_DEC_LAT", None); os.environ.pop("GIGA_LAT_NW", None)
+        t0, o0 = res["0"]
         fl = B * 64000 * FLOP_GRASP3
-        row = {"prec": prec, "scenes": B, "old_ms": round(t0, 4), "new_ms": round(t1, 4), "speedup": round(t0 / t1, 3),
-               "old_alg_frac_f16_peak": round(fl / (t0 * 1e-3) / 2.5e15, 3), "new_alg_frac_f16_peak": round(fl / (t1 * 1e-3) / 2.5e15, 3),
-               "max_abs_old_vs_new": d_ab, "scene0_err_old": e_old, "scene0_err_new": e_new,
-               "finite": bool(all(torch.isfinite(v).all() for v in o1.values()))}
+        names = ("decoder_qual", "decoder_rot", "decoder_width")
+        row = {"prec": prec, "scenes": B}
+        for mode in MODES:
+            t, o = res[mode]
+            row[f"ms_{mode}"] = round(t, 4)
+            row[f"alg_frac_{mode}"] = round(fl / (t * 1e-3) / 2.5e15, 3)
+            row[f"err_{mode}"] = [float("%.2e" % float((o[k][:1].cpu() - r).abs().max())) for k, r in zip(names, ref)]
+            row[f"vs0_{mode}"] = [float("%.2e" % float((o0[k] - o[k]).abs().max())) for k in names]
+            row[f"finite_{mode}"] = bool(all(torch.isfinite(v).all() for v in o.values()))
         rows.append(row)
         print(json.dumps(row), flush=True)

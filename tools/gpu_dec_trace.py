@@ -24,6 +24,9 @@ t0 = buf[:, 0][buf[:, 0] > 0].min()
 names = {0: "entry", 1: "dma out", 15: "exit"}
 for it in range(4):
     names[2 + 3 * it] = f"r{it} feat"; names[3 + 3 * it] = f"r{it} go"; names[4 + 3 * it] = f"r{it} done"
+if B >= 4:      # decoder_lat_kernel's points
+    names = {0: "entry", 1: "dma out", 2: "lines0", 3: "stored", 4: "barrier", 5: "tile1", 6: "tile2", 7: "tile3", 8: "slab0 tiles", 9: "lines1",
+             10: "slab0 end", 11: "slab1 tiles", 12: "lines2", 13: "slab1 end"}
 print("clocks since the first wave's entry; columns = waves")
 for k in range(16):
     if (buf[:, k] == 0).all():

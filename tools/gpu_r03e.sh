@@ -1,0 +1,5 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; R=$PWD; T=${1:-r03e}
+O=$R/gpurun_out/$T; mkdir -p $O; export TMPDIR=/tmp PYTHONPATH=$R
+DEC_LAT_MODES=0,1,3 timeout 600 python tools/gpu_dec_lat.py 8,32 > $O/dec_lat.txt 2> $O/dec_lat.err; echo "dec_lat rc=$?"; cat $O/dec_lat.txt | cut -c1-900; tail -n 3 $O/dec_lat.err
+timeout 900 python -m pytest tests/test_gpu_f16_exact.py tests/test_gpu_c4_shapes.py -q -n 1 > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -n 12 $O/pytest.log | cut -c1-600
