@@ -36,6 +36,7 @@ struct ConvArgs {
     int nimg;
     int cs0, co0, cs1, co1;              // channel stride / first channel of in0, in1 (0 stride = dense C0 / C1)
     int trace_id;                        // layer index (diagnostic builds)
+    int xcd_local;                       // 1: per-layer launches map the images onto the XCDs (conv_wg_map)
 };
 
 constexpr int MATH_NATIVE = 0, MATH_SPLIT = 1, MATH_BF16 = 2;
@@ -83,13 +84,39 @@ constexpr int conv_nw() {       // (SPLIT instantiations have T = float and exac
 // value v to the pair hi = f16(v), lo = f16(v - hi) (patch pixel = 4 groups of 8 channels x [8 hi | 8 lo] halfs, 128 B as for
 // fp32), the resident weights are [hi, lo] fragment pairs, and every (tap, 32-channel chunk) is three v_mfma_f32_16x16x32_f16
 // (W_lo*x_hi + W_hi*x_lo + W_hi*x_hi) instead of eight v_mfma_f32_16x16x4_f32: fp32-grade results at 5x less MFMA time.
+// (Measured dead end, round 3: shipping the activations between the layers as (hi | lo << 16) words, split once by the producing
+// epilogue so that staging only permutes bytes -- 1 VALU instruction per staged value instead of 5 -- changes no layer's time
+// (profiles/r03/encoder_stage_times_packed_x3_experiment.txt): the split layers wait on LDS operand reads, 1.3 KiB per 17-clock
+// MFMA, not on the conversion.)
 // The layer is written as two device functions so that it can run either as its own kernel (conv16_kernel) or as one
 // stage of the persistent U-Net kernel (unet_mega_kernel, giga_encoder.hip):
 //   conv16_fill : issue the LDS-DMA of this workgroup's weight group (all launched waves take part)
 //   conv16_run  : wait for it, then walk the units.  `block` / `nblocks` replace blockIdx.x / gridDim.x; waves beyond the
 //                 layer's own wave count (launched because another stage needs them) only take part in the barrier.
+// Workgroup -> (weight group, position among the group's workgroups, image range).  Plain map: group = block % NGRP, every group
+// walks all images.  XCD-LOCAL map (per-layer launches of large batches): workgroup b runs on XCD b % 8 (the dispatcher's
+// round-robin; an offset from the previous launch only renames the XCDs), and each XCD has its own 4-MiB L2.  A unit's haloed
+// patch is read by the NGRP workgroups that compute its output-channel groups and, through the halo, by its neighbours: with
+// group = b % NGRP those readers sit on different XCDs -- b % 8 fixes b % NGRP, so an XCD computes ONE group for ALL images -- and
+// every re-read crosses the fabric (139.5 MB per launch for 29.8 MB of input in up0.conv1, profiles/r02_traffic_c2.json).  Here XCD x
+// takes the x-th eighth of the images and its workgroups cover all the groups, so the re-reads hit in that XCD's L2.
+struct ConvWgMap { int grp, wg_in_grp, wgs_per_grp, img0, nimg; };
+template <int NGRP>
+__device__ __forceinline__ ConvWgMap conv_wg_map(const ConvArgs& a, int block, int nblocks) {
+    ConvWgMap m;
+    if (a.xcd_local && nblocks % (8 * NGRP) == 0 && a.nimg % 8 == 0) {
+        const int xcd = block & 7, j = block >> 3;
+        m.grp = j % NGRP; m.wg_in_grp = j / NGRP; m.wgs_per_grp = (nblocks >> 3) / NGRP;
+        m.nimg = a.nimg >> 3; m.img0 = xcd * m.nimg;
+    } else {
+        m.grp = block % NGRP; m.wg_in_grp = block / NGRP; m.wgs_per_grp = nblocks / NGRP;
+        m.nimg = a.nimg; m.img0 = 0;
+    }
+    return m;
+}
+
 template <typename T, int KIND, int C0, int C1, int COUT, int NB, int MATH>
-__device__ __forceinline__ void conv16_fill(const ConvArgs& a, uint8_t* smem, int block) {
+__device__ __forceinline__ void conv16_fill(const ConvArgs& a, uint8_t* smem, int block, int nblocks) {
     constexpr bool SPLIT = MATH == MATH_SPLIT;
     constexpr int TAPS = KIND == CONV3 ? 9 : KIND == DOWN ? 4 : 1;
     constexpr int KGT = (C0 + C1) / 32 * ((sizeof(T) == 2 || MATH != MATH_NATIVE) ? 1 : 2);
@@ -99,7 +126,7 @@ __device__ __forceinline__ void conv16_fill(const ConvArgs& a, uint8_t* smem, in
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwl = blockDim.x >> 6;
-    const int grp = block % NGRP;
+    const int grp = conv_wg_map<NGRP>(a, block, nblocks).grp;
     const int sub = grp / CG, nb0 = (grp % CG) * NB;
     // fragments of (sub, nb0 .. nb0+NB-1) are contiguous in the packed blob: [sub][nb][tap][kg]
     const uint8_t* wsrc = a.w + (size_t)(sub * NBT + nb0) * TAPS * KGT * WPF * FRAG;
@@ -150,13 +177,14 @@ __device__ __forceinline__ void conv16_run(const ConvArgs& a, uint8_t* smem, int
     CONV_T(0);
 
     // this workgroup's weight group (filled by conv16_fill)
-    const int grp = block % NGRP, wg_in_grp = block / NGRP, wgs_per_grp = nblocks / NGRP;
+    const ConvWgMap wm = conv_wg_map<NGRP>(a, block, nblocks);
+    const int grp = wm.grp, wg_in_grp = wm.wg_in_grp, wgs_per_grp = wm.wgs_per_grp;
     const int sub = grp / CG, nb0 = (grp % CG) * NB;
     const uint4* wl = reinterpret_cast<const uint4*>(smem);
     int tcount = 2;
 
     const int nwaves = wgs_per_grp * NWV;
-    const int units = a.nimg * TY * TX;
+    const int units = wm.nimg * TY * TX;               // units of this workgroup's image range
 
     // A geometry: row i = lane&15 : quad = i>>2 (qy = quad>>1, qx = quad&1), pos = i&3 (dy = pos>>1, dx = pos&1)
     const int ay = 2 * (j >> 3) + ((j >> 1) & 1), ax = 2 * ((j >> 2) & 1) + (j & 1);
@@ -175,7 +203,7 @@ __device__ __forceinline__ void conv16_run(const ConvArgs& a, uint8_t* smem, int
         st_pl[q] = st_ly[q] * (KIND == DOWN ? 2 * W : W) + st_lx[q];       // pixel offset from the patch origin in the input image
     }
     auto unit_coords = [&](int u, int& tx, int& ty, int& img) {
-        tx = u % TX; ty = (u / TX) % TY; img = u / (TX * TY);
+        tx = u % TX; ty = (u / TX) % TY; img = wm.img0 + u / (TX * TY);
     };
     // Patch loads.  fp32-input MFMAs do not co-execute with VALU work of any wave of the SIMD (DESIGN "fp32 MFMA and the
     // VALU"), so every VALU instruction of the loop is paid in MFMA time: the bounds tests and the pixel -> byte-offset
@@ -488,7 +516,7 @@ template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, 
           int MATH = MATH_NATIVE>
 __global__ __launch_bounds__((conv_nw<T, KIND, C0, C1, H, W, NB>() * 64)) void conv16_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    conv16_fill<T, KIND, C0, C1, COUT, NB, MATH>(a, smem, (int)blockIdx.x);
+    conv16_fill<T, KIND, C0, C1, COUT, NB, MATH>(a, smem, (int)blockIdx.x, (int)gridDim.x);
     conv16_run<T, KIND, C0, C1, COUT, H, W, NB, POOL, RELU, MATH>(a, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
@@ -536,6 +564,7 @@ inline int launch_conv(const ConvArgs& a, hipStream_t s) {
     const int units = a.nimg * (LIN ? (H * W + 15) / 16 : ((H + 3) / 4) * ((W + 3) / 4));   // per weight group
     int wgs = (units + NWV - 1) / NWV;                                // workgroups per weight group
     if (wgs > 256 / NGRP) wgs = 256 / NGRP;                           // one persistent workgroup per CU
+    else if (a.xcd_local && a.nimg % 8 == 0 && wgs % 8 != 0 && wgs + 8 - wgs % 8 <= 256 / NGRP) wgs += 8 - wgs % 8;   // (a multiple of 8 per group: conv_wg_map)
     auto kern = conv16_kernel<T, KIND, C0, C1, COUT, H, W, NB, POOL, RELU, MATH>;
     if (lds > 48 * 1024)
         giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);

@@ -523,7 +523,7 @@ __global__ __launch_bounds__(MEGA_NW * 64) void unet_mega_kernel(MegaArgs m) {
 #define X(l, KIND, C0, C1, COUT, H, W, NB, POOL, NB16)                                                                     \
     if (l < m.nlayers) {                                                                                                   \
         const ConvArgs a = conv_image_range<T, KIND, C0, C1, COUT, H, W>(m.layer[l], img0, per);                           \
-        if (l == 0) conv16_fill<T, KIND, C0, C1, COUT, (sizeof(T) == 2 ? NB16 : NB), MATH>(a, smem, block);                \
+        if (l == 0) conv16_fill<T, KIND, C0, C1, COUT, (sizeof(T) == 2 ? NB16 : NB), MATH>(a, smem, block, nblocks);                \
         conv16_run<T, KIND, C0, C1, COUT, H, W, (sizeof(T) == 2 ? NB16 : NB), POOL, KIND == CONV3, MATH>(a, smem, block, nblocks); \
         __builtin_amdgcn_s_waitcnt(0x0F70);            /* vmcnt(0): this wave's output stores are in the L2 */              \
         __syncthreads();                               /* ... everyone's, and everyone has left the weights in LDS */       \
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(MEGA_NW * 64) void unet_mega_kernel(MegaArgs m) {
     // after layer l: request layer l+1's weights (they land while the barrier is waited for), then the XCD barrier
 #define NEXT(l, KIND, C0, C1, COUT, H, W, NB, POOL, NB16)                                                                  \
     if (l < m.nlayers) {                                                                                                   \
-        conv16_fill<T, KIND, C0, C1, COUT, (sizeof(T) == 2 ? NB16 : NB), MATH>(m.layer[l], smem, block);                   \
+        conv16_fill<T, KIND, C0, C1, COUT, (sizeof(T) == 2 ? NB16 : NB), MATH>(m.layer[l], smem, block, nblocks);                   \
         xcd_barrier(counter, ++epoch * (unsigned)nblocks, l);                                                                 \
     }
     X(0, CONV3, 32, 0, 32, 40, 40, 2, false, 2)
@@ -611,6 +611,8 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     if (hipGetLastError() != hipSuccess) return -10;
 
     const int nimg = 3 * B;
+    // (tuning knob: GIGA_CONV_XCD=0 keeps the plain workgroup -> weight-group map, see conv_wg_map)
+    const int xcd_local = [] { const char* e = getenv("GIGA_CONV_XCD"); return e ? atoi(e) : 1; }();
     auto W_ = [&](int l) {
         return blob + (SPLIT ? ko.conv[l].w16s : MATH == MATH_BF16 ? ko.conv[l].wbf : precision == 1 ? ko.conv[l].w16 : ko.conv[l].w32);
     };
@@ -620,6 +622,7 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
         a.in0 = i0; a.in1 = i1; a.w = W_(l); a.bias = Bi(l); a.out = o; a.out_pool = op; a.out_nchw = nullptr;
         a.nimg = nimg;
         a.trace_id = l;
+        a.xcd_local = xcd_local;
         return a;
     };
     uint8_t* b = ws;
@@ -656,7 +659,7 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     const bool probe_layer = pr.stage >= 2 && pr.stage <= 14;
     if (mega_ok && !probe_layer && nimg % 8 == 0) {
         MegaArgs m{};
-        for (int l = 0; l < NCONV; ++l) m.layer[l] = L[l];
+        for (int l = 0; l < NCONV; ++l) { m.layer[l] = L[l]; m.layer[l].xcd_local = 0; }   // (the kernel hands every XCD its images itself)
         m.sync = reinterpret_cast<unsigned*>(b + w.SYNC);
         m.nlayers = nlayers;
         if (hipMemsetAsync(m.sync, 0, 8 * 128, s) != hipSuccess) return -10;

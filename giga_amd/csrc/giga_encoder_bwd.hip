@@ -868,6 +868,7 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
         a.in0 = in; a.in1 = nullptr; a.w = bwd_blob + (MATH == MATH_BF16 ? bo.convbf[l] : bo.conv[l]); a.bias = nullptr; a.out = out; a.nimg = nimg;
         a.cs0 = cs;
         a.mask = relu_of;
+        a.xcd_local = 1;                 // images onto XCDs, all weight groups of an image on one L2 (giga_conv16.h: conv_wg_map)
         return a;
     };
     const size_t n40 = (size_t)nimg * 1600, n20 = (size_t)nimg * 400, n10 = (size_t)nimg * 100;

@@ -7,7 +7,7 @@ from giga_amd import _capi, networks, synth, weights
 _capi.LIB_PATH = os.environ["GIGA_DIAG_LIB"]
 dev = torch.device("cuda:0")
 net = networks.get_network("giga"); net.load_state_dict(weights.make_state_dict(7))
-net = net.to(dev).eval().set_precision("fp32")
+net = net.to(dev).eval().set_precision(os.environ.get("GIGA_DIAG_PREC", "fp32"))
 B = int(os.environ.get("GIGA_DIAG_B", "32"))
 x = torch.from_numpy(synth.tsdf_batch(0, B)).to(dev)
 L = _capi.lib()
