@@ -72,19 +72,20 @@ TRAFFIC_KERNEL = {"convin_project": "convin_project_kernel<float, 5, false",
 
 
 def traffic_lookup(workload, fragment):
-    """HBM bytes per launch of the kernel whose name contains `fragment`, from profiles/r02_traffic_<workload>.json (two
+    """HBM bytes per launch of the kernel whose name contains `fragment`, from profiles/r0N_traffic_<workload>.json (two
     rocprofv3 PMC passes, tools/gpu_traffic.sh): PMC counters cannot be collected from inside this process.  Returns
     (bytes or None, provenance or None)."""
     if not fragment:
         return None, None
-    try:
-        tab = json.load(open(os.path.join(ROOT, "profiles", f"r02_traffic_{workload}.json")))
-    except (OSError, ValueError):
-        return None, None
-    for name, ent in tab.get("kernels", {}).items():
-        if fragment in name:
-            return ent["bytes"], {"table": f"profiles/r02_traffic_{workload}.json", "commit": tab.get("commit"), "kernel": name,
-                                  "fetch_kib": ent["fetch_kib"], "write_kib": ent["write_kib"]}
+    for rnd in ("r03", "r02"):                             # the newest committed table that knows the kernel
+        try:
+            tab = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_traffic_{workload}.json")))
+        except (OSError, ValueError):
+            continue
+        for name, ent in tab.get("kernels", {}).items():
+            if fragment in name:
+                return ent["bytes"], {"table": f"profiles/{rnd}_traffic_{workload}.json", "commit": tab.get("commit"), "kernel": name,
+                                      "fetch_kib": ent["fetch_kib"], "write_kib": ent["write_kib"]}
     return None, None
 
 
