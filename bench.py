@@ -59,7 +59,9 @@ _CONV = [(9, 32, 32, 40), (9, 32, 32, 40), (9, 32, 64, 20), (9, 64, 64, 20), (9,
 STAGE_NAMES = ["convin_project", "plane_finalize"] + [
     "unet.down0.conv1", "unet.down0.conv2+pool", "unet.down1.conv1", "unet.down1.conv2+pool", "unet.down2.conv1",
     "unet.down2.conv2", "unet.up0.upconv", "unet.up0.conv1", "unet.up0.conv2", "unet.up1.upconv",
-    "unet.up1.conv1", "unet.up1.conv2", "unet.conv_final"]
+    "unet.up1.conv1", "unet.up1.conv2", "unet.conv_final",
+    "unet (one persistent launch: 12 layers)"]                 # probe stage 15 = the whole U-Net, however it is launched
+UNET_STAGE = 15
 HEADLINE_STAGE = 9                      # unet.up0.conv1: the layer with the most FLOPs (5.66 GFLOP at 32 scenes) and, since the
                                         # round-2 conv_in rewrite, the longest launch of the step; see pick_headline()
 NAMED_STAGE = 0                         # convin_project: the kernel VERDICT r01 names; reported beside it (roofline.r01_kernel)
@@ -67,6 +69,7 @@ NAMED_STAGE = 0                         # convin_project: the kernel VERDICT r01
 
 # kernel-name fragments (rocprofv3 names) of the stages whose HBM traffic bench.py quotes from the committed PMC tables
 TRAFFIC_KERNEL = {"convin_project": "convin_project_kernel<float, 5, false",
+                  "unet (one persistent launch: 12 layers)": "unet_mega_kernel<float, 0>",
                   "unet.up0.conv1": "conv16_kernel<float, 0, 64, 64, 64, 20, 20, 1, false, true, 0>",
                   "unet.up1.conv1": "conv16_kernel<float, 0, 32, 32, 32, 40, 40, 2, false, true, 0>"}
 
@@ -95,6 +98,8 @@ def stage_flops(stage, B):
         return 110_592_000 * B
     if stage == 1:
         return 0
+    if stage == UNET_STAGE:                                     # the twelve layers of the folded call (conv_final is not run)
+        return sum(stage_flops(st, B) for st in range(2, 14))
     taps, cin, cout, hw = _CONV[stage - 2]
     return 2 * hw * hw * taps * cin * cout * 3 * B
 
@@ -220,7 +225,19 @@ def main():
         step(dec_probe=(dec_ev, dec2))
         dg.append(elapsed(*dec_ev)); dt.append(elapsed(*dec2))
     dec_grasp_ms, dec_occ_ms = float(np.median(dg)), float(np.median(dt))
-    dom = pick_headline(stage_ms)
+    # How the U-Net is launched in the product call: one persistent launch (the default from 8 scenes up in fp32) or one launch per
+    # layer.  Probing a single layer (stages 2..14) forces per-layer launches for that call, so the per-layer table above is always
+    # available; the dominant launch of the STEP AS TIMED is the persistent one when it is in use.
+    n0 = L.giga_launch_count()
+    with torch.no_grad():
+        net.encoder.encode_nhwc(x, blob=blob, precision="fp32", fold_final=True)
+    persistent_unet = int(L.giga_launch_count() - n0) <= 4         # conv_in, finalize, U-Net
+    reps = []
+    for _ in range(7):
+        step(probe=(UNET_STAGE, ev_a, ev_b))
+        reps.append(elapsed(ev_a, ev_b))
+    unet_ms = float(np.median(reps))
+    dom = UNET_STAGE if persistent_unet else pick_headline(stage_ms)
 
     # -------- timed region ----------------------------------------------------------------------------
     _settle()                              # (before the warm-up: an idle GPU drops its clocks ...
@@ -281,7 +298,7 @@ def main():
     # The contract line is assembled BEFORE the multi-GPU extras run, and a watchdog prints it if they hang: a collective
     # that one rank never enters (an exception elsewhere, a wedged RCCL ring) must not cost the scaling run its numbers.
     out = core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, dec_occ_ms, dom, dom_ms, step_ms, named_ms, bracket_ms,
-                      launches_per_step) if rank == 0 else None
+                      launches_per_step, unet_ms, persistent_unet) if rank == 0 else None
     extra = dict(multi)
     if dist is not None and not args.no_extra:
         import threading
@@ -347,7 +364,7 @@ def main():
 
 
 def core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, dec_occ_ms, dom, dom_ms, step_ms, named_ms, bracket_ms,
-                launches_per_step=None):
+                launches_per_step=None, unet_ms=None, persistent_unet=False):
     """The contract keys + roofline of the timed region (rank 0)."""
     # HBM bytes per launch: PMC counters cannot be collected from inside this process, so they come from the committed
     # rocprofv3 PMC table of the same workload (tools/gpu_traffic.sh -> profiles/*traffic_c2.json), stamped with the commit
@@ -361,11 +378,15 @@ def core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, d
     achieved = dom_flops / (dom_avg_ms * 1e-3) / 1e12
     flop_scene = FLOP_ENCODER + FLOP_GRASP3 * 1 + FLOP_HEAD["tsdf"] * M
     points_per_scene = 1 * 3 + M          # head evaluations per scene
-    step_total = sum(stage_ms) + dec_grasp_ms + dec_occ_ms
+    # shares of the step as it is launched: with the persistent U-Net the twelve layers are one launch of unet_ms
+    unet_layers_ms = sum(stage_ms[2:14])
+    step_total = sum(stage_ms[:2]) + (unet_ms if persistent_unet else unet_layers_ms) + dec_grasp_ms + dec_occ_ms
+    layer_scale = unet_ms / unet_layers_ms if persistent_unet else 1.0     # a layer's share inside the persistent launch, pro rata
     stages = {}
     for i, v in enumerate(stage_ms):
         fl = stage_flops(i, B)
-        stages[STAGE_NAMES[i]] = {"ms": round(v, 4), "gflop": round(fl / 1e9, 3), "share_of_step": round(v / step_total, 3),
+        stages[STAGE_NAMES[i]] = {"ms": round(v, 4), "gflop": round(fl / 1e9, 3),
+                                  "share_of_step": round(v * (layer_scale if 2 <= i < 14 else 1.0) / step_total, 3),
                                   "frac_of_fp32_mfma_peak": round(fl / (v * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 3) if fl and v > 0 else None}
     for nm, v, fl in (("decoder.grasp_heads(1 query)", dec_grasp_ms, B * FLOP_GRASP3),
                       ("decoder.occupancy(2048 queries)", dec_occ_ms, B * M * FLOP_HEAD["tsdf"])):
@@ -379,6 +400,14 @@ def core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, d
     ak, av = max(stages.items(), key=lambda kv: kv[1]["ms"])
     argmax_stage = {"kernel": ak, "ms": av["ms"], "frac": av["frac_of_fp32_mfma_peak"]}
     step_flops = sum(v["gflop"] for v in stages.values()) * 1e9
+    unet_flops = stage_flops(UNET_STAGE, B)
+    unet_launch = {"ms": round(unet_ms, 4), "gflop": round(unet_flops / 1e9, 3), "share_of_step": round(unet_ms / step_total, 3),
+                   "frac_of_fp32_mfma_peak": round(unet_flops / (unet_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS, 3),
+                   "sum_of_the_twelve_layers_as_separate_launches_ms": round(unet_layers_ms, 4),
+                   "form": "one persistent launch (unet_mega_kernel)" if persistent_unet else "one launch per layer"} if unet_ms else None
+    if unet_launch and persistent_unet:                       # the launch the step really contains; its twelve layers stay listed beside it
+        stages[STAGE_NAMES[UNET_STAGE]] = unet_launch
+        argmax_stage = {"kernel": STAGE_NAMES[UNET_STAGE], "ms": unet_launch["ms"], "frac": unet_launch["frac_of_fp32_mfma_peak"]}
     out = {
         "metric": "scenes/sec",
         "value": scenes_per_s,
@@ -408,7 +437,12 @@ def core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, d
             # (rocprofv3's kernel durations under profiles/ do not contain it)
             "empty_event_bracket_ms": bracket_ms,
             "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) peak; events on the launch stream inside the timed steps (even steps); "
-                    "kernel = the longest launch of the step: unet.up0.conv1 unless another stage exceeds 1.15x its time (pick_headline)",
+                    "kernel = the longest launch of the step as it is launched: the persistent U-Net launch (twelve layers, "
+                    "algorithmic FLOPs of all of them) when that form is in use, else unet.up0.conv1 unless another stage exceeds "
+                    "1.15x its time (pick_headline)",
+            "unet_launch": unet_launch,
+            "stages_note": "the U-Net layers of `stages` are timed as SEPARATE launches (probing one layer switches that call to "
+                           "per-layer launches); inside the persistent launch their shares are scaled pro rata",
             # the kernel VERDICT r01 named (roofline_frac 0.46 then), measured the same way on the odd steps
             "r01_kernel": {"kernel": STAGE_NAMES[NAMED_STAGE], "achieved": named_ach, "frac": named_ach / PEAK_F32_MATRIX_TFLOPS,
                            "frac_of_measured_peak": named_ach / MEASURED_F32_MATRIX_TFLOPS, "avg_launch_ms": named_avg_ms,
@@ -607,12 +641,12 @@ def check_c4_scene(out, prec, synth):
 
 def bench_c4_all(net, dev, L, _capi, synth, decode_heads):
     out = {}
-    # the opt-in one-launch U-Net (net.set_persistent_unet: caller vouches for one stream per device, which holds here)
-    net.set_persistent_unet(True)
-    for prec, key in (("fp16", "c4_persistent_unet"), ("fp16x3", "c4_fp16x3_persistent_unet")):
+    # for comparison: the same legs with one launch per U-Net layer (GIGA_LAYERWISE_UNET) instead of the default persistent launch
+    net.set_persistent_unet("layers")
+    for prec, key in (("fp16", "c4_layerwise_unet"), ("fp16x3", "c4_fp16x3_layerwise_unet")):
         r = bench_c4(net, dev, L, _capi, synth, decode_heads, prec)
         out[key] = {k: r[k] for k in ("workload", "scenes_per_sec", "ms_per_step", "step_ms_median", "step_ms_max")}
-        out[key]["workload"] += "; U-Net as one persistent launch (GIGA_PERSIST_UNET)"
+        out[key]["workload"] += "; one launch per U-Net layer (GIGA_LAYERWISE_UNET)"
     net.set_persistent_unet(False)
     for prec, key in (("fp16", "c4"), ("fp16x3", "c4_fp16x3")):
         out[key] = bench_c4(net, dev, L, _capi, synth, decode_heads, prec)

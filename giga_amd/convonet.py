@@ -257,7 +257,7 @@ class LocalVoxelEncoder(nn.Module):
         with torch.cuda.device(x.device):      # launch on the tensors' device and ITS current stream, whatever torch's current device is
             _capi.check(L.giga_encoder_forward_probe(_capi.ptr(x), _capi.ptr(blob), _capi.ptr(nhwc), _capi.ptr(nchw),
                                                      B, prec | (_capi.FOLD_FINAL if fold_final else 0) |
-                                                     (_capi.PERSIST_UNET if getattr(self, "persistent_unet", False) else 0),
+                                                     {False: 0, True: _capi.PERSIST_UNET, "layers": _capi.LAYERWISE_UNET}[getattr(self, "persistent_unet", False)],
                                                      _capi.ptr(ws), ws.numel(), _capi.stream_ptr(x.device),
                                                      stage, ev0, ev1),
                         "giga_encoder_forward")
@@ -513,12 +513,11 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
         return self
 
     def set_persistent_unet(self, enabled=True):
-        """Opt in to the one-launch U-Net (GIGA_PERSIST_UNET, include/giga_hip.h): same results (bit for bit in the f16-class modes, to fp32 rounding in fp32), no launch gaps
-        between the layers (-10 % encoder time in the f16-class modes at 8-32 scenes; nothing in fp32).  Only for processes
-        that drive the device from ONE stream at a time: the kernel's per-XCD spin barriers need all of its workgroups
-        co-resident, and two such launches in flight on two streams (or from two processes) can deadlock until the barrier
-        traps.  Takes effect for batches with 3 * B divisible by 8; hipGraph capture is fine."""
-        self.encoder.persistent_unet = bool(enabled)
+        """How the U-Net layers are launched (include/giga_hip.h, GIGA_PERSIST_UNET / GIGA_LAYERWISE_UNET): False = the default
+        (one persistent launch for the whole U-Net -- every batch size in the f16-class modes, from 8 scenes up in fp32 -- with
+        the same results as per-layer launches: bit for bit in the f16-class modes, to fp32 rounding in fp32); True = the
+        persistent launch also for small fp32 batches; "layers" = one launch per layer.  hipGraph capture is fine in every form."""
+        self.encoder.persistent_unet = "layers" if enabled == "layers" else bool(enabled)
         return self
 
     def _head_present(self):

@@ -51,7 +51,7 @@ constexpr int CONV_NW = 12;       // waves per workgroup (3 per SIMD; VGPR use i
 #ifdef GIGA_TRACE   // diagnostic build: issue timeline (s_memtime) of workgroup 0 of the layer selected at run time
 static __device__ long long g_conv_trace[CONV_NW * 64];
 static __device__ int g_conv_trace_layer = -1;
-#define CONV_T(idx) do { if (blockIdx.x == 0 && lane == 0 && a.trace_id == g_conv_trace_layer && (idx) < 64) \
+#define CONV_T(idx) do { if (block == 0 && lane == 0 && a.trace_id == g_conv_trace_layer && (idx) < 64) \
         g_conv_trace[wave * 64 + (idx)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CONV_T(idx) do {} while (0)

@@ -357,9 +357,11 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
 // planes xz = (sum of the 4 iy-group partials) / 40, yz = (sum of the NXP x-part partials) / 40
 template <typename TOut>
 __global__ void plane_finalize_kernel(const float* __restrict__ xz_partial, const float* __restrict__ yz_partial,
-                                      TOut* __restrict__ planes, int B, int nxp) {
+                                      TOut* __restrict__ planes, int B, int nxp, unsigned* __restrict__ sync_words, int nsync) {
     const size_t per4 = (size_t)B * RES * RES * CD / 4;     // float4 elements of one plane over the batch
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // this launch always precedes the U-Net: it clears the barrier words of the persistent U-Net kernel (no separate memset)
+    if (blockIdx.x == 0 && sync_words) for (int i = threadIdx.x; i < nsync; i += blockDim.x) sync_words[i] = 0u;
     if (t >= per4) return;
     const f32x4v* xs = reinterpret_cast<const f32x4v*>(xz_partial) + t;
     const f32x4v* ys = reinterpret_cast<const f32x4v*>(yz_partial) + t;
@@ -383,6 +385,7 @@ __global__ void plane_finalize_kernel(const float* __restrict__ xz_partial, cons
 // ----------------------------------------------------------------------------------------------------
 // x-parts of conv_in+project: 1 (8*B workgroups, five slices per wave) from 32 scenes up, else 5 (40*B workgroups)
 int enc_nxp(int B) { return B >= 32 ? 1 : 5; }
+constexpr int MEGA_SYNC_WORDS = (8 + 32) * 32;    // barrier words of the persistent U-Net kernel: 8 per-XCD + 32 per-group counters, 128 B apart
 
 EncWs enc_workspace(int B, int precision) {
     const size_t es = precision == 1 ? 2 : 4;
@@ -397,7 +400,7 @@ EncWs enc_workspace(int B, int precision) {
     w.U1 = take(n * 1600 * 32, es); w.A5 = take(n * 1600 * 32, es); w.A6 = take(n * 1600 * 32, es);
     w.YZ = take((size_t)(4 + enc_nxp(B)) * B * 1600 * 32, 4);   // 4 xz partials (iy-groups) + NXP yz partials (x-parts)
     w.XZ = w.YZ;
-    w.SYNC = take(8 * 128, 4);             // per-XCD barrier counters of the persistent U-Net kernel
+    w.SYNC = take(MEGA_SYNC_WORDS * 4, 4); // barrier counters of the persistent U-Net kernel (8 per-XCD + 32 per-group, 128 B apart)
     w.total = at;
     return w;
 }
@@ -434,24 +437,33 @@ EncWs enc_workspace(int B, int precision) {
     X(12, CONV1, 32, 0, 32, 40, 40, 2, false, 2)
 
 // ----------------------------------------------------------------------------------------------------
-// The U-Net as ONE persistent launch, synchronised per XCD.
-//   Images are independent, so the 3B images are split into 8 contiguous ranges and XCD x (the 32 workgroups i with
-//   i % 8 == x: workgroup i runs on XCD i % 8) takes range x through all layers.  A layer boundary is then a barrier among
-//   the 32 workgroups of ONE XCD, and everything they exchange goes through that XCD's own L2: the producer waits for its
-//   stores (vmcnt 0: acknowledged by the L2), arrives with a workgroup-scope atomic add (performed in the L2) and spins on an
-//   L2 load; a consumer reads buffers nobody on its CU has read before in this launch, so its L1 holds no older copy.  No
-//   agent-scope release / acquire (write-back + invalidate of the whole L2, ~7 us) and no device-scope atomics (resolved
-//   outside the XCD, ~8 us for 256 arrivals): tools/xcd_barrier.hip measures 5 us per write + barrier + read round against
-//   7.7, with zero stale reads, and checks the workgroup -> XCD map against the hardware register XCC_ID.  (The device-wide
-//   version of this kernel, round 2a, lost to per-layer launches: profiles/r02e_persistent_unet_experiment.txt.)
-//   The next layer's weights stream into LDS (LDS-DMA) while the barrier is waited for.  A barrier that does not complete
-//   (fewer than 256 co-resident workgroups: never on an exclusive MI355X) traps after ~1 s instead of hanging the device.
+// The U-Net as ONE persistent launch, synchronised per GROUP of 8 workgroups inside one XCD.
+//   Images are independent.  The launch is 8 * S * 8 workgroups (S = 1..4 group slots per XCD; 256 = one per CU from 25 images
+//   up).  The eight workgroups of a group run on ONE XCD (they find each other by ticket, see the kernel) and take a contiguous,
+//   balanced share of the 3B images (one image or none up to 32 images) through all layers; a layer boundary is a barrier among
+//   those 8 workgroups only, and everything they exchange goes through their XCD's own L2: the producer waits for its stores
+//   (vmcnt 0: acknowledged by the L2), arrives with a workgroup-scope atomic add (performed in the L2) and spins on an L2 load;
+//   a consumer reads buffers nobody on its CU has read before in this launch, so its L1 holds no older copy.  No agent-scope
+//   release / acquire (write-back + invalidate of the whole L2, ~7 us) and no device-scope atomics (resolved outside the XCD,
+//   ~8 us for 256 arrivals); tools/xcd_barrier.hip is the stand-alone experiment (zero stale reads).
+//   8 workgroups per group because no layer has more than 8 weight groups (conv_wg_map hands them out inside the group).
+//   The next layer's weights stream into LDS (LDS-DMA) while the barrier is waited for.
+//   History: round 2a synchronised device-wide (lost to per-layer launches, profiles/r02e_persistent_unet_experiment.txt),
+//   round 2b per XCD (32 workgroups per barrier, ~5 us each: -10 % in the f16-class modes at 8-32 scenes, an opt-in with a
+//   one-stream contract because 256 blockIdx-placed workgroups had to be co-resident); round 3 per group: a barrier among 8
+//   workgroups releases ~1 us (2.4 k clocks) after its last arrival, the groups drift apart instead of draining and refilling
+//   the device at every layer, and ticket placement removed the co-residency contract -- the form became the DEFAULT: whole
+//   encoder at one scene 94 -> 75 us (f16); at 32 scenes f16 150 -> 130, f16x3 230 -> 216, fp32 378 -> 361
+//   (profiles/r03/unet_grouped_*.txt).  fp32 layers gain nothing below ~8 scenes and keep their per-layer launches there.
 // ----------------------------------------------------------------------------------------------------
 struct MegaArgs {
     ConvArgs layer[NCONV];
-    unsigned* sync;            // 8 arrival counters (one per XCD, 128 B apart), zeroed before the launch
+    unsigned* sync;            // words zeroed by plane_finalize_kernel: [x * 32] ticket counter of XCD x, [(8 + q) * 32] arrival counter of group q
     int nlayers;               // 12 (conv_final folded into the decoder) or 13
 };
+constexpr int MEGA_GROUP = 8;                     // workgroups per group
+constexpr int MEGA_SLOTS = 4;                     // group slots per XCD at most: 8 x 4 x 8 = 256 workgroups, one per CU
+constexpr int MEGA_GROUP_MAX_IMG = 32;            // default form of the f16-class modes up to 32 images (one image per group)
 constexpr int MEGA_NW = CONV_NW;                  // waves per workgroup of the persistent kernel
 
 template <typename T, int MATH>
@@ -467,10 +479,12 @@ constexpr size_t mega_lds_bytes() {
 #ifdef GIGA_TRACE
 static __device__ long long g_mega_trace[8][32];          // [workgroup 0..7][2 * layer: arrival, release]
 #endif
-__device__ __forceinline__ void xcd_barrier(unsigned* counter, unsigned target, int idx) {
+__device__ __forceinline__ void xcd_barrier(unsigned* counter, unsigned target, int idx, int trace_row) {
 #ifdef GIGA_TRACE
-    if (threadIdx.x == 0 && blockIdx.x < 64 && (blockIdx.x & 7) == 0 && idx < 16) g_mega_trace[blockIdx.x >> 3][2 * idx] = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0 && trace_row >= 0 && trace_row < 8 && idx < 16) g_mega_trace[trace_row][2 * idx] = __builtin_amdgcn_s_memtime();
 #endif
+    // (ONE poller per workgroup.  Letting every wave poll for itself -- so that each requests its next patch the moment it sees the
+    //  release -- measured no gain for groups of 8 workgroups and made a barrier among 32 workgroups slower: 384 pollers on one L2 line.)
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // performed in this XCD's L2
         unsigned spins = 0;
@@ -481,7 +495,7 @@ __device__ __forceinline__ void xcd_barrier(unsigned* counter, unsigned target, 
     }
     __syncthreads();
 #ifdef GIGA_TRACE
-    if (threadIdx.x == 0 && blockIdx.x < 64 && (blockIdx.x & 7) == 0 && idx < 16) g_mega_trace[blockIdx.x >> 3][2 * idx + 1] = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0 && trace_row >= 0 && trace_row < 8 && idx < 16) g_mega_trace[trace_row][2 * idx + 1] = __builtin_amdgcn_s_memtime();
 #endif
 }
 
@@ -498,27 +512,38 @@ __device__ __forceinline__ ConvArgs conv_image_range(ConvArgs a, int img0, int n
     if (a.out_nchw) a.out_nchw += (size_t)img0 * COUT * H * W;
     if (a.mask) a.mask += (size_t)img0 * OH * OW * COUT;
     a.nimg = n;
+    if (img0 != 0) a.trace_id = -2;                  // (diagnostic builds trace the group that holds image 0)
     return a;
 }
 
 template <typename T, int MATH>
 __global__ __launch_bounds__(MEGA_NW * 64) void unet_mega_kernel(MegaArgs m) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int xcd = (int)blockIdx.x & 7, block = (int)blockIdx.x >> 3, nblocks = (int)gridDim.x >> 3;
-    // The barriers below are XCD-local (workgroup-scope atomics, no agent-scope release / acquire): they are only correct if
-    // the workgroups that share a counter share an L2, i.e. if the workgroups i with equal i % 8 really run on one XCD.  That is
-    // the observed dispatch order, not a contract (CU masks, partition modes, a new dispatcher): check it against the hardware
-    // register and fail loudly instead of returning stale activations.
-    // (NOT "XCC_ID == blockIdx % 8": the dispatcher's round-robin pointer carries over from the previous launch, so after a grid
-    //  that is not a multiple of 8 the map is rotated -- still one XCD per residue class, which is all the barriers need.  Each
-    //  class therefore agrees on ONE XCC_ID through a tag word next to its counter, zeroed with the counters before the launch.)
+    // A workgroup finds its place by TICKET, not by blockIdx: it reads the XCD it runs on from the hardware (XCC_ID) and draws a
+    // number from that XCD's ticket counter; ticket t is member t % 8 of group slot t / 8 on that XCD.
+    //   * The barriers are XCD-local (workgroup-scope atomics, no agent-scope release / acquire), i.e. only correct if the
+    //     workgroups that share a counter share an L2 -- true by construction here, whatever order the dispatcher uses.  (Rounds
+    //     2-3a assumed "workgroup i runs on XCD i % 8" and checked it; the dispatcher's round-robin pointer carries over from the
+    //     previous launch, so even that map is rotated after a grid that is not a multiple of 8.)  What is still assumed is that
+    //     every XCD receives gridDim / 8 workgroups: a group that never fills traps after ~1 s instead of returning stale data.
+    //   * The members of a group are the first eight workgroups of the launch that became RESIDENT on their XCD, so a launch has
+    //     at most one unfilled group per XCD, and filled groups depend on nobody: several of these launches in flight at once
+    //     (other streams, other processes) cannot hold each other's CUs in a cycle -- which is what made the blockIdx-based form
+    //     an opt-in with a one-stream contract.
+    __shared__ unsigned s_place[2];
     if (threadIdx.x == 0) {
-        const unsigned mine = (unsigned)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15) + 1u;     // HW_REG_XCC_ID[3:0] + 1
-        const unsigned seen = atomicCAS(m.sync + xcd * 32 + 1, 0u, mine);
-        if (seen != 0u && seen != mine) __builtin_trap();
+        const unsigned xcc = (unsigned)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7);     // HW_REG_XCC_ID[3:0]
+        s_place[0] = xcc;
+        s_place[1] = __hip_atomic_fetch_add(m.sync + xcc * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // performed in this XCD's L2
     }
-    const int per = m.layer[0].nimg >> 3, img0 = xcd * per;                 // (the host guarantees nimg % 8 == 0)
-    unsigned* counter = m.sync + xcd * 32;
+    __syncthreads();
+    const int xcd = (int)s_place[0], ticket = (int)s_place[1];
+    const int nq = (int)gridDim.x >> 3, slot = ticket / MEGA_GROUP, q = slot * 8 + xcd, nimg = m.layer[0].nimg;   // nq = 8 * slots = #groups
+    if (slot >= nq >> 3) return;                                            // (an XCD that was handed more than its share)
+    const int img0 = (q * nimg + nq - 1) / nq, per = ((q + 1) * nimg + nq - 1) / nq - img0;   // group q of nq: a contiguous, balanced share of the images (group 0 is never empty)
+    if (per == 0) return;                                                   // (before any barrier)
+    const int block = ticket - slot * MEGA_GROUP, nblocks = MEGA_GROUP;     // this workgroup's place inside its group
+    unsigned* counter = m.sync + (8 + q) * 32;
     unsigned epoch = 0;
 #define X(l, KIND, C0, C1, COUT, H, W, NB, POOL, NB16)                                                                     \
     if (l < m.nlayers) {                                                                                                   \
@@ -532,7 +557,7 @@ __global__ __launch_bounds__(MEGA_NW * 64) void unet_mega_kernel(MegaArgs m) {
 #define NEXT(l, KIND, C0, C1, COUT, H, W, NB, POOL, NB16)                                                                  \
     if (l < m.nlayers) {                                                                                                   \
         conv16_fill<T, KIND, C0, C1, COUT, (sizeof(T) == 2 ? NB16 : NB), MATH>(m.layer[l], smem, block, nblocks);                   \
-        xcd_barrier(counter, ++epoch * (unsigned)nblocks, l);                                                                 \
+        xcd_barrier(counter, ++epoch * (unsigned)nblocks, l, img0 == 0 ? block : -1);                                                                 \
     }
     X(0, CONV3, 32, 0, 32, 40, 40, 2, false, 2)
     NEXT(1, CONV3, 32, 0, 32, 40, 40, 2, true, 2)
@@ -569,7 +594,7 @@ struct Probe { int stage; hipEvent_t ev0, ev1; };
 
 template <typename T, int MATH = MATH_NATIVE>
 static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc, float* planes_nchw, int B,
-                       uint8_t* ws, hipStream_t s, const Probe& pr, bool fold_final, bool persist) {
+                       uint8_t* ws, hipStream_t s, const Probe& pr, bool fold_final, int persist) {
     constexpr bool SPLIT = MATH == MATH_SPLIT;
     int stage_no = 0;
     auto pre = [&]() { if (pr.stage == stage_no) (void)hipEventRecord(pr.ev0, s); };
@@ -605,7 +630,7 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     {
         pre();
         GIGA_LAUNCH(plane_finalize_kernel<T>, dim3((unsigned)((per / 4 + 255) / 256)), dim3(256), 0, s, XZP, YZP, P0, B,
-                           nxp);
+                           nxp, reinterpret_cast<unsigned*>(ws + w.SYNC), MEGA_SYNC_WORDS);
         post();
     }
     if (hipGetLastError() != hipSuccess) return -10;
@@ -640,36 +665,37 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
         args(12, b + w.A6, nullptr, planes_nhwc, nullptr)};
     L[12].out_nchw = planes_nchw;
     const int nlayers = fold_final ? 12 : 13;
-    // OPT-IN (flag GIGA_PERSIST_UNET of the call, or GIGA_UNET_PERSIST=1 in the environment for every call): one persistent
-    // launch for the whole U-Net (unet_mega_kernel) when the images split evenly over the 8 XCDs, unless a single layer is being
-    // probed (stages 2..14).  Measured (tools/gpu_stage_all.py, whole encoder, us, per-layer launches -> persistent): 8 scenes
-    // fp32 189 -> 169, f16 118 -> 96, f16x3 142 -> 122; 32 scenes fp32 422 -> 423, f16 165 -> 148, f16x3 265 -> 257; 128 scenes
-    // 1406 -> 1395, 437 -> 424, 833 -> 796: it removes the launch gaps of the f16-class layers (~1.4 us per boundary), while an
-    // fp32 layer's barrier + weight fill + first patch cost what its launch ramp cost.  Not the default because spin barriers
-    // need all 256 workgroups co-resident: two such kernels started concurrently from two streams can each hold part of the CUs
-    // and wait for the rest (the barrier then traps after ~1 s); whoever sets the flag vouches that this cannot happen.
-    static const bool env_persist = [] { const char* e = getenv("GIGA_UNET_PERSIST"); return e && atoi(e) != 0; }();
+    // One persistent launch for the whole U-Net (unet_mega_kernel) is the default, unless a single layer is being probed (stages
+    // 2..14) -- for every batch size in the f16-class modes, from 24 images (8 scenes) up in fp32 / bf16 (below that an fp32 layer's
+    // barrier + first patch cost what its launch costs: 152 vs 156 us at one scene).  The flag GIGA_LAYERWISE_UNET of the call (or
+    // GIGA_UNET_PERSIST=0 in the environment, for a whole process) keeps one launch per layer; GIGA_PERSIST_UNET forces the
+    // persistent form where the default would not take it.
+    static const int env_persist = [] { const char* e = getenv("GIGA_UNET_PERSIST"); return e ? atoi(e) : -1; }();   // -1 unset, 0 off, 1 force
     const bool full_device = [] {                             // per call: the CURRENT device (a process may drive several)
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess) return false;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
         return cus == 256;                                    // 8 XCDs x 32 CUs, one workgroup per CU
     }();
-    const bool mega_ok = (persist || env_persist) && full_device;
+    constexpr bool F16CLASS = sizeof(T) == 2 || MATH == MATH_SPLIT;
     const bool probe_layer = pr.stage >= 2 && pr.stage <= 14;
-    if (mega_ok && !probe_layer && nimg % 8 == 0) {
+    const bool by_default = F16CLASS || nimg >= 24;
+    const bool mega = full_device && !probe_layer &&
+                      (persist > 0 || (persist == 0 && (env_persist > 0 || (env_persist < 0 && by_default))));
+    if (mega) {
         MegaArgs m{};
-        for (int l = 0; l < NCONV; ++l) { m.layer[l] = L[l]; m.layer[l].xcd_local = 0; }   // (the kernel hands every XCD its images itself)
+        for (int l = 0; l < NCONV; ++l) { m.layer[l] = L[l]; m.layer[l].xcd_local = 0; }   // (the kernel hands every group its images itself)
         m.sync = reinterpret_cast<unsigned*>(b + w.SYNC);
         m.nlayers = nlayers;
-        if (hipMemsetAsync(m.sync, 0, 8 * 128, s) != hipSuccess) return -10;
+        const int slots = (nimg + 7) / 8 < MEGA_SLOTS ? (nimg + 7) / 8 : MEGA_SLOTS;
+        const unsigned grid = 8u * (unsigned)slots * MEGA_GROUP;
         auto kern = unet_mega_kernel<T, MATH>;
         constexpr size_t lds = mega_lds_bytes<T, MATH>();
         static_assert(lds <= 160 * 1024, "LDS budget of the persistent U-Net kernel");
         giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
         stage_no = 15;                                        // probe stage 15 = the whole U-Net
         pre();
-        GIGA_LAUNCH(kern, dim3(256), dim3(MEGA_NW * 64), lds, s, m);
+        GIGA_LAUNCH(kern, dim3(grid), dim3(MEGA_NW * 64), lds, s, m);
         post();
         return hipGetLastError() == hipSuccess ? 0 : -10;
     }
@@ -687,8 +713,9 @@ int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, fl
                    int precision, uint8_t* ws, hipStream_t s, int probe_stage, void* ev0, void* ev1) {
     if (B <= 0) return 0;
     Probe pr{ev0 && ev1 ? probe_stage : -1, static_cast<hipEvent_t>(ev0), static_cast<hipEvent_t>(ev1)};
-    const bool fold = (precision & GIGA_FOLD_FINAL) != 0, persist = (precision & GIGA_PERSIST_UNET) != 0;
-    const int prec = precision & ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET);
+    const bool fold = (precision & GIGA_FOLD_FINAL) != 0;
+    const int persist = (precision & GIGA_LAYERWISE_UNET) ? -1 : (precision & GIGA_PERSIST_UNET) ? 1 : 0;   // -1 per-layer launches, 0 auto, 1 persistent
+    const int prec = precision & ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET);
     if (prec == 2) return encoder_run<float, MATH_SPLIT>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist);
     if (prec == 3) return encoder_run<float, MATH_BF16>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist);
     return prec == 1 ? encoder_run<half_t>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist)

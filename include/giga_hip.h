@@ -114,14 +114,22 @@ int giga_decoder_forward(const void* planes_nhwc, const float* p, const void* pa
  * outputs (fp32 rounding-level differences), one layer less.  planes_nchw must be NULL with this flag: the planes it
  * produces are NOT LocalVoxelEncoder's return value and are only meaningful to a decoder call carrying the flag. */
 #define GIGA_FOLD_FINAL 16
-/* GIGA_PERSIST_UNET, OR-ed into `precision` of giga_encoder_forward*: run the U-Net layers as ONE persistent launch whose
- * layer boundaries are barriers among the 32 workgroups of each XCD (applies when 3 * B is a multiple of 8 on a 256-CU device;
- * ignored otherwise).  Same results bit for bit in the f16-class modes and to fp32 rounding (<= 2e-6 relative) in precision 0, where
- * the summation order of a layer's ragged last round follows the work distribution; removes the launch gaps between the layers (f16-class modes: -10 % encoder time
- * at 8-32 scenes; fp32: nothing).  CALLER'S CONTRACT: no other launch carrying this flag may be in flight on the device at the
- * same time (other streams, other processes) -- the spin barriers need all 256 workgroups of the launch co-resident, and a
- * barrier that cannot complete traps after about a second.  One stream per device satisfies it trivially. */
+/* How the twelve (thirteen) U-Net layers are launched.  DEFAULT: ONE persistent launch in which groups of 8 workgroups, each
+ * group inside one XCD, walk their share of the 3 * B plane images through all layers with a barrier among those 8 only
+ * (csrc/giga_encoder.hip::unet_mega_kernel) -- for every batch size in precisions 1 and 2, from 8 scenes up in precisions 0
+ * and 3.  Same results as one launch per layer: bit for bit in the f16-class modes, to fp32 rounding (<= 2e-6 relative) in
+ * precision 0, where the summation order of a layer's ragged last round follows the work distribution.  A layer boundary then
+ * costs a 1-us barrier instead of a launch: the whole encoder takes 75 instead of 94 us for one scene in precision 1 (the
+ * planner of detection_implicit.py:99-113 runs one scene at a time), 130 instead of 150 us at 32 scenes, 361 instead of 378 in
+ * precision 0.  The workgroups of a group find each other by ticket among the workgroups already resident on their XCD, so
+ * several such launches may be in flight on one device (other streams, other processes) without waiting on each other's CUs;
+ * a group that cannot fill (an XCD that is handed fewer workgroups than the others) traps after about a second instead of
+ * returning stale data.
+ *   GIGA_LAYERWISE_UNET, OR-ed into `precision` of giga_encoder_forward*: one launch per layer (A/B comparisons; the environment
+ *   variable GIGA_UNET_PERSIST=0 does the same for a whole process).
+ *   GIGA_PERSIST_UNET: the persistent launch also where the default keeps per-layer launches (precisions 0 / 3 below 8 scenes). */
 #define GIGA_PERSIST_UNET 32
+#define GIGA_LAYERWISE_UNET 64
 
 /* Inference fast path for the FIXED QUERY LATTICE of VGNImplicit (detection_implicit.py:28-31,107):
  * the R^3 points meshgrid(lin, lin, lin, 'ij') with z fastest, shared by all B scenes.  Each plane is

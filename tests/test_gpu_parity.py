@@ -436,32 +436,35 @@ def test_batch_256_c3_scene_consistency(net, dev):
     net.set_precision("fp32")
 
 
-@pytest.mark.parametrize("B", [8, 32])
-def test_persistent_unet_kernel_opt_in_is_bit_identical(net, dev, B):
-    """net.set_persistent_unet(True) (GIGA_PERSIST_UNET: one persistent U-Net launch, barriers per XCD through the XCD's own
-    L2) computes every image with the same instruction sequence as the per-layer launches: planes and head outputs are
-    bit-identical in the f16-class modes.  In fp32 the units of a layer's ragged last round are summed in parts
-    (conv16_run's tail split: ((p0 + p1) + p2) + p3 instead of one chain), and which units those are depends on how many
-    images a weight group walks -- an eighth of them per XCD here -- so fp32 agrees to rounding only.
-    (This process drives the device from one stream: the flag's contract holds.)"""
+@pytest.mark.parametrize("B", [1, 2, 3, 5, 8, 10, 11, 32])
+def test_persistent_unet_kernel_is_bit_identical_to_per_layer_launches(net, dev, B):
+    """The U-Net as ONE persistent launch (unet_mega_kernel: groups of 8 workgroups inside one XCD walk their images through all
+    layers, barriers through that XCD's own L2) computes every image with the same instruction sequence as the per-layer
+    launches: planes and head outputs are bit-identical in the f16-class modes.  In fp32 the units of a layer's ragged last
+    round are summed in parts (conv16_run's tail split: ((p0 + p1) + p2) + p3 instead of one chain), and which units those are
+    depends on how many images a weight group walks, so fp32 agrees to rounding only.
+    Three launch forms: "layers" (GIGA_LAYERWISE_UNET), the default (persistent up to 10 scenes in the f16-class modes) and the
+    opt-in persistent launch for every batch size (GIGA_PERSIST_UNET; this process drives the device from one stream: the
+    flag's contract holds).  Batches of 1-10 scenes put one image or none on a group; 11 and 32 scenes several, unevenly."""
     x = torch.from_numpy(synth.tsdf_batch(500, B)).to(dev)
     p = torch.from_numpy(synth.query_points(500, B, 64, stream=9)).to(dev)
     try:
         for prec in ("fp32", "fp16x3", "fp16"):
             net.set_precision(prec)
             got = {}
-            for flag in (False, True):
+            for flag in ("layers", False, True):
                 net.set_persistent_unet(flag)
                 with torch.no_grad():
                     for _ in range(3):
                         planes = net.encode_inputs(x)
                         out = net(x, p, p_tsdf=p)
                 got[flag] = [planes[k].clone() for k in ("xz", "xy", "yz")] + [o.clone() for o in out]
-            for a, b in zip(got[False], got[True]):
-                if prec == "fp32":
-                    assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max())), prec
-                else:
-                    assert torch.equal(a, b), prec
+            for flag in (False, True):
+                for a, b in zip(got["layers"], got[flag]):
+                    if prec == "fp32":
+                        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max())), (prec, flag)
+                    else:
+                        assert torch.equal(a, b), (prec, flag)
     finally:
         net.set_persistent_unet(False)
         net.set_precision("fp32")
