@@ -88,13 +88,17 @@ with torch.no_grad():
                 torch.cuda.synchronize()
                 print(prec, "B", Bt, "stage us:", out, "sum", round(sum(out), 1), "wall/iter us", round((time.perf_counter() - t0) / 10 * 1e6, 1))
 
-if what in ("train", "train_bf16"):
+if what in ("train", "train_bf16", "train_flat", "train_bf16_flat"):      # *_flat: the bench's best leg (flat parameter + giga_amd.optim.FlatAdam)
     from giga_amd.training import giga_loss
-    net.train().set_train_precision("bf16" if what.endswith("bf16") else "fp32")
+    net.train().set_train_precision("bf16" if "bf16" in what else "fp32")
     x = torch.from_numpy(synth.tsdf_batch(0, B)).to(dev); pos = torch.from_numpy(synth.query_points(0, B, 1, stream=2)).to(dev)
     pos_occ = torch.from_numpy(synth.query_points(0, B, 2048, stream=3)).to(dev)
     y = tuple(torch.from_numpy(a).to(dev) for a in synth.train_labels(0, B, 2048))
-    opt = torch.optim.Adam(net.parameters(), lr=2e-4, fused=True)
+    if what.endswith("_flat"):
+        from giga_amd.optim import FlatAdam
+        opt = FlatAdam(net.flatten_parameters(), lr=2e-4)
+    else:
+        opt = torch.optim.Adam(net.parameters(), lr=2e-4, fused=True)
     def step():
         opt.zero_grad(set_to_none=True)
         loss, _ = giga_loss(net(x, pos, p_tsdf=pos_occ), y)

@@ -1,0 +1,6 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; R=$PWD; T=${1:-r03y}
+O=$R/gpurun_out/$T; mkdir -p $O; export TMPDIR=/tmp PYTHONPATH=$R
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_train16 -o t -- python $R/tools/gpu_prof.py train_bf16_flat 10 > $O/prof_train_bf16.log 2>&1 ); echo "rocprof train bf16 rc=$?"
+python tools/prof_summary.py /tmp/prof_train16 $O/train_bf16_flat_kernel_stats.txt; head -70 $O/train_bf16_flat_kernel_stats.txt | cut -c1-200
+timeout 300 python -m pytest tests/test_bench_launcher.py -m gpu -q -x > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -n 3 $O/pytest.log
