@@ -20,6 +20,7 @@ BwdWs enc_bwd_workspace(int B);
 int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws,
                             float* gplanes, uint8_t* gws, float* grads, int head_present, int B, hipStream_t s, bool bf16_convs);
 size_t dec_bwd_scratch_floats(long long P, int nheads);
+bool dec_bwd_writes_planes(int nheads, int B, int N);
 int launch_decoder_backward(const float* planes, const float* p, const uint8_t* blob, const uint8_t* bwd_blob,
                             int head_mask, const float* const* outs, const float* const* douts, float* gplanes,
                             float* grads, int head_present, float* scratch, int B, int N, hipStream_t s);
@@ -346,19 +347,23 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
     float* gplanes = reinterpret_cast<float*>(ws);
     uint8_t* gws = ws + gp_bytes;
     float* scratch = reinterpret_cast<float*>(gws + enc_bwd_workspace(B).total);
-    if (hipMemsetAsync(gplanes, 0, gp_bytes, s) != hipSuccess) return -10;
-    if (hipMemsetAsync(grads, 0, n_params * sizeof(float), s) != hipSuccess) return -10;
     const uint8_t* blob = static_cast<const uint8_t*>(packed);
     const uint8_t* bblob = static_cast<const uint8_t*>(bwd_packed);
+    const bool occ_runs = (head_present & 8) && M > 0 && p_tsdf;
+    // The occupancy head with many queries per scene WRITES the plane gradients (plane_gather_kernel: a gather over binned points
+    // instead of global atomics), so it runs first and nothing needs clearing; the grasp heads then add theirs with atomics.
+    const bool occ_writes = occ_runs && !detach_occ && dec_bwd_writes_planes(1, B, M);
+    if (!occ_writes && hipMemsetAsync(gplanes, 0, gp_bytes, s) != hipSuccess) return -10;
+    if (hipMemsetAsync(grads, 0, n_params * sizeof(float), s) != hipSuccess) return -10;
     int rc = 0;
+    if (occ_runs) {
+        rc |= launch_decoder_backward(static_cast<const float*>(planes_nhwc), p_tsdf, blob, bblob, 8, outs, douts,
+                                      detach_occ ? nullptr : gplanes, grads, head_present, scratch, B, M, s);
+    }
     if ((head_present & 7) && N > 0) {
         if (!p) return -1;
         rc |= launch_decoder_backward(static_cast<const float*>(planes_nhwc), p, blob, bblob, head_present & 7, outs,
                                       douts, gplanes, grads, head_present, scratch, B, N, s);
-    }
-    if ((head_present & 8) && M > 0 && p_tsdf) {
-        rc |= launch_decoder_backward(static_cast<const float*>(planes_nhwc), p_tsdf, blob, bblob, 8, outs, douts,
-                                      detach_occ ? nullptr : gplanes, grads, head_present, scratch, B, M, s);
     }
     rc |= launch_encoder_backward(tsdf, blob, bblob, static_cast<const uint8_t*>(enc_workspace_fwd), gplanes, gws,
                                   grads, head_present, B, s, bf16_convs);

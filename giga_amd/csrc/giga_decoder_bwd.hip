@@ -35,6 +35,9 @@ struct DecBwdArgs {
     float* scratch[NHEADS];     // DB_NARR arrays of [P][32]
     float* Cbuf; float* Pbuf;   // [P][96], [P][32]
     float* gplanes;             // NHWC fp32 [3][B][40][40][32], accumulated with atomics; nullptr = detached head
+    float* dcbuf;               // [P][96] or nullptr.  Set (many points per scene, all heads in one workgroup): the kernel stores
+                                // the gradient of the sampled features per point here instead of scattering it with atomics, and
+                                // plane_gather_kernel builds the plane gradients from it (below)
     int nheads, B, N;
     long long P;
     int nbatch; float invN;
@@ -297,7 +300,16 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdArgs a) {
         // Every atomic instruction covers two (point, tap) pairs x 32 CONTIGUOUS channels (two 128-B runs) instead of
         // 64 scattered words: float atomics are resolved outside the XCD-local L2, one fabric operation per touched
         // line, so the transposition through LDS (the weight image is dead by now) cuts that traffic 16-fold.
-        if (a.gplanes) {                          // nullptr: this head is detached from the planes
+        if (a.gplanes && a.dcbuf) {               // the scatter is plane_gather_kernel's: hand over dc as rows of [P][96]
+            if (valid) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(a.dcbuf + g * 96 + pl * 32 + 8 * q + 4 * hi) =
+                            make_float4(dc[pl][4 * q], dc[pl][4 * q + 1], dc[pl][4 * q + 2], dc[pl][4 * q + 3]);
+            }
+        } else if (a.gplanes) {                   // nullptr: this head is detached from the planes
             __syncthreads();                      // every wave is done with the weight image
             float* T = reinterpret_cast<float*>(smem) + wave * (32 * 96 + 32 * 12 * 2);    // [point][96] values
             int* Q = reinterpret_cast<int*>(T + 32 * 96);                                   // [point][plane][tap] offsets
@@ -334,6 +346,114 @@ __global__ __launch_bounds__(256, 1) void decoder_bwd_kernel(DecBwdArgs a) {
                     }
                 }
         }
+    }
+}
+
+// ------------------------------- plane gradients of a many-point head, without float atomics --------------------
+// sample_plane_feature backward (decoder.py:117-122 through autograd = aten's grid_sampler_2d backward): every query point adds
+// w_tap * dc[plane][0..31] to the four pixels of its bilinear footprint in each of the three planes.  As fp32 atomics on HBM
+// that was 74 of the 170 us of the occupancy head's backward at 32 x 2048 queries (25 M atomic lanes; float atomics are resolved
+// outside the XCD-local L2).  LDS float atomics are no way out either: ds_add_f32 retires about one LANE per clock (a
+// 40 x 40 x 16 tile per workgroup filled that way took 169 us, profiles/r03/).  So the scatter is turned into a GATHER:
+// a workgroup owns (half of the pixels, plane, scene); it bins the scene's N points by the pixel cell of their footprint's
+// corner (counting sort in LDS: integer atomics for the histogram and the ranks, one wave for the prefix sum, every cell's short
+// list then ordered by point index), and every output pixel sums the contributions of the points in its four neighbouring cells,
+// with the weights bilin_setup gives (the forward's own).  The result is WRITTEN (no memset, no read-modify-write): a head that
+// uses this path runs before the heads that add with atomics.  Unlike atomics, the sum is in a fixed order (by point index
+// inside a cell, cells in a fixed order): the plane gradient of this head is reproducible bit for bit.
+constexpr int PS_NW = 16;                                   // waves per workgroup
+constexpr int PS_MAXN = 4096;                               // points per scene this path takes (LDS: 6 + 16 bytes per point)
+constexpr int PS_CELLS = RES * RES;
+constexpr size_t PS_LDS = (size_t)(2 * PS_CELLS + 64) * 4 + (size_t)PS_MAXN * (6 + 16);
+__global__ __launch_bounds__(PS_NW * 64) void plane_gather_kernel(const float* __restrict__ dcbuf, const float* __restrict__ p,
+                                                                  float* __restrict__ gplanes, int B, int N) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float4* wts = reinterpret_cast<float4*>(smem);                    // [N] (w00, w01, w10, w11) of every point, by point index
+    int* cnt = reinterpret_cast<int*>(wts + PS_MAXN);                 // [1600] histogram
+    int* start = cnt + PS_CELLS;                                      // [1601] first slot of every cell
+    unsigned short* cell_of = reinterpret_cast<unsigned short*>(start + PS_CELLS + 64);    // [N]
+    unsigned short* rank_of = cell_of + PS_MAXN;                      // [N]
+    unsigned short* sorted = rank_of + PS_MAXN;                       // [N] point indices, cell by cell
+    const int half = blockIdx.x, pl = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t g0 = (size_t)b * N;
+    for (int i = tid; i < PS_CELLS; i += PS_NW * 64) cnt[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += PS_NW * 64) {
+        const size_t g = g0 + i;
+        const float nx = norm_coord(p[3 * g + 0]), ny = norm_coord(p[3 * g + 1]), nz = norm_coord(p[3 * g + 2]);
+        const Bilin bl = pl == 0 ? bilin_setup(nx, nz) : pl == 1 ? bilin_setup(nx, ny) : bilin_setup(ny, nz);
+        wts[i] = make_float4(bl.w00, bl.w01, bl.w10, bl.w11);
+        cell_of[i] = (unsigned short)bl.o00;                          // y0 * 40 + x0
+        rank_of[i] = (unsigned short)atomicAdd(cnt + bl.o00, 1);
+    }
+    __syncthreads();
+    if (wave == 0) {                                                  // exclusive prefix sum of the 1600 counts: 25 cells per lane
+        int tot = 0;
+        for (int k = 0; k < 25; ++k) tot += cnt[lane * 25 + k];
+        int incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        int run = incl - tot;
+        for (int k = 0; k < 25; ++k) { start[lane * 25 + k] = run; run += cnt[lane * 25 + k]; }
+        if (lane == 63) start[PS_CELLS] = run;
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += PS_NW * 64) sorted[start[cell_of[i]] + rank_of[i]] = (unsigned short)i;
+    __syncthreads();
+    for (int c = tid; c < PS_CELLS; c += PS_NW * 64) {                // order every cell's (short) list by point index
+        const int s0 = start[c], s1 = start[c + 1];
+        for (int x = s0 + 1; x < s1; ++x) {
+            const unsigned short v = sorted[x];
+            int y = x - 1;
+            while (y >= s0 && sorted[y] > v) { sorted[y + 1] = sorted[y]; --y; }
+            sorted[y + 1] = v;
+        }
+    }
+    __syncthreads();
+    // gather: 8 lanes per pixel (a float4 of channels each), this half's 800 pixels.  The cells (cy, x-1) and (cy, x) are
+    // neighbours in the sorted array: one contiguous range per cell row (2.6 points on average at 2048 queries per scene); both
+    // rows are walked four points at a time with all eight loads in flight.
+    float* dst = gplanes + ((size_t)pl * B + b) * PS_CELLS * CD;
+    const int q = tid & 7;
+    for (int px = half * (PS_CELLS / 2) + (tid >> 3); px < (half + 1) * (PS_CELLS / 2); px += PS_NW * 64 / 8) {
+        const int y = px / RES, x = px - y * RES;
+        int k0[2], kmid[2], kend[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {                                 // r = 0: the cell row above (its taps dy = 1), r = 1: this row (dy = 0)
+            const int cy = y - 1 + r;
+            const int c_hi = (cy < 0 ? 0 : cy) * RES + x, c_lo = x > 0 ? c_hi - 1 : c_hi;   // tap dx = 1 comes from cell x-1
+            k0[r] = start[c_lo]; kmid[r] = start[c_hi]; kend[r] = cy < 0 ? k0[r] : start[c_hi + 1];
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        while (k0[0] < kend[0] || k0[1] < kend[1]) {
+            float4 v[2][4], w4[2][4];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0[r] + u;
+                    const int id = sorted[k < kend[r] ? k : 0];
+                    w4[r][u] = wts[id];
+                    v[r][u] = *reinterpret_cast<const float4*>(dcbuf + (g0 + id) * 96 + pl * 32 + 4 * q);
+                }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0[r] + u;
+                    if (k >= kend[r]) continue;
+                    const bool dx = k < kmid[r];                      // from cell x-1: this pixel is its right-hand tap
+                    const float w = r == 0 ? (dx ? w4[r][u].w : w4[r][u].z) : (dx ? w4[r][u].y : w4[r][u].x);
+                    acc.x = fmaf(v[r][u].x, w, acc.x); acc.y = fmaf(v[r][u].y, w, acc.y);
+                    acc.z = fmaf(v[r][u].z, w, acc.z); acc.w = fmaf(v[r][u].w, w, acc.w);
+                }
+            k0[0] += 4; k0[1] += 4;
+        }
+        *reinterpret_cast<float4*>(dst + (size_t)px * CD + 4 * q) = acc;
     }
 }
 
@@ -397,7 +517,10 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(LinArgs a) {
 }
 
 // ------------------------------- launcher ------------------------------------------------------------------------
-size_t dec_bwd_scratch_floats(long long P, int nheads) { return (size_t)P * 32 * DB_NARR * nheads + (size_t)P * (96 + 32); }
+size_t dec_bwd_scratch_floats(long long P, int nheads) { return (size_t)P * 32 * DB_NARR * nheads + (size_t)P * (96 + 32 + 96); }
+
+// the plane gradients of this call are gathered and WRITTEN (plane_gather_kernel) instead of added with atomics
+bool dec_bwd_writes_planes(int nheads, int B, int N) { return nheads == 1 && N >= 256 && N <= PS_MAXN && B > 0; }
 
 int launch_decoder_backward(const float* planes, const float* p, const uint8_t* blob, const uint8_t* bwd_blob,
                             int head_mask, const float* const* outs, const float* const* douts, float* gplanes,
@@ -419,6 +542,7 @@ int launch_decoder_backward(const float* planes, const float* p, const uint8_t* 
         ++a.nheads;
     }
     a.Cbuf = sc; a.Pbuf = sc + (size_t)P * 96;
+    a.dcbuf = gplanes && dec_bwd_writes_planes(a.nheads, B, N) ? a.Pbuf + (size_t)P * 32 : nullptr;
     const long long tiles = (P + 31) / 32;
     a.nbatch = (int)((tiles + 3) / 4);
     const int grid = a.nbatch < 256 ? a.nbatch : 256;
@@ -427,6 +551,10 @@ int launch_decoder_backward(const float* planes, const float* p, const uint8_t* 
     const size_t lds = DEC32_BYTES > DECB_BYTES ? DEC32_BYTES : DECB_BYTES;
     giga::dyn_lds_once(reinterpret_cast<const void*>(decoder_bwd_kernel), (int)lds);
     GIGA_LAUNCH(decoder_bwd_kernel, dim3(grid, split ? a.nheads : 1), dim3(256), lds, s, a);
+    if (a.dcbuf) {
+        giga::dyn_lds_once(reinterpret_cast<const void*>(plane_gather_kernel), (int)PS_LDS);
+        GIGA_LAUNCH(plane_gather_kernel, dim3(2, 3, B), dim3(PS_NW * 64), PS_LDS, s, a.dcbuf, p, gplanes, B, N);
+    }
     // weight / bias gradients: one launch per head
     for (int hh = 0; hh < a.nheads; ++hh) {
         const int h = a.head_id[hh];
