@@ -66,8 +66,12 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ g
 //   CONV3 / CONV1 : R = dPre (m = co), Cc = layer input at the tap-shifted pixel (n = ci, zero outside)
 //   UPCONV        : R = layer input (m = ci), Cc = dU at (2y+dy, 2x+dx) (n = co)
 // Operands come straight from HBM/L2 (32 lanes x 4 B contiguous per pixel), no LDS staging: one MFMA
-// (64 cycles) per two 128-byte loads.  Block = (tap, 32x32 block of dW, pixel range); its 4 waves split
+// (64 cycles) per two 128-byte loads.  Block = (tap, 32x32 block of dW, pixel range); its 16 waves split
 // the range, partials are summed through LDS and added to the gradient buffer with one atomic per element.
+// ~256 workgroups per launch: these launches are bound by their ATOMICS, not by the reduction (float atomics are fabric
+// operations, and all pixel ranges of a block hit the same 1024 addresses): with 768 workgroups of 4 waves the 1x1 layer's
+// gradient took 39 us and the two ConvTranspose layers' 31 us each for 4-5 us of loads and MFMAs; a third of the workgroups
+// with four times the waves issue a third of the atomics and keep the same number of loads in flight.
 struct WgradArgs {
     const float* R; int csR, coR;                 // row tensor, channel stride, first channel
     const float* C0p; const float* C1p;           // column tensor(s) (concat order), channel strides / split
@@ -77,10 +81,13 @@ struct WgradArgs {
     int nimg, H, W;                               // base pixel grid (the R tensor's)
     unsigned mHW, mW;                             // magic multipliers for / (H*W) and / W
     long long npix; int pix_per_block;
+    float* partial;                               // [workgroup][16 registers][64 lanes]: the workgroups' 32x32 tiles, summed by conv_wgrad_reduce_kernel
 };
 
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
-    __shared__ float red[3][64][17];
+constexpr int WG_NW = 16;                          // waves per workgroup of conv_wgrad_kernel
+template <bool UP>                                 // UP: the ConvTranspose form (a.kind == UPCONV); else CONV3 / CONV1
+__global__ __launch_bounds__(WG_NW * 64) void conv_wgrad_kernel(WgradArgs a) {
+    __shared__ float red[WG_NW][16][64];             // [wave][register][lane]: conflict-free both ways, 64 KiB
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, hi = lane >> 5;
@@ -96,56 +103,93 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int csC = n0 < a.nC0 ? a.csC0 : a.csC1;
     const int cn = (n0 < a.nC0 ? n0 : n0 - a.nC0) + i;
     const int HW = a.H * a.W;
-    const int ky = a.kind == CONV3 ? tap / 3 - 1 : 0, kx = a.kind == CONV3 ? tap % 3 - 1 : 0;
+    const int ky = !UP && a.kind == CONV3 ? tap / 3 - 1 : 0, kx = !UP && a.kind == CONV3 ? tap % 3 - 1 : 0;
 
     // fp32 MFMA shares the VALU, so the loop keeps per-load vector work at zero: W is even, hence a pixel pair
     // (p even, p+1) never straddles a row and the pair's (image, row, column) are wave-uniform SALU values; the
     // per-lane part of every address (odd pixel of the pair for the upper lane half, channel) is loop-invariant.
-    const int laneR = hi * a.csR + a.coR + mb * 32 + i;
-    const int laneC = (a.kind == UPCONV ? 2 * hi : hi) * csC + cn;
+    // The SCALAR work matters just as much: a CU has one scalar unit for its sixteen waves, and the first version of this loop
+    // (two magic divisions and 64-bit index arithmetic per pixel pair, ~80 SALU instructions) made these launches 21-39 us for
+    // ~4 us of loads and MFMAs.  Now: one division per step of four pairs, the pairs after the first by increment, 32-bit
+    // element offsets from the tensor bases (launch_wgrad bounds the tensors), all eight loads of a step issued before the
+    // first use.
+    const unsigned laneR = (unsigned)(hi * a.csR + a.coR + mb * 32 + i);
+    const unsigned laneC = (unsigned)((UP ? 2 * hi : hi) * csC + cn);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // this wave's share: pixels p0 + 8*wave + 32*k + {0..7}; lane half hi takes the odd pixel of each pair
-    for (long long base = p0 + 8 * wave; base < p1; base += 32) {
-        float av[4], bv[4];
+    // this wave's share: pixels p0 + 8*wave + 8*WG_NW*k + {0..7}; lane half hi takes the odd pixel of each pair
+    for (long long base = p0 + 8 * wave; base < p1; base += 8 * WG_NW) {
+        int img = div_magic((int)base, a.mHW), rem = (int)base - img * HW;
+        int py = div_magic(rem, a.mW), px = rem - py * a.W;
+        unsigned oR[4], oC[4];
+        bool okR[4], okC[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const long long pe = base + 2 * s;                    // even pixel of the pair (uniform)
-            float x = 0.f, y = 0.f;
-            if (pe < p1) {                                        // npix and the block ranges are even
-                x = a.R[(size_t)pe * a.csR + laneR];
-                const int img = div_magic((int)pe, a.mHW), rem = (int)pe - img * HW;
-                const int py = div_magic(rem, a.mW), px = rem - py * a.W;
-                if (a.kind == UPCONV) {
-                    const size_t q = ((size_t)img * 2 * a.H + 2 * py + (tap >> 1)) * (2 * a.W) + 2 * px + (tap & 1);
-                    y = Cc[q * csC + laneC];
-                } else {
-                    const int qy = py + ky, qx = px + kx;         // column of the even pixel's tap
-                    const bool row_in = qy >= 0 && qy < a.H;
-                    const bool lo_ok = qx >= 0, hi_ok = qx + 1 < a.W;       // uniform; qx+1 >= 0 and qx < W always
-                    if (row_in && (hi ? hi_ok : lo_ok))
-                        y = Cc[((long long)img * HW + qy * a.W + qx) * csC + laneC];
-                }
+            okR[s] = base + 2 * s < p1;                           // npix and the block ranges are even
+            oR[s] = (unsigned)((int)base + 2 * s) * (unsigned)a.csR + laneR;
+            if constexpr (UP) {
+                const unsigned q = (unsigned)((img * 2 * a.H + 2 * py + (tap >> 1)) * (2 * a.W) + 2 * px + (tap & 1));
+                oC[s] = q * (unsigned)csC + laneC; okC[s] = okR[s];
+            } else {
+                const int qy = py + ky, qx = px + kx;             // column of the even pixel's tap
+                const bool row_in = qy >= 0 && qy < a.H;
+                const bool lo_ok = qx >= 0, hi_ok = qx + 1 < a.W;           // uniform; qx+1 >= 0 and qx < W always
+                okC[s] = okR[s] && row_in && (hi ? hi_ok : lo_ok);
+                oC[s] = (unsigned)(img * HW + qy * a.W + qx) * (unsigned)csC + laneC;
             }
-            av[s] = x; bv[s] = y;
+            if (!okR[s]) oR[s] = oR[0];                           // (clamped: the value is zeroed below)
+            if (!okC[s]) oC[s] = laneC;
+            px += 2;
+            if (px >= a.W) { px = 0; if (++py >= a.H) { py = 0; ++img; } }
         }
+        float av[4], bv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { av[s] = a.R[oR[s]]; bv[s] = Cc[oC[s]]; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { av[s] = okR[s] ? av[s] : 0.f; bv[s] = okC[s] ? bv[s] : 0.f; }
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = mfma32(av[s], bv[s], acc);
     }
-    // D: lane (n = lane&31, hi), reg r <-> row m = drow(r, hi), column n
-    if (wave > 0) {
+    // D: lane (n = lane&31, hi), reg r <-> row m = drow(r, hi), column n.  Every wave parks its tile; wave w then sums register w
+    // of all sixteen tiles (sixteen LDS reads per wave, side by side -- one wave summing fifteen tiles took longer than the loop).
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave - 1][lane][r] = acc[r];
-    }
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
     __syncthreads();
-    if (wave == 0) {
+    static_assert(WG_NW == 16, "one wave per accumulator register");
+    float v = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float v = acc[r] + red[0][lane][r] + red[1][lane][r] + red[2][lane][r];
-            const int m = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, n = n0 + i;
-            atomicAdd(a.dW + (size_t)m * a.sM + (size_t)n * a.sN + (size_t)tap * a.sT, v);
-        }
+    for (int w = 0; w < WG_NW; ++w) v += red[w][wave][lane];
+    a.partial[((size_t)blockIdx.x * 16 + wave) * 64 + lane] = v;
+}
+
+// dW[m][n][tap] += sum over the pixel ranges of the workgroups' tiles.  One workgroup per 64 tile elements: four quarter sums
+// per element (every thread a quarter of the ranges, eight loads in flight), folded through LDS; every dW element has exactly
+// one writer.  (Atomics instead -- 256...768 workgroups adding onto the same 1024 addresses per block -- made these launches
+// 27-39 us for 4-5 us of loads and MFMAs: float atomics are fabric operations.)
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(WgradArgs a, int blocks_wn, int ksplit) {
+    __shared__ float part[4][64];
+    const int blk = blockIdx.x >> 4, e = ((blockIdx.x & 15) << 6) + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const float* src = a.partial + (size_t)blk * 1024 + e;
+    const size_t stride = (size_t)blocks_wn * 1024;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int ks = q;
+    for (; ks + 12 < ksplit; ks += 16) {
+        s0 += src[(size_t)ks * stride]; s1 += src[(size_t)(ks + 4) * stride];
+        s2 += src[(size_t)(ks + 8) * stride]; s3 += src[(size_t)(ks + 12) * stride];
+    }
+    for (; ks < ksplit; ks += 4) s0 += src[(size_t)ks * stride];
+    part[q][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0) {
+        const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        int b = blk;
+        const int nb = b % a.Nb; b /= a.Nb;
+        const int mb = b % a.Mb; b /= a.Mb;
+        const int tap = b;
+        const int r = e >> 6, lane = e & 63, i = lane & 31, hi = lane >> 5;
+        const int m = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, n = nb * 32 + i;
+        a.dW[(size_t)m * a.sM + (size_t)n * a.sN + (size_t)tap * a.sT] += v;
     }
 }
 
@@ -153,15 +197,20 @@ static int launch_wgrad(WgradArgs a, hipStream_t s) {
     a.npix = (long long)a.nimg * a.H * a.W;
     a.mHW = (unsigned)((0x100000000ULL + (unsigned)(a.H * a.W) - 1) / (unsigned)(a.H * a.W));
     a.mW = (unsigned)((0x100000000ULL + (unsigned)a.W - 1) / (unsigned)a.W);
+    // conv_wgrad_kernel addresses its tensors with 32-bit element offsets
+    const long long cpix = a.npix * (a.kind == UPCONV ? 4 : 1);
+    if (a.npix >= (1ll << 31) || a.npix * a.csR >= (1ll << 31) || cpix * (a.csC0 > a.csC1 ? a.csC0 : a.csC1) >= (1ll << 31)) return -7;
     const int blocks_wn = a.taps * a.Mb * a.Nb;
-    int ksplit = 768 / blocks_wn;      // few workgroups per gradient element: every atomic is a fabric operation
+    int ksplit = 256 / blocks_wn;      // few workgroups per gradient element: every atomic is a fabric operation
     if (ksplit < 1) ksplit = 1;
     long long ppb = (a.npix + ksplit - 1) / ksplit;
     ppb = (ppb + 31) / 32 * 32;
     if (ppb < 32) ppb = 32;
     a.pix_per_block = (int)ppb;
     ksplit = (int)((a.npix + ppb - 1) / ppb);
-    GIGA_LAUNCH(conv_wgrad_kernel, dim3(blocks_wn * ksplit), dim3(256), 0, s, a);
+    if (a.kind == UPCONV) GIGA_LAUNCH(conv_wgrad_kernel<true>, dim3(blocks_wn * ksplit), dim3(WG_NW * 64), 0, s, a);
+    else GIGA_LAUNCH(conv_wgrad_kernel<false>, dim3(blocks_wn * ksplit), dim3(WG_NW * 64), 0, s, a);
+    GIGA_LAUNCH(conv_wgrad_reduce_kernel, dim3(blocks_wn * 16), dim3(256), 0, s, a, blocks_wn, ksplit);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
@@ -830,6 +879,7 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
         a.dW = grads + po.conv_w[l]; a.sM = cin * taps; a.sN = taps; a.sT = 1;
         a.kind = d.kind; a.taps = taps; a.Mb = d.cout / 32; a.Nb = cin / 32;
         a.nimg = nimg; a.H = H; a.W = H;
+        a.partial = G(g.WG);
         if (d.kind == CONV3) {
             Wgrad3Args w3{dpre, in0, in1, grads + po.conv_w[l], grads + po.conv_b[l], G(g.WG), nimg};
 #define WG3(...) (MATH == MATH_BF16 ? launch_wgrad3_bf16<__VA_ARGS__>(w3, s) : launch_wgrad3<__VA_ARGS__>(w3, s))
@@ -858,6 +908,7 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
         a.dW = grads + po.conv_w[l]; a.sM = d.cout * 4; a.sN = 4; a.sT = 1;
         a.kind = UPCONV; a.taps = 4; a.Mb = d.cin0 / 32; a.Nb = d.cout / 32;
         a.nimg = nimg; a.H = H; a.W = H;
+        a.partial = G(g.WG);
         rc |= launch_wgrad(a, s);
         colsum(dcat, cs_cat, 0, d.cout, (size_t)nimg * 4 * H * H, l);
     };

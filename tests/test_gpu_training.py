@@ -88,6 +88,40 @@ def test_gradients_at_batch_32(sd7, M, loss_kind):
         assert (got - ref).abs().max().item() <= 2e-3 * scale + 1e-6, name
 
 
+@pytest.mark.parametrize("B,M", [(3, 301), (2, 4096), (5, 256)])
+def test_plane_gradient_gather_path(sd7, B, M):
+    """From 256 occupancy queries per scene up (to 4096) the plane gradient of the occupancy head is built by a binned gather
+    (csrc/giga_decoder_bwd.hip::plane_gather_kernel: sample_plane_feature backward, decoder.py:117-122 through autograd) instead
+    of fp32 atomics.  Ragged sizes (M not a multiple of 4 / 64, the LDS capacity), queries ON the cube's faces and corners
+    (footprints in the last pixel row / column, the clamped coordinates of common.py:238-261) and many queries in ONE pixel
+    cell (long cell lists); gradients against the oracle, and the encoder gradients -- which only see the decoders through
+    the plane gradient -- again after a second identical step (the gather sums in a fixed order; what remains of run-to-run
+    differences are the atomics of the weight-gradient reductions)."""
+    dev = torch.device("cuda:0")
+    x, pos, pos_occ, y = _batch(700, B, M)
+    pos_occ = pos_occ.clone()
+    pos_occ[:, 0:8] = torch.tensor([[-0.5, -0.5, -0.5], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [-0.5, 0.5, -0.5],
+                                    [0.5, 0.0, 0.0], [0.0, 0.5, 0.0], [0.0, 0.0, 0.5], [0.6, -0.7, 0.55]])
+    pos_occ[:, 8:72] = torch.tensor([0.1013, -0.2031, 0.3047]) + 1e-3 * torch.rand(64, 3, generator=torch.Generator().manual_seed(3))
+    ref_loss, ref_grads, _ = _oracle_grads(sd7, x, pos, pos_occ, y)
+    net = networks.get_network("giga")
+    net.load_state_dict(sd7)
+    net = net.to(dev).train()
+    runs = []
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)
+        loss, _ = giga_loss(net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev)), tuple(t.to(dev) for t in y))
+        assert abs(loss.item() - ref_loss) < 1e-5
+        loss.backward()
+        runs.append({n: q.grad.detach().clone() for n, q in net.named_parameters()})
+    for name, ref in ref_grads.items():
+        got = runs[0][name].cpu()
+        scale = ref.abs().max().item()
+        assert (got - ref).abs().max().item() <= 2e-3 * scale + 1e-6, name
+        if name.startswith("encoder."):
+            assert (runs[0][name] - runs[1][name]).abs().max().item() <= 1e-4 * scale + 1e-7, name
+
+
 def test_bf16_training_step(sd7, monkeypatch):
     """BASELINE c5 arithmetic: bf16 operands (fp32 accumulate) in the U-Net's forward and data-gradient convolutions.
     bf16 keeps 8 significant bits, and this U-Net has no normalisation layers: on the synthetic weights the planes move by ~1 %
