@@ -33,34 +33,6 @@ __global__ void pool_bwd_add_kernel(float* __restrict__ dS, const float* __restr
     dS[i] = s > 0.f ? dcat[pix * cs + coff + c] + (s == Q[qi] ? dQ[qi] : 0.f) : 0.f;
 }
 
-// db[c] += sum over rows of g[row * cs + coff + c]   (C, cs, coff multiples of 4; C/4 divides 256)
-// 16-byte loads, four rows in flight per thread, and only 128 workgroups: the C atomics per workgroup all
-// land on the same C addresses, and it is their serialisation, not the read, that the old 256-WG scalar
-// version spent its time on.
-__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ g, int cs, int coff, int C,
-                                                     size_t rows, float* __restrict__ db) {
-    __shared__ float4 part[256];
-    const int tpr = C >> 2, q = threadIdx.x % tpr, lane_row = threadIdx.x / tpr, rpb = 256 / tpr;
-    const size_t stride = (size_t)gridDim.x * rpb;
-    const float* p = g + coff + 4 * q;
-    auto ld = [&](size_t r) { return *reinterpret_cast<const float4*>(p + r * cs); };
-    float4 s = {0.f, 0.f, 0.f, 0.f};
-    auto acc = [&](const float4& v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; };
-    size_t r = (size_t)blockIdx.x * rpb + lane_row;
-    for (; r + 3 * stride < rows; r += 4 * stride) {
-        const float4 v0 = ld(r), v1 = ld(r + stride), v2 = ld(r + 2 * stride), v3 = ld(r + 3 * stride);
-        acc(v0); acc(v1); acc(v2); acc(v3);
-    }
-    for (; r < rows; r += stride) acc(ld(r));
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (lane_row == 0) {
-        for (int k = 1; k < rpb; ++k) acc(part[k * tpr + q]);
-        atomicAdd(db + 4 * q + 0, s.x); atomicAdd(db + 4 * q + 1, s.y);
-        atomicAdd(db + 4 * q + 2, s.z); atomicAdd(db + 4 * q + 3, s.w);
-    }
-}
-
 // ------------------------------- weight gradient (MFMA reduction over pixels) ----------------------------
 // D[m][n] += sum_p R[p][m] * Cc[map(p, tap)][n]   on v_mfma_f32_32x32x2_f32 (2 pixels per MFMA).
 //   CONV3 / CONV1 : R = dPre (m = co), Cc = layer input at the tap-shifted pixel (n = ci, zero outside)
@@ -81,7 +53,9 @@ struct WgradArgs {
     int nimg, H, W;                               // base pixel grid (the R tensor's)
     unsigned mHW, mW;                             // magic multipliers for / (H*W) and / W
     long long npix; int pix_per_block;
-    float* partial;                               // [workgroup][16 registers][64 lanes]: the workgroups' 32x32 tiles, summed by conv_wgrad_reduce_kernel
+    float* partial;                               // [workgroup][16 registers][64 lanes]: the workgroups' 32x32 tiles, summed by conv_wgrad_reduce_kernel;
+                                                  // behind them [workgroup][32]: column sums of the gradient tensor (bias gradient)
+    float* db; int nbias;                         // bias gradient (cout entries) or nullptr
 };
 
 constexpr int WG_NW = 16;                          // waves per workgroup of conv_wgrad_kernel
@@ -118,6 +92,7 @@ __global__ __launch_bounds__(WG_NW * 64) void conv_wgrad_kernel(WgradArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;
     // this wave's share: pixels p0 + 8*wave + 8*WG_NW*k + {0..7}; lane half hi takes the odd pixel of each pair
     for (long long base = p0 + 8 * wave; base < p1; base += 8 * WG_NW) {
         int img = div_magic((int)base, a.mHW), rem = (int)base - img * HW;
@@ -149,6 +124,8 @@ __global__ __launch_bounds__(WG_NW * 64) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) { av[s] = okR[s] ? av[s] : 0.f; bv[s] = okC[s] ? bv[s] : 0.f; }
 #pragma unroll
+        for (int s = 0; s < 4; ++s) bsum += UP ? bv[s] : av[s];   // the gradient tensor's channel of this lane (bias gradient)
+#pragma unroll
         for (int s = 0; s < 4; ++s) acc = mfma32(av[s], bv[s], acc);
     }
     // D: lane (n = lane&31, hi), reg r <-> row m = drow(r, hi), column n.  Every wave parks its tile; wave w then sums register w
@@ -161,6 +138,21 @@ __global__ __launch_bounds__(WG_NW * 64) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int w = 0; w < WG_NW; ++w) v += red[w][wave][lane];
     a.partial[((size_t)blockIdx.x * 16 + wave) * 64 + lane] = v;
+    // bias gradient = column sums of the gradient tensor (dPre, or dU for the ConvTranspose form): the blocks that see every
+    // channel exactly once per pixel range hand over their sums (UP: column block nb of every tap, first row block; else: row
+    // block mb, first column block and tap)
+    if (a.db && (UP ? mb == 0 : (nb == 0 && tap == 0))) {
+        bsum += __shfl_xor(bsum, 32);
+        __syncthreads();                                         // the tiles in `red` have been read
+        if (hi == 0) red[wave][0][i] = bsum;
+        __syncthreads();
+        if (wave == 0 && hi == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WG_NW; ++w) t += red[w][0][i];
+            a.partial[(size_t)gridDim.x * 1024 + (size_t)blockIdx.x * 32 + i] = t;
+        }
+    }
 }
 
 // dW[m][n][tap] += sum over the pixel ranges of the workgroups' tiles.  One workgroup per 64 tile elements: four quarter sums
@@ -169,6 +161,28 @@ __global__ __launch_bounds__(WG_NW * 64) void conv_wgrad_kernel(WgradArgs a) {
 // 27-39 us for 4-5 us of loads and MFMAs: float atomics are fabric operations.)
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(WgradArgs a, int blocks_wn, int ksplit) {
     __shared__ float part[4][64];
+    if ((int)blockIdx.x >= blocks_wn * 16) {                     // the workgroups behind the tiles: bias gradient, 32 channels each
+        const int cb = (int)blockIdx.x - blocks_wn * 16, i = threadIdx.x & 31, q8 = threadIdx.x >> 5;   // 8 partial sums per channel
+        const bool up = a.kind == UPCONV;
+        const float* bsrc = a.partial + (size_t)blocks_wn * ksplit * 1024;
+        // contributing blocks: UP: (tap 0..3, mb = 0, nb = cb); else: (tap 0, mb = cb, nb = 0); index ((ks*taps + tap)*Mb + mb)*Nb + nb
+        const int ntap = up ? a.taps : 1;
+        float t = 0.f;
+        for (int j = q8; j < ksplit * ntap; j += 8) {
+            const int ks = j / ntap, tap = j - ks * ntap;
+            const int blk = up ? ((ks * a.taps + tap) * a.Mb) * a.Nb + cb : ((ks * a.taps) * a.Mb + cb) * a.Nb;
+            t += bsrc[(size_t)blk * 32 + i];
+        }
+        part[q8 >> 1][(q8 & 1) * 32 + i] = t;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += part[k >> 1][(k & 1) * 32 + i];
+            a.db[cb * 32 + i] += v;
+        }
+        return;
+    }
     const int blk = blockIdx.x >> 4, e = ((blockIdx.x & 15) << 6) + (threadIdx.x & 63), q = threadIdx.x >> 6;
     const float* src = a.partial + (size_t)blk * 1024 + e;
     const size_t stride = (size_t)blocks_wn * 1024;
@@ -210,7 +224,7 @@ static int launch_wgrad(WgradArgs a, hipStream_t s) {
     ksplit = (int)((a.npix + ppb - 1) / ppb);
     if (a.kind == UPCONV) GIGA_LAUNCH(conv_wgrad_kernel<true>, dim3(blocks_wn * ksplit), dim3(WG_NW * 64), 0, s, a);
     else GIGA_LAUNCH(conv_wgrad_kernel<false>, dim3(blocks_wn * ksplit), dim3(WG_NW * 64), 0, s, a);
-    GIGA_LAUNCH(conv_wgrad_reduce_kernel, dim3(blocks_wn * 16), dim3(256), 0, s, a, blocks_wn, ksplit);
+    GIGA_LAUNCH(conv_wgrad_reduce_kernel, dim3(blocks_wn * 16 + (a.db ? a.nbias / 32 : 0)), dim3(256), 0, s, a, blocks_wn, ksplit);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
@@ -866,9 +880,6 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
     auto F = [&](size_t off) { return reinterpret_cast<const float*>(fws + off); };
     auto G = [&](size_t off) { return reinterpret_cast<float*>(gws + off); };
     int rc = 0;
-    auto colsum = [&](const float* grad, int cs, int coff, int C, size_t rows, int layer) {
-        GIGA_LAUNCH(colsum_kernel, dim3(128), dim3(256), 0, s, grad, cs, coff, C, rows, grads + po.conv_b[layer]);
-    };
     // weight gradient of layer l: R = dPre (channels = cout), columns = layer input (in0 [, in1])
     auto wgrad3 = [&](int l, const float* dpre, const float* in0, const float* in1, int H) {
         const ConvLayerDesc& d = kConv[l];
@@ -880,6 +891,7 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
         a.kind = d.kind; a.taps = taps; a.Mb = d.cout / 32; a.Nb = cin / 32;
         a.nimg = nimg; a.H = H; a.W = H;
         a.partial = G(g.WG);
+        a.db = grads + po.conv_b[l]; a.nbias = d.cout;          // bias gradient = column sums of dPre, folded into the same two launches
         if (d.kind == CONV3) {
             Wgrad3Args w3{dpre, in0, in1, grads + po.conv_w[l], grads + po.conv_b[l], G(g.WG), nimg};
 #define WG3(...) (MATH == MATH_BF16 ? launch_wgrad3_bf16<__VA_ARGS__>(w3, s) : launch_wgrad3<__VA_ARGS__>(w3, s))
@@ -892,11 +904,10 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
                 case 4: rc |= WG3(64, 0, 128, 10, 2); break;
                 case 5: rc |= WG3(128, 0, 128, 10, 2); break;
 #undef WG3
-                default: rc |= launch_wgrad(a, s); colsum(dpre, d.cout, 0, d.cout, (size_t)nimg * H * H, l);
+                default: rc |= launch_wgrad(a, s);
             }
         } else {
             rc |= launch_wgrad(a, s);
-            colsum(dpre, d.cout, 0, d.cout, (size_t)nimg * H * H, l);
         }
     };
     // ConvTranspose2d(cin, cout, 2, 2): dW[ci][co][d] = sum In[p][ci] * dU[up(p,d)][co]; dU = channels [0,cout) of dcat
@@ -909,8 +920,8 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
         a.kind = UPCONV; a.taps = 4; a.Mb = d.cin0 / 32; a.Nb = d.cout / 32;
         a.nimg = nimg; a.H = H; a.W = H;
         a.partial = G(g.WG);
+        a.db = grads + po.conv_b[l]; a.nbias = d.cout;          // bias gradient = column sums of dU over all four taps
         rc |= launch_wgrad(a, s);
-        colsum(dcat, cs_cat, 0, d.cout, (size_t)nimg * 4 * H * H, l);
     };
     // data gradient of layer l; relu_of: the forward activation the gradient flows into next (ReLU output of the layer
     // below): its backward mask is applied in the convolution's epilogue instead of by a separate pass over the tensor
