@@ -425,15 +425,18 @@ __global__ __launch_bounds__(512) void conv3_wgrad_kernel(Wgrad3Args a) {
     WG3_T(31);
 }
 
-// dW[co][ci][tap] of block gb = sum over the nx workgroups of partial[by][bx][b][tap][co][ci]   (gb = by*BPG + b);
-// the sum over workgroups is split in NZ groups (blockIdx.z) whose results meet in dW with one atomic each
-template <int CIN, int BPG, int NZ>
+// dW[co][ci][tap] of block gb = sum over the nx workgroups of partial[by][bx][b][tap][co][ci]   (gb = by*BPG + b).
+// A workgroup takes 64 elements of a block; every element's sum over the nx partial images is cut into four interleaved quarter
+// sums (one per wave, up to eight loads in flight), folded through LDS; every dW element has exactly one writer.  (Round 2: one
+// thread per element walked all nx = 128-256 images -- a chain of 32-64 dependent round trips, 13-24 us per layer, 128 us of the
+// bf16 step -- or, for the small layers, NZ groups meeting in dW with atomics.)
+template <int CIN, int BPG>
 __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restrict__ partial, int nx, float* __restrict__ dW,
                                                             float* __restrict__ db, int cout, int ny) {
     constexpr int RN = 9 * 1024, NBK = CIN / 32;
-    if (blockIdx.x == RN / 256) {                               // one extra block: the bias gradient
-        if (blockIdx.y != 0 || blockIdx.z != 0) return;
-        __shared__ float sb[256];
+    __shared__ float sb[256];
+    if (blockIdx.x == RN / 64) {                                // one extra block: the bias gradient
+        if (blockIdx.y != 0) return;
         const int c = threadIdx.x % cout, part = threadIdx.x / cout, np = 256 / cout;     // cout divides 256
         const float* bsrc = partial + (size_t)ny * nx * BPG * RN + c;
         float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
@@ -452,20 +455,27 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restr
         }
         return;
     }
-    const int e = blockIdx.x * 256 + threadIdx.x;               // RN is a multiple of 256
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
     const int gb = blockIdx.y, by = gb / BPG, b = gb % BPG;
-    const int x0 = (int)((long long)nx * blockIdx.z / NZ), x1 = (int)((long long)nx * (blockIdx.z + 1) / NZ);
     const float* src = partial + ((size_t)by * nx * BPG + b) * RN + e;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int x = x0;
-    for (; x + 4 <= x1; x += 4) {
-        s0 += src[(size_t)(x + 0) * BPG * RN]; s1 += src[(size_t)(x + 1) * BPG * RN];
-        s2 += src[(size_t)(x + 2) * BPG * RN]; s3 += src[(size_t)(x + 3) * BPG * RN];
+    constexpr size_t ST = (size_t)BPG * RN;
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
+    int x = q;
+    for (; x + 28 < nx; x += 32) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += src[(size_t)(x + 4 * k) * ST];
     }
-    for (; x < x1; ++x) s0 += src[(size_t)x * BPG * RN];
-    const int t = e >> 10, m = (e >> 5) & 31, n = e & 31;
-    const int gmb = gb / NBK, gnb = gb % NBK;
-    atomicAdd(dW + ((size_t)(gmb * 32 + m) * CIN + gnb * 32 + n) * 9 + t, (s0 + s1) + (s2 + s3));
+    for (; x < nx; x += 4) s[0] += src[(size_t)x * ST];
+    sb[threadIdx.x] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (q == 0) {
+        const float v = (sb[threadIdx.x] + sb[64 + threadIdx.x]) + (sb[128 + threadIdx.x] + sb[192 + threadIdx.x]);
+        const int t = e >> 10, m = (e >> 5) & 31, n = e & 31;
+        const int gmb = gb / NBK, gnb = gb % NBK;
+        dW[((size_t)(gmb * 32 + m) * CIN + gnb * 32 + n) * 9 + t] += v;
+    }
 }
 
 template <int C0, int C1, int COUT, int H, int RS>
@@ -482,8 +492,7 @@ static int launch_wgrad3(const Wgrad3Args& a, hipStream_t s) {
     auto kern = conv3_wgrad_kernel<C0, C1, COUT, H, RS>;
     giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
     GIGA_LAUNCH(kern, dim3(gx, NY), dim3(512), lds, s, a);
-    constexpr int NZ = NBLK >= 8 ? 1 : 8 / NBLK;                 // >= 288 reducing workgroups for every layer
-    GIGA_LAUNCH((wgrad3_reduce_kernel<CIN, BPG, NZ>), dim3(9 * 1024 / 256 + 1, NBLK, NZ), dim3(256), 0, s, a.partial, gx,
+    GIGA_LAUNCH((wgrad3_reduce_kernel<CIN, BPG>), dim3(9 * 1024 / 64 + 1, NBLK), dim3(256), 0, s, a.partial, gx,
                        a.dW, a.db, COUT, NY);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
@@ -672,8 +681,7 @@ static int launch_wgrad3_bf16(const Wgrad3Args& a, hipStream_t s) {
     auto kern = conv3_wgrad_bf16_kernel<C0, C1, COUT, H, RS>;
     giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
     GIGA_LAUNCH(kern, dim3(gx, NY), dim3(512), lds, s, a);
-    constexpr int NZ = NBLK >= 8 ? 1 : 8 / NBLK;
-    GIGA_LAUNCH((wgrad3_reduce_kernel<CIN, BPG, NZ>), dim3(9 * 1024 / 256 + 1, NBLK, NZ), dim3(256), 0, s, a.partial, gx,
+    GIGA_LAUNCH((wgrad3_reduce_kernel<CIN, BPG>), dim3(9 * 1024 / 64 + 1, NBLK), dim3(256), 0, s, a.partial, gx,
                        a.dW, a.db, COUT, NY);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
