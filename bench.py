@@ -616,6 +616,46 @@ def bench_c4(net, dev, L, _capi, synth, decode_heads, prec, Bc=32, steps=10):
     }
 
 
+def bench_c4_graph(net, dev, synth, decode_heads, prec, Bc=1, replays=300):
+    """The c4 network call (encoder + lattice decode of Bc scenes) captured ONCE into a hipGraph and replayed: what a planner loop
+    pays per call when the host only replays (giga_amd.detection.VGNImplicit does that), without this file's event brackets and
+    without the per-launch host cost of five library calls.  The replayed output is checked against the oracle afterwards."""
+    net.set_precision(prec)
+    blob = net.packed_blob(dev)
+    from giga_amd.detection import query_lattice
+    x = torch.from_numpy(synth.tsdf_batch(1000, Bc)).to(dev)
+    lat = query_lattice(40, dev)
+
+    def step():
+        with torch.no_grad():
+            nhwc, _ = net.encoder.encode_nhwc(x, blob=blob, precision=prec, fold_final=True)
+            return decode_heads(nhwc, lat, blob, 7, prec, True, folded=True)
+
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = step()
+    _settle()
+    for _ in range(200):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(replays):
+        graph.replay()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    checked = check_c4_scene(out, prec, synth)
+    net.set_precision("fp32")
+    return {"workload": f"c4 network call on {Bc} scene(s) x the 64000-point lattice, {prec}, one hipGraph replay per call",
+            "ms_per_call": el / replays * 1e3, "scenes_per_sec": Bc * replays / el, "replays": replays, "checked_vs_oracle": checked}
+
+
 _C4_ORACLE = {}
 C4_TOL = {"fp32": 1e-4, "fp16x3": 1e-4, "fp16": 1e-2}       # the tolerances of tests/test_gpu_c4_shapes.py (rot, width: x2)
 
@@ -660,6 +700,7 @@ def bench_c4_all(net, dev, L, _capi, synth, decode_heads):
                           "decoder_frac_net_of_bracket": r["roofline"]["frac_net_of_bracket"],
                           "checked_vs_oracle_max_abs_err": r["checked_vs_oracle"]["max_abs_err"]})
         out[key + "_sweep"] = sweep
+        out[key + "_single_scene_graph_replay"] = bench_c4_graph(net, dev, synth, decode_heads, prec)
     return out
 
 
