@@ -8,9 +8,9 @@ timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o b -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/prof_bench.log 2>&1 ); echo "rocprof bench rc=$?"
 python tools/prof_summary.py /tmp/prof_bench $O/bench_kernel_stats.txt
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_train -o t -- python $R/tools/gpu_prof.py train 10 > $O/prof_train.log 2>&1 ); echo "rocprof train rc=$?"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_train -o t -- python $R/tools/gpu_prof.py train_flat 10 > $O/prof_train.log 2>&1 ); echo "rocprof train rc=$?"
 python tools/prof_summary.py /tmp/prof_train $O/train_kernel_stats.txt
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_train16 -o t -- python $R/tools/gpu_prof.py train_bf16 10 > $O/prof_train_bf16.log 2>&1 ); echo "rocprof train bf16 rc=$?"
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_train16 -o t -- python $R/tools/gpu_prof.py train_bf16_flat 10 > $O/prof_train_bf16.log 2>&1 ); echo "rocprof train bf16 rc=$?"
 python tools/prof_summary.py /tmp/prof_train16 $O/train_bf16_kernel_stats.txt
 bash tools/gpu_traffic.sh "c2 c4step c4step_x3" > $O/traffic.txt 2>&1; echo "traffic rc=$?"; cp gpurun_out/traffic/*.json $O/ 2>/dev/null
 bash tools/gpu_pmc.sh "c4step c4step_x3 c2" > $O/pmc.txt 2>&1; echo "pmc rc=$?"; grep -E "==|giga" $O/pmc.txt | cut -c1-250 | tail -n 45
