@@ -436,6 +436,35 @@ def test_batch_256_c3_scene_consistency(net, dev):
     net.set_precision("fp32")
 
 
+def test_persistent_unet_launches_in_flight_on_several_streams(net, dev):
+    """The persistent U-Net launch places its workgroups by ticket among the workgroups already resident on their XCD, so that
+    several such launches -- each a full device's worth of spinning workgroups -- can be in flight at once without holding each
+    other's CUs in a cycle (csrc/giga_encoder.hip::unet_mega_kernel; the round-2 form needed a one-stream contract).  Four
+    streams enqueue 32-scene and 2-scene encoder calls back to back without any synchronisation in between; every result must
+    equal the same call made alone, and nothing may trap (a group that cannot fill traps after about a second)."""
+    streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    xs = [torch.from_numpy(synth.tsdf_batch(900 + 40 * k, 32 if k % 2 == 0 else 2)).to(dev) for k in range(4)]
+    try:
+        for prec in ("fp16", "fp32"):
+            net.set_precision(prec)
+            net.set_persistent_unet(True)                       # (fp32 at 2 scenes takes the persistent form only when asked)
+            with torch.no_grad():
+                want = [net.encode_inputs(x)["xz"].clone() for x in xs]
+                torch.cuda.synchronize()
+                got = [[] for _ in xs]
+                for rep in range(25):
+                    for k, (st, x) in enumerate(zip(streams, xs)):
+                        with torch.cuda.stream(st):
+                            got[k].append(net.encode_inputs(x)["xz"])
+                torch.cuda.synchronize()
+            for k in range(4):
+                for g in got[k]:
+                    assert torch.equal(g, want[k]), (prec, k)
+    finally:
+        net.set_persistent_unet(False)
+        net.set_precision("fp32")
+
+
 @pytest.mark.parametrize("B", [1, 2, 3, 5, 8, 10, 11, 32])
 def test_persistent_unet_kernel_is_bit_identical_to_per_layer_launches(net, dev, B):
     """The U-Net as ONE persistent launch (unet_mega_kernel: groups of 8 workgroups inside one XCD walk their images through all
