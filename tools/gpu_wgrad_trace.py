@@ -8,6 +8,7 @@ from giga_amd.training import giga_loss
 _capi.LIB_PATH = os.environ["GIGA_DIAG_LIB"]
 dev = torch.device("cuda:0")
 net = networks.get_network("giga"); net.load_state_dict(weights.make_state_dict(7)); net = net.to(dev).train()
+net.set_train_precision(os.environ.get("GIGA_DIAG_TRAIN_PREC", "fp32"))    # bf16: conv3_wgrad_bf16_kernel (same trace slots)
 B, M = 32, 2048
 x = torch.from_numpy(synth.tsdf_batch(0, B)).to(dev); pos = torch.from_numpy(synth.query_points(0, B, 1, stream=2)).to(dev)
 pos_occ = torch.from_numpy(synth.query_points(0, B, M, stream=3)).to(dev)
