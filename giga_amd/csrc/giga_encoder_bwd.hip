@@ -547,24 +547,27 @@ __global__ __launch_bounds__(512) void conv3_wgrad_bf16_kernel(Wgrad3Args a) {
     const int sg = rest % G, sr = rest / G;           // group within the row, strip row
     constexpr int SPI = H / RS;
     const int nstrips = a.nimg * SPI;
+    // All eight loads of a staging item are issued UNCONDITIONALLY from clamped addresses and zeroed when they are stored
+    // (`ok`): behind `if`s every load sat in its own basic block, the register allocator overlapped their destinations and the
+    // compiler put s_waitcnt vmcnt(0) between them -- an item cost two to three dependent memory round trips instead of one
+    // (the strip loop ran at ~6 k clocks per strip, tools/gpu_wgrad_trace.py).
     float4 stg[8];
+    unsigned ok = 0;                                  // bit e: element e of the staged item is inside the image
     auto issue = [&](int st) {
         const int img = st / SPI, y0 = (st % SPI) * RS;
+        const int gy = y0 - 1 + sr, gyc = gy < 0 ? 0 : gy >= H ? H - 1 : gy, c = 4 * cq;
+        // (threads without an item read like a dY item of row 0: always a valid address)
+        const float* rowp = !isx ? a.dY + ((size_t)(img * H + y0 + (isy ? sr : 0)) * W) * COUT + c
+                                 : c < C0 ? a.in0 + ((size_t)(img * H + gyc) * W) * C0 + c
+                                          : a.in1 + ((size_t)(img * H + gyc) * W) * C1 + (c - C0);
+        const int ps = !isx ? COUT : c < C0 ? C0 : C1;
+        const bool row_ok = isy || (isx && gy >= 0 && gy < H);
+        ok = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int x = 8 * sg + e;
-            if (isy) {
-                if (x < W) val = *reinterpret_cast<const float4*>(a.dY + ((size_t)(img * H + y0 + sr) * W + x) * COUT + 4 * cq);
-            } else if (isx) {
-                const int gy = y0 - 1 + sr, c = 4 * cq;
-                if (gy >= 0 && gy < H && x < W) {
-                    const size_t px = (size_t)(img * H + gy) * W + x;
-                    val = c < C0 ? *reinterpret_cast<const float4*>(a.in0 + px * C0 + c)
-                                 : *reinterpret_cast<const float4*>(a.in1 + px * C1 + (c - C0));
-                }
-            }
-            stg[e] = val;
+            const int x = 8 * sg + e, xc = x < W ? x : W - 1;
+            stg[e] = *reinterpret_cast<const float4*>(rowp + (size_t)xc * ps);
+            ok |= (row_ok && x < W) ? 1u << e : 0u;
         }
     };
 
@@ -581,12 +584,13 @@ __global__ __launch_bounds__(512) void conv3_wgrad_bf16_kernel(Wgrad3Args a) {
     if (st < nstrips) issue(st);
     for (; st < nstrips; st += gridDim.x) {
         __syncthreads();                              // everyone is done reading the previous strip (and the zero fill)
+        const unsigned okc = ok;
         if (isx || isy) {
             __bf16* dst = isx ? Xt + ((size_t)(4 * cq) * XR + sr) * PX + 8 + 8 * sg : Yt + ((size_t)(4 * cq) * RS + sr) * PY + 8 * sg;
             const int cstride = isx ? XR * PX : RS * PY;
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {
-                const float v8[8] = {ch == 0 ? stg[0].x : ch == 1 ? stg[0].y : ch == 2 ? stg[0].z : stg[0].w,
+                float v8[8] = {ch == 0 ? stg[0].x : ch == 1 ? stg[0].y : ch == 2 ? stg[0].z : stg[0].w,
                                      ch == 0 ? stg[1].x : ch == 1 ? stg[1].y : ch == 2 ? stg[1].z : stg[1].w,
                                      ch == 0 ? stg[2].x : ch == 1 ? stg[2].y : ch == 2 ? stg[2].z : stg[2].w,
                                      ch == 0 ? stg[3].x : ch == 1 ? stg[3].y : ch == 2 ? stg[3].z : stg[3].w,
@@ -594,6 +598,8 @@ __global__ __launch_bounds__(512) void conv3_wgrad_bf16_kernel(Wgrad3Args a) {
                                      ch == 0 ? stg[5].x : ch == 1 ? stg[5].y : ch == 2 ? stg[5].z : stg[5].w,
                                      ch == 0 ? stg[6].x : ch == 1 ? stg[6].y : ch == 2 ? stg[6].z : stg[6].w,
                                      ch == 0 ? stg[7].x : ch == 1 ? stg[7].y : ch == 2 ? stg[7].z : stg[7].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = (okc >> e & 1u) ? v8[e] : 0.f;
                 wbf8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (__bf16)v8[e];
@@ -667,6 +673,170 @@ __global__ __launch_bounds__(512) void conv3_wgrad_bf16_kernel(Wgrad3Args a) {
     }
 }
 
+// ---- the same weight gradient for layers with at most four 32x32 blocks: the NINE TAPS go to nine waves ----------------------
+// In conv3_wgrad_bf16_kernel a wave owns a block for all nine taps (144 accumulator registers) and the waves of a block split the
+// pixels.  For the layers with one to four blocks (32 -> 32 and 32 + 32 -> 32 at 40x40, 32 -> 64 and 64 -> 64 at 20x20) that leaves
+//   * no registers for a second strip of loads in flight: a strip is ~600 clocks of MFMAs against a ~6 k-clock memory round trip,
+//     one strip deep the loop runs at one strip per round trip (tools/gpu_wgrad_trace.py, profiles/r03/wgrad3_bf16_trace_layer0.txt);
+//   * an epilogue of three LDS rounds in which the 8 waves' tiles are summed (9.6 k of the launch's 44 k clocks).
+// Here wave t takes tap t of EVERY block and every k-chunk of the strip: 16 x NBLK accumulator registers, the same number of
+// MFMAs per wave, no cross-wave sum at all (a wave writes its tiles straight to the partial image), and two strips of loads in
+// flight (ping-pong staging registers).  Workgroup barriers inside the loop are s_barrier after lgkmcnt(0) only: __syncthreads()
+// also waits for vmcnt(0), i.e. for the prefetched loads.  Staging, partial-image layout and reduce kernel are unchanged.
+template <int C0, int C1, int COUT, int H, int RS>
+__global__ __launch_bounds__(576) void conv3_wgrad_bf16_taps_kernel(Wgrad3Args a) {
+    constexpr int W = H, CIN = C0 + C1;
+    constexpr int NBK = CIN / 32, NMB = COUT / 32, NBLK = NMB * NBK;
+    static_assert(NBLK <= 4, "one tap per wave: few blocks");
+    constexpr bool DEEP = NBLK == 1;                  // two strips of loads in flight; with 2-4 blocks (32-64 accumulator registers) the second
+                                                      // staging set no longer fits the 168 registers of a 9-wave workgroup (100-400 B of scratch)
+    constexpr int G = (W + 7) / 8;
+    constexpr int PY = 8 * G, PX = 8 * G + 16;
+    constexpr int XR = RS + 2;
+    constexpr int NVX = (CIN / 4) * XR * G, NVY = (COUT / 4) * RS * G, NV = NVX + NVY;
+    static_assert(NV <= 512, "one staging item per thread");
+    constexpr int XELEMS = CIN * XR * PX;
+    constexpr int NCH = RS * G / 2;
+    static_assert((RS * G) % 2 == 0 && H % RS == 0, "strip geometry");
+    extern __shared__ __attribute__((aligned(16))) float wg_lds[];
+    __bf16* Xt = reinterpret_cast<__bf16*>(wg_lds);
+    __bf16* Yt = Xt + XELEMS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // = tap
+    const int n = lane & 31, hi = lane >> 5;
+    const int ty = wave / 3, tx = wave - 3 * ty;
+
+    for (int v = tid; v < XELEMS / 8; v += 576) reinterpret_cast<uint4*>(Xt)[v] = make_uint4(0, 0, 0, 0);
+
+    const bool isx = tid < NVX, isy = !isx && tid < NV;
+    const int u = isx ? tid : tid - NVX;
+    const int cq = isx ? u % (CIN / 4) : u % (COUT / 4);
+    const int rest = isx ? u / (CIN / 4) : u / (COUT / 4);
+    const int sg = rest % G, sr = rest / G;
+    constexpr int SPI = H / RS;
+    const int nstrips = a.nimg * SPI;
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    float4 stgA[8], stgB[8];
+    unsigned okA = 0, okB = 0;                        // bit e: element e of the staged item is inside the image
+    // (unconditional loads from clamped addresses, zeroed when stored: see conv3_wgrad_bf16_kernel)
+    auto issue = [&](int st, float4 (&stg)[8], unsigned& ok) {
+        const int img = st / SPI, y0 = (st % SPI) * RS;
+        const int gy = y0 - 1 + sr, gyc = gy < 0 ? 0 : gy >= H ? H - 1 : gy, c = 4 * cq;
+        // (threads without an item read like a dY item of row 0: always a valid address)
+        const float* rowp = !isx ? a.dY + ((size_t)(img * H + y0 + (isy ? sr : 0)) * W) * COUT + c
+                                 : c < C0 ? a.in0 + ((size_t)(img * H + gyc) * W) * C0 + c
+                                          : a.in1 + ((size_t)(img * H + gyc) * W) * C1 + (c - C0);
+        const int ps = !isx ? COUT : c < C0 ? C0 : C1;
+        const bool row_ok = isy || (isx && gy >= 0 && gy < H);
+        ok = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int x = 8 * sg + e, xc = x < W ? x : W - 1;
+            stg[e] = *reinterpret_cast<const float4*>(rowp + (size_t)xc * ps);
+            ok |= (row_ok && x < W) ? 1u << e : 0u;
+        }
+    };
+
+    f32x16 acc[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    int st = blockIdx.x;
+    const int gstep = (int)gridDim.x;
+    if (st < nstrips) issue(st, stgA, okA);
+    if (DEEP && st + gstep < nstrips) issue(st + gstep, stgB, okB);
+    __syncthreads();                                  // the zero fill of the X image
+    auto strip = [&](float4 (&stg)[8], unsigned& ok, int st_) {
+        lds_barrier();                                // everyone is done reading the previous strip
+        const unsigned okc = ok;
+        if (isx || isy) {
+            __bf16* dst = isx ? Xt + ((size_t)(4 * cq) * XR + sr) * PX + 8 + 8 * sg : Yt + ((size_t)(4 * cq) * RS + sr) * PY + 8 * sg;
+            const int cstride = isx ? XR * PX : RS * PY;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                float v8[8] = {ch == 0 ? stg[0].x : ch == 1 ? stg[0].y : ch == 2 ? stg[0].z : stg[0].w,
+                                     ch == 0 ? stg[1].x : ch == 1 ? stg[1].y : ch == 2 ? stg[1].z : stg[1].w,
+                                     ch == 0 ? stg[2].x : ch == 1 ? stg[2].y : ch == 2 ? stg[2].z : stg[2].w,
+                                     ch == 0 ? stg[3].x : ch == 1 ? stg[3].y : ch == 2 ? stg[3].z : stg[3].w,
+                                     ch == 0 ? stg[4].x : ch == 1 ? stg[4].y : ch == 2 ? stg[4].z : stg[4].w,
+                                     ch == 0 ? stg[5].x : ch == 1 ? stg[5].y : ch == 2 ? stg[5].z : stg[5].w,
+                                     ch == 0 ? stg[6].x : ch == 1 ? stg[6].y : ch == 2 ? stg[6].z : stg[6].w,
+                                     ch == 0 ? stg[7].x : ch == 1 ? stg[7].y : ch == 2 ? stg[7].z : stg[7].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = (okc >> e & 1u) ? v8[e] : 0.f;
+                wbf8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (__bf16)v8[e];
+                *reinterpret_cast<wbf8*>(dst + (size_t)ch * cstride) = o;
+                if (isy)                              // bias gradient: column sums of dY, from the fp32 values
+                    bsum[ch] += ((v8[0] + v8[1]) + (v8[2] + v8[3])) + ((v8[4] + v8[5]) + (v8[6] + v8[7]));
+            }
+        }
+        if (st_ + (DEEP ? 2 : 1) * gstep < nstrips) issue(st_ + (DEEP ? 2 : 1) * gstep, stg, ok);   // into the registers just drained
+        lds_barrier();
+#pragma unroll 2
+        for (int j = 0; j < NCH; ++j) {
+            const int gi = 2 * j + hi, r = gi / G, xg = gi % G;
+            wbf8 A[NMB], B[NBK];
+#pragma unroll
+            for (int m = 0; m < NMB; ++m) A[m] = *reinterpret_cast<const wbf8*>(Yt + (size_t)(m * 32 + n) * RS * PY + r * PY + 8 * xg);
+#pragma unroll
+            for (int k = 0; k < NBK; ++k) {
+                const __bf16* row = Xt + (size_t)(k * 32 + n) * XR * PX + 8 + (r + ty) * PX + 8 * xg;   // X row y + ty - 1, col of the group's x0
+                const uint4 mid = *reinterpret_cast<const uint4*>(row);
+                uint4 sel = mid;
+                if (tx == 0) {
+                    const unsigned wp = *reinterpret_cast<const unsigned*>(row - 2);                  // elements x0-2, x0-1
+                    sel = uint4{__builtin_amdgcn_alignbyte(mid.x, wp, 2), __builtin_amdgcn_alignbyte(mid.y, mid.x, 2),
+                                __builtin_amdgcn_alignbyte(mid.z, mid.y, 2), __builtin_amdgcn_alignbyte(mid.w, mid.z, 2)};
+                } else if (tx == 2) {
+                    const unsigned wn = *reinterpret_cast<const unsigned*>(row + 8);                  // elements x0+8, x0+9
+                    sel = uint4{__builtin_amdgcn_alignbyte(mid.y, mid.x, 2), __builtin_amdgcn_alignbyte(mid.z, mid.y, 2),
+                                __builtin_amdgcn_alignbyte(mid.w, mid.z, 2), __builtin_amdgcn_alignbyte(wn, mid.w, 2)};
+                }
+                B[k] = __builtin_bit_cast(wbf8, sel);
+            }
+#pragma unroll
+            for (int m = 0; m < NMB; ++m)
+#pragma unroll
+                for (int k = 0; k < NBK; ++k)
+                    acc[m * NBK + k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m], B[k], acc[m * NBK + k], 0, 0, 0);
+        }
+    };
+    if constexpr (DEEP) {
+        for (;;) {
+            if (st >= nstrips) break;
+            strip(stgA, okA, st); st += gstep;
+            if (st >= nstrips) break;
+            strip(stgB, okB, st); st += gstep;
+        }
+    } else {
+        for (; st < nstrips; st += gstep) strip(stgA, okA, st);
+    }
+    // ---- epilogue: every wave writes its tap's tiles (D layout: lane (n, hi), register r <-> row (r&3) + 8(r>>2) + 4hi) ------------
+    constexpr int RN = 9 * 1024;
+    float* part = a.partial + (size_t)blockIdx.x * NBLK * RN;
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            part[((size_t)(b * 9 + wave) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + n] = acc[b][r];
+    // per-channel totals of dY: threads of the dY items hold 4 channels each for their (row, group)
+    __syncthreads();
+    float* red = wg_lds;
+    for (int c = tid; c < COUT; c += 576) red[c] = 0.f;
+    __syncthreads();
+    if (isy) {
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) atomicAdd(red + 4 * cq + ch, bsum[ch]);      // LDS, <= RS*G addends per channel
+    }
+    __syncthreads();
+    if (tid < COUT) a.partial[(size_t)gridDim.x * NBLK * RN + (size_t)blockIdx.x * COUT + tid] = red[tid];
+}
+
 template <int C0, int C1, int COUT, int H, int RS>
 static int launch_wgrad3_bf16(const Wgrad3Args& a, hipStream_t s) {
     constexpr int CIN = C0 + C1, W = H;
@@ -678,6 +848,17 @@ static int launch_wgrad3_bf16(const Wgrad3Args& a, hipStream_t s) {
     const int nstrips = a.nimg * (H / RS);
     int gx = 256 / NY;
     if (gx > nstrips) gx = nstrips;
+    if constexpr (NBLK <= 4) {                        // one tap per wave (conv3_wgrad_bf16_taps_kernel)
+        static const bool taps = [] { const char* e = getenv("GIGA_WGRAD_TAPS"); return !e || atoi(e) != 0; }();
+        if (taps) {
+            auto kern = conv3_wgrad_bf16_taps_kernel<C0, C1, COUT, H, RS>;
+            giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)strip);
+            GIGA_LAUNCH(kern, dim3(gx), dim3(576), strip, s, a);
+            GIGA_LAUNCH((wgrad3_reduce_kernel<CIN, BPG>), dim3(9 * 1024 / 64 + 1, NBLK), dim3(256), 0, s, a.partial, gx,
+                               a.dW, a.db, COUT, NY);
+            return hipGetLastError() == hipSuccess ? 0 : -10;
+        }
+    }
     auto kern = conv3_wgrad_bf16_kernel<C0, C1, COUT, H, RS>;
     giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
     GIGA_LAUNCH(kern, dim3(gx, NY), dim3(512), lds, s, a);
