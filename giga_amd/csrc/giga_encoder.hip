@@ -490,7 +490,7 @@ __device__ __forceinline__ void xcd_barrier(unsigned* counter, unsigned target, 
         unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {   // an L2 read
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 24)) __builtin_trap();       // ~1 s: fail loudly, never hang the device
+            if (++spins > (1u << 24)) __builtin_trap();       // a few seconds (an L2 round trip + s_sleep per spin): fail loudly, never hang the device
         }
     }
     __syncthreads();
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(MEGA_NW * 64) void unet_mega_kernel(MegaArgs m) {
     //     workgroups that share a counter share an L2 -- true by construction here, whatever order the dispatcher uses.  (Rounds
     //     2-3a assumed "workgroup i runs on XCD i % 8" and checked it; the dispatcher's round-robin pointer carries over from the
     //     previous launch, so even that map is rotated after a grid that is not a multiple of 8.)  What is still assumed is that
-    //     every XCD receives gridDim / 8 workgroups: a group that never fills traps after ~1 s instead of returning stale data.
+    //     every XCD receives gridDim / 8 workgroups: a group that never fills traps after a few seconds instead of returning stale data.
     //   * The members of a group are the first eight workgroups of the launch that became RESIDENT on their XCD, so a launch has
     //     at most one unfilled group per XCD, and filled groups depend on nobody: several of these launches in flight at once
     //     (other streams, other processes) cannot hold each other's CUs in a cycle -- which is what made the blockIdx-based form

@@ -123,7 +123,7 @@ int giga_decoder_forward(const void* planes_nhwc, const float* p, const void* pa
  * planner of detection_implicit.py:99-113 runs one scene at a time), 130 instead of 150 us at 32 scenes, 361 instead of 378 in
  * precision 0.  The workgroups of a group find each other by ticket among the workgroups already resident on their XCD, so
  * several such launches may be in flight on one device (other streams, other processes) without waiting on each other's CUs;
- * a group that cannot fill (an XCD that is handed fewer workgroups than the others) traps after about a second instead of
+ * a group that cannot fill (an XCD that is handed fewer workgroups than the others) traps after a few seconds instead of
  * returning stale data.
  *   GIGA_LAYERWISE_UNET, OR-ed into `precision` of giga_encoder_forward*: one launch per layer (A/B comparisons; the environment
  *   variable GIGA_UNET_PERSIST=0 does the same for a whole process).
