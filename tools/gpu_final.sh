@@ -8,6 +8,9 @@ timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o b -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/prof_bench.log 2>&1 ); echo "rocprof bench rc=$?"
 python tools/prof_summary.py /tmp/prof_bench $O/bench_kernel_stats.txt
+# the same command without the extra legs: the dominant launch's rocprofv3 average in the SAME context as bench.py's HIP events
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_core -o b -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $O/prof_bench_core.log 2>&1 ); echo "rocprof bench core rc=$?"
+python tools/prof_summary.py /tmp/prof_core $O/bench_core_kernel_stats.txt
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_train -o t -- python $R/tools/gpu_prof.py train_flat 10 > $O/prof_train.log 2>&1 ); echo "rocprof train rc=$?"
 python tools/prof_summary.py /tmp/prof_train $O/train_kernel_stats.txt
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_train16 -o t -- python $R/tools/gpu_prof.py train_bf16_flat 10 > $O/prof_train_bf16.log 2>&1 ); echo "rocprof train bf16 rc=$?"
