@@ -472,8 +472,9 @@ def test_persistent_unet_kernel_is_bit_identical_to_per_layer_launches(net, dev,
     launches: planes and head outputs are bit-identical in the f16-class modes.  In fp32 the units of a layer's ragged last
     round are summed in parts (conv16_run's tail split: ((p0 + p1) + p2) + p3 instead of one chain), and which units those are
     depends on how many images a weight group walks, so fp32 agrees to rounding only.
-    Three launch forms: "layers" (GIGA_LAYERWISE_UNET), the default (persistent up to 10 scenes in the f16-class modes) and the
-    forced persistent launch for every batch size and precision (GIGA_PERSIST_UNET).  Batches of 1-10 scenes put one image or none on a group; 11 and 32 scenes several, unevenly."""
+    Three launch forms: "layers" (GIGA_LAYERWISE_UNET), the default (persistent for every batch size in the f16-class modes,
+    from 8 scenes up in fp32) and the forced persistent launch (GIGA_PERSIST_UNET).  Batches of 1-10 scenes put one image or
+    none on a group; 11 and 32 scenes several, unevenly."""
     x = torch.from_numpy(synth.tsdf_batch(500, B)).to(dev)
     p = torch.from_numpy(synth.query_points(500, B, 64, stream=9)).to(dev)
     try:
