@@ -26,6 +26,26 @@ def test_library_exports_every_declared_symbol():
     assert lib.giga_strerror(0) == b"ok" and lib.giga_strerror(-4) == b"workspace too small"
 
 
+def test_python_constants_equal_the_header_defines():
+    """giga_amd._capi repeats the flag values of include/giga_hip.h; pin them to the header (a drifted flag bit would select
+    another launch form or arithmetic mode silently), and check that the library masks every flag before validating."""
+    hdr = open(os.path.join(ROOT, "include", "giga_hip.h")).read()
+    defines = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"^#define\s+(GIGA_[A-Z0-9_]+)\s+(0x[0-9a-fA-F]+|\d+)\s*$", hdr, re.M)}
+    for name, value in (("GIGA_FOLD_FINAL", _capi.FOLD_FINAL), ("GIGA_PERSIST_UNET", _capi.PERSIST_UNET),
+                        ("GIGA_LAYERWISE_UNET", _capi.LAYERWISE_UNET), ("GIGA_MAX_SCENES", _capi.MAX_SCENES)):
+        assert defines.get(name) == value, (name, defines.get(name), value)
+    flags = _capi.FOLD_FINAL | _capi.PERSIST_UNET | _capi.LAYERWISE_UNET
+    assert flags & 3 == 0 and bin(flags).count("1") == 3          # distinct bits above the precision values 0..3
+    lib = _capi.lib()
+    for f in (_capi.PERSIST_UNET, _capi.LAYERWISE_UNET, flags):
+        assert lib.giga_encoder_workspace_bytes(4, 1 | f) == lib.giga_encoder_workspace_bytes(4, 1)
+        assert lib.giga_encoder_forward(None, None, None, None, 0, f, None, 0, None) == 0          # empty batch
+    # the launch form of the U-Net is a per-call choice of the module: False (default), True (forced persistent), "layers"
+    net = networks.get_network("giga")
+    for mode in (True, "layers", False):
+        assert net.set_persistent_unet(mode) is net and net.encoder.persistent_unet == mode
+
+
 def test_param_counts_and_sizes():
     lib = _capi.lib()
     assert lib.giga_param_count(15) == 581863          # SURVEY 8a
