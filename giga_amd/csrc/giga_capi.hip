@@ -23,7 +23,7 @@ size_t dec_bwd_scratch_floats(long long P, int nheads);
 bool dec_bwd_writes_planes(int nheads, int B, int N);
 int launch_decoder_backward(const float* planes, const float* p, const uint8_t* blob, const uint8_t* bwd_blob,
                             int head_mask, const float* const* outs, const float* const* douts, float* gplanes,
-                            float* grads, int head_present, float* scratch, int B, int N, hipStream_t s);
+                            float* grads, int head_present, float* scratch, int B, int N, hipStream_t s, bool writes_planes);
 // giga_loss.hip
 int launch_train_loss(const float* qual, const float* rot, const float* width, const float* occ, const float* label,
                       const float* rot_t, const float* width_t, const float* occ_t, int B, int M, float* losses,
@@ -358,12 +358,12 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
     int rc = 0;
     if (occ_runs) {
         rc |= launch_decoder_backward(static_cast<const float*>(planes_nhwc), p_tsdf, blob, bblob, 8, outs, douts,
-                                      detach_occ ? nullptr : gplanes, grads, head_present, scratch, B, M, s);
+                                      detach_occ ? nullptr : gplanes, grads, head_present, scratch, B, M, s, occ_writes);
     }
     if ((head_present & 7) && N > 0) {
         if (!p) return -1;
         rc |= launch_decoder_backward(static_cast<const float*>(planes_nhwc), p, blob, bblob, head_present & 7, outs,
-                                      douts, gplanes, grads, head_present, scratch, B, N, s);
+                                      douts, gplanes, grads, head_present, scratch, B, N, s, false);
     }
     rc |= launch_encoder_backward(tsdf, blob, bblob, static_cast<const uint8_t*>(enc_workspace_fwd), gplanes, gws,
                                   grads, head_present, B, s, bf16_convs);

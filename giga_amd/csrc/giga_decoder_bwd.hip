@@ -524,7 +524,9 @@ bool dec_bwd_writes_planes(int nheads, int B, int N) { return nheads == 1 && N >
 
 int launch_decoder_backward(const float* planes, const float* p, const uint8_t* blob, const uint8_t* bwd_blob,
                             int head_mask, const float* const* outs, const float* const* douts, float* gplanes,
-                            float* grads, int head_present, float* scratch, int B, int N, hipStream_t s) {
+                            float* grads, int head_present, float* scratch, int B, int N, hipStream_t s, bool writes_planes) {
+    // writes_planes: this call's plane gradient is built by plane_gather_kernel and WRITTEN into `gplanes` (the caller runs it before
+    // the calls that add with atomics and has checked dec_bwd_writes_planes); otherwise it is added to what `gplanes` holds
     const long long P = (long long)B * N;
     if (P <= 0 || (head_mask & 15) == 0) return 0;
     const PackOff ko = pack_offsets();
@@ -542,7 +544,7 @@ int launch_decoder_backward(const float* planes, const float* p, const uint8_t* 
         ++a.nheads;
     }
     a.Cbuf = sc; a.Pbuf = sc + (size_t)P * 96;
-    a.dcbuf = gplanes && dec_bwd_writes_planes(a.nheads, B, N) ? a.Pbuf + (size_t)P * 32 : nullptr;
+    a.dcbuf = gplanes && writes_planes && dec_bwd_writes_planes(a.nheads, B, N) ? a.Pbuf + (size_t)P * 32 : nullptr;
     const long long tiles = (P + 31) / 32;
     a.nbatch = (int)((tiles + 3) / 4);
     const int grid = a.nbatch < 256 ? a.nbatch : 256;
