@@ -263,6 +263,8 @@ def main():
         L.giga_event_destroy(a); L.giga_event_destroy(b)
     named_ms = named_ms or dom_ms
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(K)]
+    if os.environ.get("GIGA_BENCH_DUMP_STEPS"):            # diagnosis: which of the K steps are the slow ones
+        print("step_ms", " ".join(f"{v:.4f}" for v in step_ms), "| wall", f"{elapsed_s * 1e3:.4f}", "ms", file=sys.stderr)
     t_elapsed = torch.tensor([elapsed_s], dtype=torch.float64, device=dev)
     rccl = None
     multi = {}
