@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from giga_amd import _capi, networks, synth, weights  # noqa: E402
 from giga_amd.convonet import decode_heads  # noqa: E402
