@@ -11,6 +11,7 @@
 #include "../../include/giga_hip.h"
 #include "giga_dev.h"
 #include "giga_conv16.h"
+#include "giga_conv32.h"
 #include "giga_args.h"
 
 namespace giga {
@@ -588,6 +589,70 @@ __global__ __launch_bounds__(MEGA_NW * 64) void unet_mega_kernel(MegaArgs m) {
 #undef X
 }
 
+// ----------------------------------------------------------------------------------------------------
+// The f16-class U-Net on conv32 (giga_conv32.h): the same persistent launch -- groups of 8 workgroups placed by ticket inside one
+// XCD, a barrier among those 8 per layer -- but a member of a group owns an eighth of the ROWS of the group's stacked images
+// (all output channels), keeps its sub-band of the layer's input resident in LDS and its weights in registers.  4 waves of up to
+// 512 VGPRs.  The layer table (GIGA_UNET32_LAYERS) lives in giga_conv32_geom.h.
+// ----------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(C32_NW * 64) void unet32_mega_kernel(MegaArgs m) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // placement by ticket: see unet_mega_kernel
+    __shared__ unsigned s_place[2];
+    if (threadIdx.x == 0) {
+        const unsigned xcc = (unsigned)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7);     // HW_REG_XCC_ID[3:0]
+        s_place[0] = xcc;
+        s_place[1] = __hip_atomic_fetch_add(m.sync + xcc * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    const int xcd = (int)s_place[0], ticket = (int)s_place[1];
+    const int nq = (int)gridDim.x >> 3, slot = ticket / MEGA_GROUP, q = slot * 8 + xcd, nimg = m.layer[0].nimg;
+    if (slot >= nq >> 3) return;
+    int img0, per;
+    c32_group_images(q, nq, nimg, img0, per);
+    if (per == 0) return;                                                   // (before any barrier)
+    const int block = ticket - slot * MEGA_GROUP;                           // this workgroup's place inside its group
+    unsigned* counter = m.sync + (8 + q) * 32;
+    unsigned epoch = 0;
+    // FIRST(l): weights of layer l, no barrier.  NEXT(l): request layer l's weights (they land while the barrier is waited for),
+    // then the group barrier.  RUN(l): stage / MFMA / store; then every wave's stores are acknowledged by the L2 and every wave
+    // has left the LDS image.
+#define FIRST(l)                                                                                                   \
+    using G##l = typename U32Layer<MODE, l>::G;                                                                    \
+    C32W<G##l> w##l;                                                                                               \
+    c32_load_weights<G##l>(m.layer[l], w##l, 0);
+#define NEXT(l)                                                                                                    \
+    using G##l = typename U32Layer<MODE, l>::G;                                                                    \
+    C32W<G##l> w##l;                                                                                               \
+    if (l < m.nlayers) {                                                                                           \
+        c32_load_weights<G##l>(m.layer[l], w##l, 0);                                                               \
+        xcd_barrier(counter, ++epoch * (unsigned)MEGA_GROUP, l, img0 == 0 ? block : -1);                           \
+    }
+#define RUN(l)                                                                                                     \
+    if (l < m.nlayers) {                                                                                           \
+        c32_run<G##l, U32Layer<MODE, l>::RELU>(c32_image_range<G##l>(m.layer[l], img0, per), smem, block, w##l);   \
+        __builtin_amdgcn_s_waitcnt(0x0F70);            /* vmcnt(0): this wave's output stores are in the L2 */      \
+        __syncthreads();                                                                                           \
+    }
+    FIRST(0) RUN(0)
+    NEXT(1) RUN(1)
+    NEXT(2) RUN(2)
+    NEXT(3) RUN(3)
+    NEXT(4) RUN(4)
+    NEXT(5) RUN(5)
+    NEXT(6) RUN(6)
+    NEXT(7) RUN(7)
+    NEXT(8) RUN(8)
+    NEXT(9) RUN(9)
+    NEXT(10) RUN(10)
+    NEXT(11) RUN(11)
+    NEXT(12) RUN(12)
+#undef FIRST
+#undef NEXT
+#undef RUN
+}
+
 // probe: if probe_stage == k, ev0/ev1 (hipEvent_t) are recorded right before / after launch k
 // (k = 0 conv_in+project, 1 plane_finalize, 2..14 = U-Net layers 0..12).
 struct Probe { int stage; hipEvent_t ev0, ev1; };
@@ -682,6 +747,40 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     const bool by_default = F16CLASS || nimg >= 24;
     const bool mega = full_device && !probe_layer &&
                       (persist > 0 || (persist == 0 && (env_persist > 0 || (env_persist < 0 && by_default))));
+    // conv32 (giga_conv32.h): the f16-class modes.  GIGA_CONV32=0 keeps conv16 (A/B runs).
+    constexpr int C32MODE = sizeof(T) == 2 ? C32_NATIVE : -1;
+    static const int env_c32 = [] { const char* e = getenv("GIGA_CONV32"); return e ? atoi(e) : 1; }();
+    if constexpr (C32MODE >= 0) {
+        if (env_c32) {
+            auto W32 = [&](int l) { return blob + ko.conv[l].c32h; };
+            ConvArgs M[NCONV];
+            for (int l = 0; l < NCONV; ++l) { M[l] = L[l]; M[l].w = W32(l); M[l].xcd_local = 0; M[l].out_pool = nullptr; }
+            M[2].in0 = b + w.S0; M[2].out_pool = b + w.Q0;      // layers 2 and 4 pool their input while staging it
+            M[4].in0 = b + w.S1; M[4].out_pool = b + w.Q1;
+            if (mega) {
+                MegaArgs m{};
+                for (int l = 0; l < NCONV; ++l) m.layer[l] = M[l];
+                m.sync = reinterpret_cast<unsigned*>(b + w.SYNC);
+                m.nlayers = nlayers;
+                const unsigned grid = (unsigned)c32_groups(nimg) * MEGA_GROUP;
+                auto kern = unet32_mega_kernel<C32MODE>;
+                giga::dyn_lds_once(reinterpret_cast<const void*>(kern), C32_LDS);
+                stage_no = 15;
+                pre();
+                GIGA_LAUNCH(kern, dim3(grid), dim3(C32_NW * 64), C32_LDS, s, m);
+                post();
+                return hipGetLastError() == hipSuccess ? 0 : -10;
+            }
+            if (pr.stage == 15) (void)hipEventRecord(pr.ev0, s);
+#define X(l, KIND, C0, C1, COUT, H, W, POOLIN, SN, SS)                                                                      \
+            if (l < nlayers) { pre(); rc |= launch_conv32<typename U32Layer<C32MODE, l>::G, U32Layer<C32MODE, l>::RELU>(M[l], s); post(); } \
+            else { pre(); post(); }
+            GIGA_UNET32_LAYERS(X)
+#undef X
+            if (pr.stage == 15) (void)hipEventRecord(pr.ev1, s);
+            return rc;
+        }
+    }
     if (mega) {
         MegaArgs m{};
         for (int l = 0; l < NCONV; ++l) { m.layer[l] = L[l]; m.layer[l].xcd_local = 0; }   // (the kernel hands every group its images itself)

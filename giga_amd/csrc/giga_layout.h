@@ -117,7 +117,9 @@ constexpr size_t DEC16S_BYTES = (DEC16S_FRAGS + 1) * FRAG;                // 111
 constexpr int DEC32_FRAGS = NBLK * (12 + 1 + 4 + 4) + 1 + 4;              // 110
 constexpr size_t DEC32_BYTES = (DEC32_FRAGS + 1) * FRAG;                  // 111 KiB: fragments + C table chunk (LDS-DMA image)
 
-struct ConvPackOff { size_t w16, w32, bias, w16s, wbf; int nfrag16, nfrag32; };   // wbf: bf16 fragments (f16 fragment layout), derived from w32   // w16s: f16x3 split [hi, lo] fragment pairs (2 * nfrag16)
+// w16s: f16x3 split [hi, lo] fragment pairs (2 * nfrag16); wbf: bf16 fragments (f16 fragment layout), derived from w32;
+// c32h / c32s / c32b: conv32 images (giga_conv32_geom.h) in f16, f16x3 [hi, lo] pairs (2 * nfragc32) and bf16
+struct ConvPackOff { size_t w16, w32, bias, w16s, wbf; int nfrag16, nfrag32; size_t c32h, c32s, c32b; int nfragc32; };
 struct PackOff {
     size_t convin_w;        // fp32 [2][7][64]  B operands (channel half, K-step of 4 taps; tap 27 = 0)
     size_t convin_b;        // fp32 [32]
@@ -161,6 +163,14 @@ inline PackOff pack_offsets() {
     for (int l = 0; l < NCONV; ++l) { o.conv[l].w16s = at; at += (size_t)2 * o.conv[l].nfrag16 * FRAG; }
     o.convin_ws = at; at += 4 * FRAG;
     for (int l = 0; l < NCONV; ++l) { o.conv[l].wbf = at; at += (size_t)o.conv[l].nfrag16 * FRAG; }
+    // conv32 (round 4): 32x32x16 A-operand fragments, [slice = sub * (cout / 32) + cs][tap][k-chunk of 16 input channels]
+    for (int l = 0; l < NCONV; ++l) {
+        const ConvLayerDesc& d = kConv[l];
+        o.conv[l].nfragc32 = conv_nsub(d) * (d.cout / 32) * conv_taps(d) * ((d.cin0 + d.cin1) / 16);
+        o.conv[l].c32h = at; at += (size_t)o.conv[l].nfragc32 * FRAG;
+        o.conv[l].c32s = at; at += (size_t)2 * o.conv[l].nfragc32 * FRAG;
+        o.conv[l].c32b = at; at += (size_t)o.conv[l].nfragc32 * FRAG;
+    }
     o.total = at;
     return o;
 }

@@ -7,6 +7,7 @@
 //    and B images agree, which is what lets a layer's D registers feed the next layer's B operand
 //    without any cross-lane movement.
 #include "giga_layout.h"
+#include "giga_conv32_geom.h"
 
 #include <cmath>
 #include <cstring>
@@ -233,6 +234,29 @@ static void pack_conv(const float* P, const ParamOff& po, const PackOff& ko, int
             }
     float* bias = reinterpret_cast<float*>(blob + ko.conv[l].bias);
     for (int c = 0; c < d.cout; ++c) bias[c] = P[po.conv_b[l] + c];
+    // conv32 images (giga_conv32_geom.h): A operand of v_mfma_f32_32x32x16_{f16,bf16}, lane (i = lane&31 -> row, hi = lane>>5),
+    // 8 halfs e -> W[co = 32 cs + c32_row_cout(i)][ci = 16 kc + 8 hi + e][tap]; fragment order [sub][cs][tap][kc]
+    half_t* c32h = reinterpret_cast<half_t*>(blob + ko.conv[l].c32h);
+    half_t* c32s = reinterpret_cast<half_t*>(blob + ko.conv[l].c32s);     // pair (2 f, 2 f + 1) = (hi, lo)
+    uint16_t* c32b = reinterpret_cast<uint16_t*>(blob + ko.conv[l].c32b);
+    size_t f = 0;
+    for (int sub = 0; sub < nsub; ++sub)
+        for (int cs = 0; cs < d.cout / 32; ++cs)
+            for (int tap = 0; tap < taps; ++tap) {
+                const int wtap = d.kind == UPCONV ? sub : tap;
+                for (int kc = 0; kc < cin / 16; ++kc, ++f)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int i = lane & 31, hi = lane >> 5;
+                        for (int e = 0; e < 8; ++e) {
+                            const float w = conv_w_at(W, d, 32 * cs + c32_row_cout(i), 16 * kc + 8 * hi + e, wtap);
+                            const half_t h = f2h(w);
+                            c32h[f * 512 + lane * 8 + e] = h;
+                            c32s[(2 * f) * 512 + lane * 8 + e] = h;
+                            c32s[(2 * f + 1) * 512 + lane * 8 + e] = f2h(w - (float)h);
+                            c32b[f * 512 + lane * 8 + e] = f2bf(w);
+                        }
+                    }
+            }
 }
 
 size_t packed_bytes() { return pack_offsets().total; }

@@ -44,6 +44,8 @@ def _blob_and_offsets(sd):
     for _ in range(4):
         dec16s.append(at); at += 2 * up(111 * 1024)
     at += tail
+    # conv32 images (round 4): f16 + f16x3 [hi, lo] pairs + bf16 = 4 fragments per (32-channel slice, tap, 16-channel chunk)
+    at += sum(4 * (co // 32 * (4 if kind == 1 else 1)) * (9 if kind == 0 else 1) * ((c0 + c1) // 16) * 1024 for kind, c0, c1, co in conv)
     assert at == blob.size
     _blob_and_offsets.dec16s = dec16s
     return blob, dec16, dec32

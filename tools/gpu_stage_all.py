@@ -1,5 +1,6 @@
 """HIP-event time of EVERY encoder stage for each precision (median of 9).   PYTHONPATH=. python tools/gpu_stage_all.py [B ...]"""
 import ctypes
+import os
 import sys
 
 import numpy as np
@@ -19,7 +20,8 @@ ms = ctypes.c_float()
 for B in [int(a) for a in sys.argv[1:]] or [32, 1]:
     x = torch.from_numpy(synth.tsdf_batch(0, B)).to(dev)
     rows = {}
-    for prec in ("fp32", "fp16", "fp16x3"):
+    PRECS = os.environ.get("GIGA_PRECS", "fp32,fp16,fp16x3").split(",")
+    for prec in PRECS:
         blob = net.packed_blob(dev)
         with torch.no_grad():
             for _ in range(3):
@@ -38,8 +40,8 @@ for B in [int(a) for a in sys.argv[1:]] or [32, 1]:
                 e0.record(); net.encoder.encode_nhwc(x, blob=blob, precision=prec); e1.record(); torch.cuda.synchronize()
                 tot.append(e0.elapsed_time(e1) * 1e3)
         rows[prec] = (ts, float(np.median(tot)))
-    print(f"B={B}: stage us      fp32     fp16   fp16x3")
+    print(f"B={B}: stage us    " + "".join(f"{p:>9s}" for p in PRECS))
     for i, n in enumerate(NAMES):
-        print(f"  {n:20s} {rows['fp32'][0][i]:8.1f} {rows['fp16'][0][i]:8.1f} {rows['fp16x3'][0][i]:8.1f}")
-    print(f"  {'sum of stages':20s} {sum(rows['fp32'][0]):8.1f} {sum(rows['fp16'][0]):8.1f} {sum(rows['fp16x3'][0]):8.1f}")
-    print(f"  {'whole encoder':20s} {rows['fp32'][1]:8.1f} {rows['fp16'][1]:8.1f} {rows['fp16x3'][1]:8.1f}")
+        print(f"  {n:20s}" + "".join(f" {rows[p][0][i]:8.1f}" for p in PRECS))
+    print(f"  {'sum of stages':20s}" + "".join(f" {sum(rows[p][0]):8.1f}" for p in PRECS))
+    print(f"  {'whole encoder':20s}" + "".join(f" {rows[p][1]:8.1f}" for p in PRECS))

@@ -1,6 +1,7 @@
 """Small-batch U-Net: per-layer launches against the per-image persistent launch (GIGA_LAYERWISE_UNET / default), whole encoder
 and whole network call on the inference lattice, with an equality check of the planes.
     PYTHONPATH=. python tools/gpu_unet_small.py [B ...]"""
+import os
 import sys
 
 import numpy as np
@@ -30,7 +31,7 @@ def timed(fn, n=30):
 
 for B in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8, 10]:
     x = torch.from_numpy(synth.tsdf_batch(0, B)).to(dev)
-    for prec in ("fp16", "fp16x3", "fp32"):
+    for prec in os.environ.get("GIGA_PRECS", "fp16,fp16x3,fp32").split(","):
         net.set_precision(prec)
         blob = net.packed_blob(dev)
         row, planes = {}, {}
