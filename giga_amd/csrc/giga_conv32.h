@@ -23,6 +23,14 @@ __device__ __forceinline__ f32x16 mfma16_bf(bf16x8v a, bf16x8v b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+#ifdef GIGA_TRACE   // diagnostic build: s_memtime stamps of member 0 of the group that holds image 0, per layer and wave
+static __device__ long long g_c32_trace[NCONV][C32_NW][8];
+#define C32_T(a, idx) do { if ((a).trace_id >= 0 && member == 0 && (threadIdx.x & 63) == 0) \
+        g_c32_trace[(a).trace_id][threadIdx.x >> 6][idx] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define C32_T(a, idx) do {} while (0)
+#endif
+
 template <class G>
 struct C32W { uint4 v[G::SPW][G::TAPS * G::KCP][G::NOP]; };
 
@@ -47,70 +55,88 @@ __device__ __forceinline__ void c32_load_weights(const ConvArgs& a, C32W<G>& w, 
 }
 
 // ---- staging: the haloed sub-band [sb - HALO, sb + R + HALO) x P pixels -> LDS ------------------------------------------------
+// All of a thread's loads (up to U items) are in flight before the first LDS write; the zero pixels are written under their
+// latency.  Thread t takes items t, t + 256, ... of the sub-band's real rows (giga_conv32_geom.h: Cur).
 template <class G>
 __device__ __forceinline__ void c32_stage(const ConvArgs& a, uint8_t* smem, int sb, int R) {
     constexpr int MODE = G::MODE, ES = G::ES;
     constexpr int NPOS = G::POOLIN ? 4 : 1;                  // source pixels per staged pixel
     constexpr int VPI = MODE == C32_NATIVE ? 1 : 2;          // 16-byte source vectors per item (8 channels)
-    constexpr int U = G::POOLIN ? 2 : 4;                     // items per thread in flight
-    const int tid = threadIdx.x, nitems = G::n_items(R), Gimg = a.nimg;
+    constexpr int U = (MODE == C32_NATIVE ? 24 : 12) / NPOS; // items per thread in flight
+    const int tid = threadIdx.x, Gimg = a.nimg;
+    int rrA, rrB;
+    G::real_rows(sb, R, Gimg, rrA, rrB);
+    const int nA = (rrB - rrA) * G::RI;
     const char* in0 = reinterpret_cast<const char*>(a.in0);
     const char* in1 = reinterpret_cast<const char*>(a.in1);
-    for (int i0 = tid; i0 < nitems; i0 += C32_NW * 64 * U) {
+    typename G::Cur k = G::cur_init(rrA, tid);
+    bool first_chunk = true;
+    for (int j0 = tid;; j0 += G::NTHR * U) {
         uint4 v[U][NPOS][VPI];
-        typename G::Item it[U];
-        bool ok[U];
+        int lds[U];
+        uint32_t qoff[U];
+        bool ok[U], own[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = i0 + C32_NW * 64 * u;
-            ok[u] = i < nitems;
-            it[u] = G::item(ok[u] ? i : 0, sb, R, Gimg);
-            const bool ld = ok[u] && it[u].inside;
-            const bool first = G::C1 == 0 || it[u].ch < G::C0;
+            ok[u] = j0 + G::NTHR * u < nA;
+            lds[u] = G::cur_lds(k, sb);
+            const int ch0 = G::cur_ch(k);
+            const bool first = G::C1 == 0 || ch0 < G::C0;
             const char* src = first ? in0 : in1;
-            const int C = first ? G::C0 : G::C1, ch = first ? it[u].ch : it[u].ch - G::C0;
+            const uint32_t C = first ? G::C0 : G::C1, ch = first ? ch0 : ch0 - G::C0;
 #pragma unroll
             for (int q = 0; q < NPOS; ++q) {
-                const int yy = G::POOLIN ? 2 * it[u].y + (q >> 1) : it[u].y, xx = G::POOLIN ? 2 * it[u].x + (q & 1) : it[u].x;
-                const uint32_t pix = (uint32_t)((it[u].g * G::IH + yy) * G::IW + xx);
-                const uint32_t off = ld ? (pix * (uint32_t)C + (uint32_t)ch) * (uint32_t)ES : 0u;     // (clamped: every load is issued)
+                const uint32_t off = ok[u] ? ((uint32_t)G::cur_src_pixel(k, q) * C + ch) * (uint32_t)ES : 0u;   // (clamped: every load is issued)
 #pragma unroll
-                for (int k = 0; k < VPI; ++k) v[u][q][k] = *reinterpret_cast<const uint4*>(src + off + 16 * k);
+                for (int e = 0; e < VPI; ++e) v[u][q][e] = *reinterpret_cast<const uint4*>(src + off + 16 * e);
+            }
+            if constexpr (G::POOLIN) {
+                own[u] = ok[u] && G::cur_own(k, sb, R);
+                qoff[u] = ((uint32_t)(k.rr * G::W + G::cur_x(k)) * G::C0 + ch0) * (uint32_t)ES;
+            }
+            G::cur_next(k);
+        }
+        if (first_chunk) {                                   // zero rows / zero columns, under the latency of the loads
+            first_chunk = false;
+            if constexpr (G::HALO) {
+                const int nq = G::n_buf_pixels(R);
+                for (int q = tid; q < nq; q += G::NTHR)
+                    if (G::pad_pixel(q, sb, Gimg)) {
+#pragma unroll
+                        for (int e = 0; e < G::IPP * G::ILB / 16; ++e)
+                            *reinterpret_cast<uint4*>(smem + q * G::PS + 16 * e) = make_uint4(0, 0, 0, 0);
+                    }
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!ok[u]) continue;
-            uint8_t* dst = smem + it[u].lds;
-            const bool ld = it[u].inside;
+            uint8_t* dst = smem + lds[u];
             if constexpr (MODE == C32_NATIVE) {
                 half8 x = __builtin_bit_cast(half8, v[u][0][0]);
 #pragma unroll
                 for (int q = 1; q < NPOS; ++q) x = __builtin_elementwise_max(x, __builtin_bit_cast(half8, v[u][q][0]));
-                const uint4 val = ld ? __builtin_bit_cast(uint4, x) : make_uint4(0, 0, 0, 0);
-                *reinterpret_cast<uint4*>(dst) = val;
+                *reinterpret_cast<half8*>(dst) = x;
                 if constexpr (G::POOLIN) {
-                    if (it[u].own && a.out_pool)
-                        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(a.out_pool) +
-                            ((size_t)((it[u].g * G::H + it[u].y) * G::W + it[u].x) * G::C0 + it[u].ch) * ES) = val;
+                    if (own[u] && a.out_pool) *reinterpret_cast<half8*>(reinterpret_cast<char*>(a.out_pool) + qoff[u]) = x;
                 }
             } else {
                 float x[8];
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    f32x4v f = __builtin_bit_cast(f32x4v, v[u][0][k]);
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    f32x4v f = __builtin_bit_cast(f32x4v, v[u][0][e2]);
 #pragma unroll
                     for (int q = 1; q < NPOS; ++q) {
-                        const f32x4v g = __builtin_bit_cast(f32x4v, v[u][q][k]);
+                        const f32x4v g = __builtin_bit_cast(f32x4v, v[u][q][e2]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) f[e] = __builtin_fmaxf(f[e], g[e]);
                     }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) x[4 * k + e] = ld ? f[e] : 0.f;
+                    for (int e = 0; e < 4; ++e) x[4 * e2 + e] = f[e];
                 }
                 if constexpr (G::POOLIN) {
-                    if (it[u].own && a.out_pool) {
-                        float* q = reinterpret_cast<float*>(a.out_pool) + (size_t)((it[u].g * G::H + it[u].y) * G::W + it[u].x) * G::C0 + it[u].ch;
+                    if (own[u] && a.out_pool) {
+                        float* q = reinterpret_cast<float*>(reinterpret_cast<char*>(a.out_pool) + qoff[u]);
                         *reinterpret_cast<float4*>(q) = make_float4(x[0], x[1], x[2], x[3]);
                         *reinterpret_cast<float4*>(q + 4) = make_float4(x[4], x[5], x[6], x[7]);
                     }
@@ -121,13 +147,14 @@ __device__ __forceinline__ void c32_stage(const ConvArgs& a, uint8_t* smem, int 
                     *reinterpret_cast<half8*>(dst) = hi;
                     *reinterpret_cast<half8*>(dst + 16) = lo;
                 } else {
-                    bf16x8v b;
+                    bf16x8v b8;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) b[e] = (__bf16)x[e];
-                    *reinterpret_cast<bf16x8v*>(dst) = b;
+                    for (int e = 0; e < 8; ++e) b8[e] = (__bf16)x[e];
+                    *reinterpret_cast<bf16x8v*>(dst) = b8;
                 }
             }
         }
+        if (j0 + G::NTHR * U >= nA) break;
     }
 }
 
@@ -200,12 +227,15 @@ __device__ __forceinline__ void c32_run(const ConvArgs& a, uint8_t* smem, int me
         }
     }
     const int lbase = G::lane_base(lane);
+    C32_T(a, 0);
     for (int b = 0; b < nsb; ++b) {
         const int sb = sA + b * rows;
         const int R = (sB - sb) < rows ? (sB - sb) : rows;
         if (b > 0) __syncthreads();                        // everyone has finished reading the previous sub-band
         c32_stage<G>(a, smem, sb, R);
+        C32_T(a, 1);
         __syncthreads();                                   // (the compiler waits for the LDS writes before the barrier)
+        C32_T(a, 2);
         const int NT = G::n_tiles(R);
         for (int t0 = tl; t0 < NT; t0 += G::TL * G::NTB) {
             int tt[G::NTB], base[G::NTB];
@@ -252,12 +282,14 @@ __device__ __forceinline__ void c32_run(const ConvArgs& a, uint8_t* smem, int me
                 }
             }
         }
+        C32_T(a, 3);
     }
 }
 
 // the image range [img0, img0 + n) of one layer's operands
 template <class G>
 __device__ __forceinline__ ConvArgs c32_image_range(ConvArgs a, int img0, int n) {
+    if (img0 != 0) a.trace_id = -2;                  // (diagnostic builds trace the group that holds image 0)
     const size_t es = G::ES;
     a.in0 = reinterpret_cast<const char*>(a.in0) + (size_t)img0 * G::IH * G::IW * G::C0 * es;
     if (a.in1) a.in1 = reinterpret_cast<const char*>(a.in1) + (size_t)img0 * G::IH * G::IW * G::C1 * es;

@@ -100,26 +100,71 @@ struct C32 {
         n = (r + RBMAX - 1) / RBMAX;
         rows = n ? (r + n - 1) / n : 0;
     }
-    static GIGA_HD int n_items(int R) { return (R + 2 * HALO) * P * IPP; }
     static GIGA_HD int n_tiles(int R) { return (R * P - 2 * HALO + 31) / 32; }
     static GIGA_HD int lds_bytes(int R) { return ((R + 2 * HALO) * P + C32_TAIL) * PS; }
 
-    // staging item i of the sub-band that starts at stacked row sb: LDS byte offset, source pixel (image g of the group, row y,
-    // column x of the H x W input grid), first channel, and whether it lies inside an image (else it is a zero)
-    struct Item { int lds, g, y, x, ch; bool inside, own; };
-    static GIGA_HD Item item(int i, int sb, int R, int G) {
-        Item it;
-        const int pixel = i / IPP, v = i - pixel * IPP;
-        const int brow = pixel / P, col = pixel - brow * P;
+    // ---- staging -------------------------------------------------------------------------------------------------------------
+    // The REAL input rows of the group (rows inside an image) are numbered rr = g * H + y; an ITEM is 8 channels of one pixel,
+    // RI items per real row.  The real rows a sub-band needs are a contiguous range [rrA, rrB) and their items are contiguous
+    // in memory (a single dense tensor: byte offset = item index * item bytes), so thread t takes items t, t + 256, ... : the
+    // source address is linear, and the (row, position) decomposition that the LDS address needs is carried along
+    // incrementally (Cur: two adds and two compares per item, no division).  Zero rows and the two zero columns of every row
+    // are written separately (pad_pixel).
+    static constexpr int RI = W * IPP;
+    static constexpr int NTHR = C32_NW * 64;
+    // number of real rows whose stacked index is < s
+    static GIGA_HD int real_rows_below(int s, int G) {
+        if (HALO == 0) return s < 0 ? 0 : (s > G * H ? G * H : s);
+        if (s <= 0) return 0;
+        if (s >= G * SR) return G * H;
+        const int g = s / SR, r = s - g * SR;
+        return g * H + (r > 0 ? r - 1 : 0);
+    }
+    static GIGA_HD void real_rows(int sb, int R, int G, int& rrA, int& rrB) {
+        rrA = real_rows_below(sb - HALO, G);
+        rrB = real_rows_below(sb + R + HALO, G);
+    }
+    struct Cur { int rr, c, g, y; };                     // real row, item inside the row, image, row inside the image
+    static GIGA_HD Cur cur_init(int rrA, int j) {
+        Cur k;
+        const int q = j / RI;
+        k.rr = rrA + q; k.c = j - q * RI;
+        k.g = k.rr / H; k.y = k.rr - k.g * H;
+        return k;
+    }
+    static GIGA_HD void cur_next(Cur& k) {               // j += NTHR
+        constexpr int DR = NTHR / RI, DC = NTHR % RI;
+        static_assert(DR + 1 < H, "at most one image boundary per step");
+        int d = DR;
+        k.c += DC;
+        if (k.c >= RI) { k.c -= RI; ++d; }
+        k.rr += d; k.y += d;
+        if (k.y >= H) { k.y -= H; ++k.g; }
+    }
+    static GIGA_HD int cur_x(const Cur& k) { return k.c / IPP; }
+    static GIGA_HD int cur_ch(const Cur& k) { return 8 * (k.c % IPP); }
+    // LDS byte offset of the item in the sub-band that starts at stacked row sb
+    static GIGA_HD int cur_lds(const Cur& k, int sb) {
+        const int brow = k.g * SR + HALO + k.y - (sb - HALO);
+        return (brow * P + cur_x(k) + HALO) * PS + (k.c % IPP) * ILB;
+    }
+    // is row `s` (stacked) one this sub-band computes, i.e. not a halo row?  (the pooled write-through of the POOLIN layers)
+    static GIGA_HD bool cur_own(const Cur& k, int sb, int R) {
+        const int s = k.g * SR + HALO + k.y;
+        return s >= sb && s < sb + R;
+    }
+    // source pixel (in pixels of the IH x IW source grid of the group) of sub-position q (POOLIN: the 2x2 window; else q = 0)
+    static GIGA_HD int cur_src_pixel(const Cur& k, int q) {
+        return POOLIN ? (2 * k.rr + (q >> 1)) * IW + 2 * cur_x(k) + (q & 1) : k.rr * W + cur_x(k);
+    }
+    // buffer pixel q of the sub-band (0 .. (R + 2 HALO) * P): must it be written as zeros?
+    static GIGA_HD int n_buf_pixels(int R) { return (R + 2 * HALO) * P; }
+    static GIGA_HD bool pad_pixel(int q, int sb, int G) {
+        if (HALO == 0) return false;
+        const int brow = q / P, col = q - brow * P;
         const int s = sb - HALO + brow;
-        it.g = s / SR;
-        it.y = s - it.g * SR - HALO;
-        it.x = col - HALO;
-        it.ch = 8 * v;
-        it.lds = pixel * PS + v * ILB;
-        it.inside = it.g < G && it.y >= 0 && it.x >= 0 && it.x < W;
-        it.own = it.inside && brow >= HALO && brow < HALO + R;     // a row this sub-band computes (not a halo row)
-        return it;
+        const int g = s / SR, r = s - g * SR;
+        return r == 0 || g >= G || col == 0 || col == P - 1;
     }
     // LDS byte offset a lane adds to (tile, tap, chunk) offsets
     static GIGA_HD int lane_base(int lane) { return (lane & 31) * PS + (lane >> 5) * HB; }

@@ -627,14 +627,23 @@ __global__ __launch_bounds__(C32_NW * 64) void unet32_mega_kernel(MegaArgs m) {
     C32W<G##l> w##l;                                                                                               \
     if (l < m.nlayers) {                                                                                           \
         c32_load_weights<G##l>(m.layer[l], w##l, 0);                                                               \
+        MEGA32_T(l, 5);                                                                                            \
         xcd_barrier(counter, ++epoch * (unsigned)MEGA_GROUP, l, img0 == 0 ? block : -1);                           \
+        MEGA32_T(l, 6);                                                                                            \
     }
 #define RUN(l)                                                                                                     \
     if (l < m.nlayers) {                                                                                           \
         c32_run<G##l, U32Layer<MODE, l>::RELU>(c32_image_range<G##l>(m.layer[l], img0, per), smem, block, w##l);   \
         __builtin_amdgcn_s_waitcnt(0x0F70);            /* vmcnt(0): this wave's output stores are in the L2 */      \
         __syncthreads();                                                                                           \
+        MEGA32_T(l, 4);                                                                                            \
     }
+#ifdef GIGA_TRACE
+#define MEGA32_T(l, idx) do { if (img0 == 0 && block == 0 && (threadIdx.x & 63) == 0) \
+        g_c32_trace[l][threadIdx.x >> 6][idx] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MEGA32_T(l, idx) do {} while (0)
+#endif
     FIRST(0) RUN(0)
     NEXT(1) RUN(1)
     NEXT(2) RUN(2)
@@ -827,6 +836,9 @@ int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, fl
 // diagnostic build only: select the traced U-Net layer (host_out == nullptr) or read the timeline back
 extern "C" int giga_debug_mega_trace(long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(giga::g_mega_trace), sizeof(long long) * 8 * 32) == hipSuccess ? 0 : -10;
+}
+extern "C" int giga_debug_c32_trace(long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(giga::g_c32_trace), sizeof(long long) * giga::NCONV * giga::C32_NW * 8) == hipSuccess ? 0 : -10;
 }
 extern "C" int giga_debug_convin_trace(long long* host_out) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(giga::g_ci_trace), sizeof(long long) * 8 * 64) == hipSuccess ? 0 : -10;

@@ -62,41 +62,56 @@ static int emu_layer(const uint8_t* wimg, const float* bias, int Gimg, const flo
             if (G::lds_bytes(R) > C32_LDS) return -1;
             if (G::lds_bytes(R) > max_lds) max_lds = G::lds_bytes(R);
             std::memset(lds.data(), 0xFF, lds.size());          // NaN patterns: an unwritten byte that reaches a valid output is seen
-            // ---- c32_stage ----
-            const int nitems = G::n_items(R);
-            for (int i = 0; i < nitems; ++i) {
-                const typename G::Item it = G::item(i, sb, R, Gimg);
-                float x[8];
-                for (int e = 0; e < 8; ++e) x[e] = 0.f;
-                if (it.inside) {
-                    const bool first = G::C1 == 0 || it.ch < G::C0;
+            // ---- c32_stage: thread t takes items t, t + 256, ... of the real rows; zero pixels separately ----
+            int rrA, rrB;
+            G::real_rows(sb, R, Gimg, rrA, rrB);
+            const int nA = (rrB - rrA) * G::RI;
+            std::vector<uint8_t> wrote(G::lds_bytes(R), 0);
+            for (int tid = 0; tid < G::NTHR; ++tid) {
+                typename G::Cur k = G::cur_init(rrA, tid);
+                for (int j = tid; j < nA; j += G::NTHR, G::cur_next(k)) {
+                    float x[8];
+                    const int ch0 = G::cur_ch(k);
+                    const bool first = G::C1 == 0 || ch0 < G::C0;
                     const float* src = first ? in0 : in1;
-                    const int C = first ? G::C0 : G::C1, ch = first ? it.ch : it.ch - G::C0;
+                    const int C = first ? G::C0 : G::C1, ch = first ? ch0 : ch0 - G::C0;
+                    if (k.g < 0 || k.g >= Gimg || k.y < 0 || k.y >= G::H || k.rr != k.g * G::H + k.y) return -2;
                     for (int e = 0; e < 8; ++e) {
                         float m = -INFINITY;
                         for (int q = 0; q < (G::POOLIN ? 4 : 1); ++q) {
-                            const int yy = G::POOLIN ? 2 * it.y + (q >> 1) : it.y, xx = G::POOLIN ? 2 * it.x + (q & 1) : it.x;
-                            if (yy < 0 || yy >= G::IH || xx < 0 || xx >= G::IW || it.g < 0 || it.g >= Gimg) return -2;
-                            m = std::fmax(m, src[((size_t)(it.g * G::IH + yy) * G::IW + xx) * C + ch + e]);
+                            const int pix = G::cur_src_pixel(k, q);
+                            if (pix < 0 || pix >= Gimg * G::IH * G::IW) return -2;
+                            m = std::fmax(m, src[(size_t)pix * C + ch + e]);
                         }
                         x[e] = m;
                     }
-                    if (G::POOLIN && it.own && out_pool)
-                        for (int e = 0; e < 8; ++e) out_pool[((size_t)(it.g * G::H + it.y) * G::W + it.x) * G::C0 + it.ch + e] = x[e];
-                }
-                if (it.lds < 0 || it.lds + G::ILB > G::lds_bytes(R)) return -3;
-                uint8_t* dst = lds.data() + it.lds;
-                for (int e = 0; e < 8; ++e) {
-                    if (MODE == C32_SPLIT) {
-                        const half_t h = (half_t)x[e];
-                        const half_t l = (half_t)(x[e] - (float)h);
-                        std::memcpy(dst + 2 * e, &h, 2);
-                        std::memcpy(dst + 16 + 2 * e, &l, 2);
-                    } else {
-                        store16(dst + 2 * e, x[e], MODE);
+                    if (G::POOLIN && G::cur_own(k, sb, R) && out_pool)
+                        for (int e = 0; e < 8; ++e) out_pool[(size_t)(k.rr * G::W + G::cur_x(k)) * G::C0 + ch0 + e] = x[e];
+                    const int lo = G::cur_lds(k, sb);
+                    if (lo < 0 || lo + G::ILB > G::lds_bytes(R)) return -3;
+                    uint8_t* dst = lds.data() + lo;
+                    for (int e = 0; e < G::ILB; ++e) wrote[lo + e] += 1;
+                    for (int e = 0; e < 8; ++e) {
+                        if (MODE == C32_SPLIT) {
+                            const half_t h = (half_t)x[e];
+                            const half_t l = (half_t)(x[e] - (float)h);
+                            std::memcpy(dst + 2 * e, &h, 2);
+                            std::memcpy(dst + 16 + 2 * e, &l, 2);
+                        } else {
+                            store16(dst + 2 * e, x[e], MODE);
+                        }
                     }
                 }
             }
+            if (G::HALO)
+                for (int q = 0; q < G::n_buf_pixels(R); ++q)
+                    if (G::pad_pixel(q, sb, Gimg)) {
+                        std::memset(lds.data() + (size_t)q * G::PS, 0, G::IPP * G::ILB);
+                        for (int e = 0; e < G::IPP * G::ILB; ++e) wrote[(size_t)q * G::PS + e] += 1;
+                    }
+            for (int q = 0; q < G::n_buf_pixels(R); ++q)        // every channel byte of every buffer pixel exactly once
+                for (int e = 0; e < G::IPP * G::ILB; ++e)
+                    if (wrote[(size_t)q * G::PS + e] != 1) return -6;
             // ---- c32_run: waves, tiles ----
             const int NT = G::n_tiles(R);
             ntiles_total += NT;

@@ -214,7 +214,11 @@ def test_bf16_training_step(sd7, monkeypatch):
     conv = [(0, 32, 32), (0, 32, 32), (0, 32, 64), (0, 64, 64), (0, 64, 128), (0, 128, 128), (1, 128, 64), (0, 128, 64), (0, 64, 64),
             (1, 64, 32), (0, 64, 32), (0, 32, 32), (2, 32, 32)]
     tail = sum((co // 16 * (4 if k == 1 else 1)) * (9 if k == 0 else 1) * (ci // 32) * 1024 for k, ci, co in conv)
-    assert torch.equal(st.blob.cpu()[-tail:], host_fwd[-tail:]), "device repack + derive != host pack (forward bf16 fragments)"
+    # (the conv32 images of round 4 -- f16, f16x3 pairs, bf16: 4 fragments per (32-channel slice, tap, 16-channel chunk) -- follow them)
+    c32 = sum(4 * (co // 32 * (4 if k == 1 else 1)) * (9 if k == 0 else 1) * (ci // 16) * 1024 for k, ci, co in conv)
+    n = st.blob.numel()
+    assert torch.equal(st.blob.cpu()[n - c32 - tail:n - c32], host_fwd[n - c32 - tail:n - c32]), \
+        "device repack + derive != host pack (forward bf16 fragments)"
     assert torch.equal(st.bwd_blob.cpu(), host_bwd), "device repack + derive != host pack (backward blob)"
     assert _capi.lib().giga_derive_bf16_fragments(None, None, None) == -1
     # and a few optimizer steps in bf16 reduce the loss like the fp32 run does
