@@ -1,13 +1,14 @@
-// conv32: the weight-stationary, LDS-image-resident convolution of the f16-class U-Net (f16, f16x3 split and bf16 arithmetic).
+// conv32: the LDS-image-resident 32x32x16 convolution of the f16-class U-Net (f16, f16x3 split and bf16 arithmetic).
 // Geometry, the reasons for it and the reference citations: giga_conv32_geom.h.  This file is the gfx950 side:
-//   c32_load_weights : a wave pulls the fragments of its slice group straight from the packed blob (L2) into REGISTERS -- issued
-//                      before the group barrier of the persistent kernel, so they land while the barrier is waited for;
-//   c32_stage        : the workgroup copies its haloed sub-band into LDS (16-byte vectors, pad columns / rows written as zeros;
-//                      2x2 max-pool, f16x3 split or bf16 rounding applied on the way);
-//   c32_mma          : per (tile, tap, k-chunk) ONE ds_read_b128 per lane at `lane base + immediate` feeds SPW MFMAs whose A
-//                      operands never leave the register file; a ring of four reads is in flight per tile;
-//   epilogue         : a lane holds 16 consecutive output channels of one pixel: bias (accumulator init), ReLU, rounding, one or
-//                      two 16-byte stores per 8 channels.
+//   c32_fill   : LDS-DMA of the member's weight fragments into LDS bytes [0, WBYTES) -- one copy per workgroup; issued before the
+//                group barrier of the persistent kernel, so it lands while the barrier is waited for;
+//   c32_stage  : the workgroup copies its haloed sub-band into LDS behind the weights (16-byte vectors, every load of a thread in
+//                flight before its first LDS write, pad columns / rows written as zeros; 2x2 max-pool, f16x3 split or bf16
+//                rounding applied on the way);
+//   c32_mma    : a wave's register tile of NTB tiles x SPW slices: per (tap, k-chunk) SPW + NTB ds_read_b128 at `base +
+//                immediate` feed NTB * SPW MFMAs; a ring of three steps is in flight;
+//   epilogue   : a lane holds 16 consecutive output channels of one pixel: bias (accumulator init), ReLU, rounding, one or
+//                two 16-byte stores per 8 channels.
 // The summation order of every output is fixed (bias, then taps x k-chunks in order), so results do not depend on how the rows
 // are dealt out: the persistent kernel, the per-layer launches and every batch size agree bit for bit.
 #pragma once
@@ -31,83 +32,86 @@ static __device__ long long g_c32_trace[NCONV][C32_NW][8];
 #define C32_T(a, idx) do {} while (0)
 #endif
 
+// the member's WFR fragments of channel part `part` -> LDS bytes [0, WBYTES): 1 KiB per wave instruction (all waves take part)
 template <class G>
-struct C32W { uint4 v[G::SPW][G::TAPS * G::KCP][G::NOP]; };
-
-// fragments of slice group sg = wave % SG, k-part `part`: [slice][tap][k-chunk] x NOP, 16 bytes per lane each
-template <class G>
-__device__ __forceinline__ void c32_load_weights(const ConvArgs& a, C32W<G>& w, int part) {
+__device__ __forceinline__ void c32_fill(const ConvArgs& a, uint8_t* smem, int member, int part = 0) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int sg = wave % G::SG;
-    const uint8_t* base = a.w + lane * 16;
-#pragma unroll
-    for (int s = 0; s < G::SPW; ++s)
-#pragma unroll
-        for (int tap = 0; tap < G::TAPS; ++tap)
-#pragma unroll
-            for (int kcp = 0; kcp < G::KCP; ++kcp) {
-                const int f = G::frag(sg * G::SPW + s, tap, part * G::KCP + kcp);
-#pragma unroll
-                for (int o = 0; o < G::NOP; ++o)
-                    w.v[s][tap * G::KCP + kcp][o] = *reinterpret_cast<const uint4*>(base + (size_t)(f * G::NOP + o) * FRAG);
-            }
+    const int sgm = G::member_sgm(member);
+    const uint8_t* wsrc = a.w + lane * 16;
+    for (int c = wave; c < G::WFR; c += C32_NW)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)G::fill_src(c, sgm, part) * FRAG),
+                                         (__attribute__((address_space(3))) void*)(smem + c * FRAG), 16, 0, 0);
 }
 
 // ---- staging: the haloed sub-band [sb - HALO, sb + R + HALO) x P pixels -> LDS ------------------------------------------------
-// All of a thread's loads (up to U items) are in flight before the first LDS write; the zero pixels are written under their
-// latency.  Thread t takes items t, t + 256, ... of the sub-band's real rows (giga_conv32_geom.h: Cur).
+// Thread t takes items t, t + 256, ... of the sub-band's real rows (giga_conv32_geom.h: Cur -- source and LDS offsets advance by
+// adds).  A chunk issues ALL its loads (8 / 16 / 24 items of 16 bytes per thread, chosen by what is left) before the first LDS
+// write; the zero pixels are written under the latency of the first chunk.
 template <class G>
-__device__ __forceinline__ void c32_stage(const ConvArgs& a, uint8_t* smem, int sb, int R) {
-    constexpr int MODE = G::MODE, ES = G::ES;
-    constexpr int NPOS = G::POOLIN ? 4 : 1;                  // source pixels per staged pixel
-    constexpr int VPI = MODE == C32_NATIVE ? 1 : 2;          // 16-byte source vectors per item (8 channels)
-    constexpr int U = (MODE == C32_NATIVE ? 24 : 12) / NPOS; // items per thread in flight
-    const int tid = threadIdx.x, Gimg = a.nimg;
-    int rrA, rrB;
-    G::real_rows(sb, R, Gimg, rrA, rrB);
-    const int nA = (rrB - rrA) * G::RI;
-    const char* in0 = reinterpret_cast<const char*>(a.in0);
-    const char* in1 = reinterpret_cast<const char*>(a.in1);
-    typename G::Cur k = G::cur_init(rrA, tid);
-    bool first_chunk = true;
-    for (int j0 = tid;; j0 += G::NTHR * U) {
+struct C32Stage {
+    static constexpr int MODE = G::MODE, ES = G::ES;
+    static constexpr int NPOS = G::POOLIN ? 4 : 1;                  // source pixels per staged pixel
+    static constexpr int VPI = MODE == C32_NATIVE ? 1 : 2;          // 16-byte source vectors per item (8 channels)
+    static constexpr int UMAX = 24 / (VPI * NPOS);                  // items per thread in flight at most
+    const ConvArgs& a;
+    uint8_t* smem;
+    const char* src;                                                // this thread's source tensor (concat: in0 or in1)
+    uint32_t pixb, chb, qchb;                                       // bytes per source pixel, byte offset of the thread's 8 channels (source / pooled copy)
+    int sb, R, nA, j;
+    typename G::Cur k;
+    bool zero_pending;
+
+    __device__ __forceinline__ C32Stage(const ConvArgs& a_, uint8_t* smem_, int sb_, int R_, int part) : a(a_), smem(smem_), sb(sb_), R(R_) {
+        const int tid = threadIdx.x;
+        int rrA, rrB;
+        G::real_rows(sb, R, a.nimg, rrA, rrB);
+        nA = (rrB - rrA) * G::RI;
+        const int ch0 = G::thr_ch(tid);
+        // KP == 1: a concatenated pixel is [C0 channels of in0 | C1 channels of in1]; KP > 1: the part names its tensor / channel range
+        const bool first = G::KP > 1 ? G::part_tensor(part) == 0 : (G::C1 == 0 || ch0 < G::C0);
+        src = reinterpret_cast<const char*>(first ? a.in0 : a.in1);
+        pixb = (uint32_t)(first ? G::C0 : G::C1) * ES;
+        chb = (uint32_t)(G::KP > 1 ? G::part_ch0(part) + ch0 : (first ? ch0 : ch0 - G::C0)) * ES;
+        qchb = (uint32_t)ch0 * ES;
+        k = G::cur_init(rrA, tid, sb);
+        j = tid;
+        zero_pending = G::HALO != 0;
+    }
+    __device__ __forceinline__ void zeros() {
+        zero_pending = false;
+        const int nq = G::n_buf_pixels(R);
+        for (int q = threadIdx.x; q < nq; q += G::NTHR)
+            if (G::pad_pixel(q, sb, a.nimg)) {
+#pragma unroll
+                for (int e = 0; e < G::IPP * G::ILB / 16; ++e)
+                    *reinterpret_cast<uint4*>(smem + G::WBYTES + q * G::PS + 16 * e) = make_uint4(0, 0, 0, 0);
+            }
+    }
+    template <int U>
+    __device__ __forceinline__ void chunk() {
         uint4 v[U][NPOS][VPI];
         int lds[U];
         uint32_t qoff[U];
         bool ok[U], own[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            ok[u] = j0 + G::NTHR * u < nA;
-            lds[u] = G::cur_lds(k, sb);
-            const int ch0 = G::cur_ch(k);
-            const bool first = G::C1 == 0 || ch0 < G::C0;
-            const char* src = first ? in0 : in1;
-            const uint32_t C = first ? G::C0 : G::C1, ch = first ? ch0 : ch0 - G::C0;
+            ok[u] = j < nA;
+            lds[u] = k.lds;
 #pragma unroll
             for (int q = 0; q < NPOS; ++q) {
-                const uint32_t off = ok[u] ? ((uint32_t)G::cur_src_pixel(k, q) * C + ch) * (uint32_t)ES : 0u;   // (clamped: every load is issued)
+                const uint32_t off = ok[u] ? __umul24((uint32_t)G::cur_src_pixel(k, q), pixb) + chb : 0u;   // (clamped: every load is issued)
 #pragma unroll
                 for (int e = 0; e < VPI; ++e) v[u][q][e] = *reinterpret_cast<const uint4*>(src + off + 16 * e);
             }
             if constexpr (G::POOLIN) {
                 own[u] = ok[u] && G::cur_own(k, sb, R);
-                qoff[u] = ((uint32_t)(k.rr * G::W + G::cur_x(k)) * G::C0 + ch0) * (uint32_t)ES;
+                qoff[u] = __umul24((uint32_t)k.spix, (uint32_t)G::C0 * ES) + qchb;
             }
             G::cur_next(k);
+            j += G::NTHR;
         }
-        if (first_chunk) {                                   // zero rows / zero columns, under the latency of the loads
-            first_chunk = false;
-            if constexpr (G::HALO) {
-                const int nq = G::n_buf_pixels(R);
-                for (int q = tid; q < nq; q += G::NTHR)
-                    if (G::pad_pixel(q, sb, Gimg)) {
-#pragma unroll
-                        for (int e = 0; e < G::IPP * G::ILB / 16; ++e)
-                            *reinterpret_cast<uint4*>(smem + q * G::PS + 16 * e) = make_uint4(0, 0, 0, 0);
-                    }
-            }
-        }
+        if (zero_pending) zeros();                           // under the latency of the loads
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!ok[u]) continue;
@@ -154,24 +158,40 @@ __device__ __forceinline__ void c32_stage(const ConvArgs& a, uint8_t* smem, int 
                 }
             }
         }
-        if (j0 + G::NTHR * U >= nA) break;
     }
+    __device__ __forceinline__ void run() {
+        constexpr int U1 = UMAX >= 3 ? UMAX / 3 : 1, U2 = UMAX >= 3 ? 2 * UMAX / 3 : (UMAX >= 2 ? 2 : 1);
+        int rem = (nA + G::NTHR - 1) / G::NTHR;              // steps of the slowest thread (uniform)
+        while (rem > 0) {
+            if (rem > U2 && UMAX > U2) { chunk<UMAX>(); rem -= UMAX; }
+            else if (rem > U1 && U2 > U1) { chunk<U2>(); rem -= U2; }
+            else { chunk<U1>(); rem -= U1; }
+        }
+        if (zero_pending) zeros();
+    }
+};
+template <class G>
+__device__ __forceinline__ void c32_stage(const ConvArgs& a, uint8_t* smem, int sb, int R, int part = 0) {
+    C32Stage<G> st(a, smem, sb, R, part);
+    st.run();
 }
 
-// ---- the MFMA loop of NTB tiles: taps x k-chunks of part PART, B operands through a ring of PD reads per tile -------------------
-template <class G, int PART>
-__device__ __forceinline__ void c32_mma(const uint8_t* smem, const int (&base)[G::NTB], const C32W<G>& w,
-                                        f32x16 (&acc)[G::NTB][G::SPW]) {
-    constexpr int NIT = G::TAPS * G::KCP, PD = NIT < 4 ? NIT : 4;
-    uint4 ring[PD][G::NTB][G::NOP];
+// ---- the MFMA loop of a register tile: NTB tiles x SPW slices, taps x k-chunks; operands through a ring of PD steps ------------
+// wl: this lane's LDS byte offset of the first A fragment of the slice pass (lane * 16 + pass base); base[j]: its B offset of tile j
+template <class G, int NTB>
+__device__ __forceinline__ void c32_mma(const uint8_t* smem, const int wl, const int (&base)[NTB], f32x16 (&acc)[NTB][G::SPW]) {
+    constexpr int NIT = G::NIT, PD = NIT < 3 ? NIT : 3;
+    uint4 ra[PD][G::SPW][G::NOP], rb[PD][NTB][G::NOP];
     auto rd = [&](const int it, const int slot) {
-        const int tap = it / G::KCP, kcp = it % G::KCP;
-        const int off = G::tap_off(tap) + G::kc_off(PART * G::KCP + kcp);
+        const int off = G::tap_off(it / G::KCP) + G::kc_off(it % G::KCP);
 #pragma unroll
-        for (int j = 0; j < G::NTB; ++j)
+        for (int s = 0; s < G::SPW; ++s)
 #pragma unroll
-            for (int o = 0; o < G::NOP; ++o)
-                ring[slot][j][o] = *reinterpret_cast<const uint4*>(smem + base[j] + off + 16 * o);
+            for (int o = 0; o < G::NOP; ++o) ra[slot][s][o] = *reinterpret_cast<const uint4*>(smem + wl + G::w_off(s, it, o));
+#pragma unroll
+        for (int j = 0; j < NTB; ++j)
+#pragma unroll
+            for (int o = 0; o < G::NOP; ++o) rb[slot][j][o] = *reinterpret_cast<const uint4*>(smem + base[j] + off + 16 * o);
     };
 #pragma unroll
     for (int it = 0; it < PD; ++it) rd(it, it);
@@ -179,20 +199,20 @@ __device__ __forceinline__ void c32_mma(const uint8_t* smem, const int (&base)[G
     for (int it = 0; it < NIT; ++it) {
         const int slot = it % PD;
 #pragma unroll
-        for (int j = 0; j < G::NTB; ++j)
+        for (int j = 0; j < NTB; ++j)
 #pragma unroll
             for (int s = 0; s < G::SPW; ++s) {
                 f32x16& c = acc[j][s];
                 if constexpr (G::MODE == C32_SPLIT) {
-                    const half8 Wh = __builtin_bit_cast(half8, w.v[s][it][0]), Wl = __builtin_bit_cast(half8, w.v[s][it][G::NOP - 1]);
-                    const half8 Xh = __builtin_bit_cast(half8, ring[slot][j][0]), Xl = __builtin_bit_cast(half8, ring[slot][j][G::NOP - 1]);
+                    const half8 Wh = __builtin_bit_cast(half8, ra[slot][s][0]), Wl = __builtin_bit_cast(half8, ra[slot][s][G::NOP - 1]);
+                    const half8 Xh = __builtin_bit_cast(half8, rb[slot][j][0]), Xl = __builtin_bit_cast(half8, rb[slot][j][G::NOP - 1]);
                     c = mfma16(Wl, Xh, c);
                     c = mfma16(Wh, Xl, c);
                     c = mfma16(Wh, Xh, c);
                 } else if constexpr (G::MODE == C32_BF16) {
-                    c = mfma16_bf(__builtin_bit_cast(bf16x8v, w.v[s][it][0]), __builtin_bit_cast(bf16x8v, ring[slot][j][0]), c);
+                    c = mfma16_bf(__builtin_bit_cast(bf16x8v, ra[slot][s][0]), __builtin_bit_cast(bf16x8v, rb[slot][j][0]), c);
                 } else {
-                    c = mfma16(__builtin_bit_cast(half8, w.v[s][it][0]), __builtin_bit_cast(half8, ring[slot][j][0]), c);
+                    c = mfma16(__builtin_bit_cast(half8, ra[slot][s][0]), __builtin_bit_cast(half8, rb[slot][j][0]), c);
                 }
             }
         __builtin_amdgcn_sched_barrier(0);
@@ -201,88 +221,140 @@ __device__ __forceinline__ void c32_mma(const uint8_t* smem, const int (&base)[G
     }
 }
 
-// ---- one layer for one member of a group: `a` is already the group's image range (a.nimg = its G images) ---------------------
-// `w` holds the fragments of part 0 (c32_load_weights, issued by the caller before its barrier).
-template <class G, bool RELU>
-__device__ __forceinline__ void c32_run(const ConvArgs& a, uint8_t* smem, int member, C32W<G>& w) {
+// a register tile: NTB tiles (t0 ..) x the SPW slices of slice pass sp
+template <class G, bool RELU, int NTB>
+struct C32Tile {
     using T = std::conditional_t<G::MODE == C32_NATIVE, half_t, float>;
-    static_assert(G::KPARTS == 1, "k parts: not built yet");
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = lane & 31, hi = lane >> 5;
-    const int sg = wave % G::SG, tl = wave / G::SG;
-    int sA, sB, nsb, rows;
-    G::member_rows(member, a.nimg, sA, sB);
-    G::sub_bands(sA, sB, nsb, rows);
-    // accumulator init = bias of the lane's 16 output channels
-    f32x16 bias[G::SPW];
+    f32x16 acc[NTB][G::SPW];
+    int base[NTB];
+    __device__ __forceinline__ void init(const ConvArgs& a, int sgm, int sp, int t0, int NT) {
+        const int lane = threadIdx.x & 63, hi = lane >> 5;
+        const int lbase = G::lane_base(lane);
 #pragma unroll
-    for (int s = 0; s < G::SPW; ++s) {
-        const int cs = (sg * G::SPW + s) % G::CS;
-        const float4* bp = reinterpret_cast<const float4*>(a.bias + 32 * cs + 16 * hi);
+        for (int j = 0; j < NTB; ++j) base[j] = (t0 + j < NT ? t0 + j : t0) * G::tile_step() + lbase;   // (a missing tile repeats the first; not stored)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 b4 = bp[q];
-            bias[s][4 * q] = b4.x; bias[s][4 * q + 1] = b4.y; bias[s][4 * q + 2] = b4.z; bias[s][4 * q + 3] = b4.w;
+        for (int s = 0; s < G::SPW; ++s) {                 // accumulator init = bias of the lane's 16 output channels
+            const int cs = (sgm * G::SPM + sp * G::SPW + s) % G::CS;
+            const float4* bp = reinterpret_cast<const float4*>(a.bias + 32 * cs + 16 * hi);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b4 = bp[q];
+#pragma unroll
+                for (int j = 0; j < NTB; ++j) {
+                    acc[j][s][4 * q] = b4.x; acc[j][s][4 * q + 1] = b4.y; acc[j][s][4 * q + 2] = b4.z; acc[j][s][4 * q + 3] = b4.w;
+                }
+            }
         }
     }
-    const int lbase = G::lane_base(lane);
-    C32_T(a, 0);
-    for (int b = 0; b < nsb; ++b) {
-        const int sb = sA + b * rows;
-        const int R = (sB - sb) < rows ? (sB - sb) : rows;
-        if (b > 0) __syncthreads();                        // everyone has finished reading the previous sub-band
-        c32_stage<G>(a, smem, sb, R);
-        C32_T(a, 1);
-        __syncthreads();                                   // (the compiler waits for the LDS writes before the barrier)
-        C32_T(a, 2);
-        const int NT = G::n_tiles(R);
-        for (int t0 = tl; t0 < NT; t0 += G::TL * G::NTB) {
-            int tt[G::NTB], base[G::NTB];
-            f32x16 acc[G::NTB][G::SPW];
+    __device__ __forceinline__ void mma(const uint8_t* smem, int sp) {
+        c32_mma<G, NTB>(smem, (int)(threadIdx.x & 63) * 16 + G::w_off(sp * G::SPW, 0, 0), base, acc);
+    }
+    __device__ __forceinline__ void store(const ConvArgs& a, int sgm, int sp, int t0, int NT, int sb, int R) {
+        const int lane = threadIdx.x & 63, n = lane & 31, hi = lane >> 5;
 #pragma unroll
-            for (int j = 0; j < G::NTB; ++j) {
-                tt[j] = t0 + G::TL * j;
-                base[j] = (tt[j] < NT ? tt[j] : t0) * G::tile_step() + lbase;      // (a missing second tile repeats the first; not stored)
+        for (int j = 0; j < NTB; ++j) {
+            if (t0 + j >= NT) continue;
+            const typename G::Out o = G::out_pixel(t0 + j, n, sb, R);
+            if (!o.valid) continue;
 #pragma unroll
-                for (int s = 0; s < G::SPW; ++s) acc[j][s] = bias[s];
-            }
-            c32_mma<G, 0>(smem, base, w, acc);
+            for (int s = 0; s < G::SPW; ++s) {
+                const int slice = sgm * G::SPM + sp * G::SPW + s, sub = slice / G::CS, cs = slice % G::CS;
+                const size_t pix = (size_t)G::out_index(o.g, o.y, o.x, sub);
+                float v[16];
 #pragma unroll
-            for (int j = 0; j < G::NTB; ++j) {
-                if (tt[j] >= NT) continue;
-                const typename G::Out o = G::out_pixel(tt[j], n, sb, R);
-                if (!o.valid) continue;
+                for (int r = 0; r < 16; ++r) v[r] = RELU ? relu(acc[j][s][r]) : acc[j][s][r];
+                T* dst = reinterpret_cast<T*>(a.out) + pix * G::COUT + 32 * cs + 16 * hi;
+                if constexpr (G::MODE == C32_NATIVE) {
+                    half8 h0, h1;
 #pragma unroll
-                for (int s = 0; s < G::SPW; ++s) {
-                    const int slice = sg * G::SPW + s, sub = slice / G::CS, cs = slice % G::CS;
-                    const size_t pix = (size_t)G::out_index(o.g, o.y, o.x, sub);
-                    float v[16];
+                    for (int r = 0; r < 8; ++r) { h0[r] = (half_t)v[r]; h1[r] = (half_t)v[8 + r]; }
+                    *reinterpret_cast<half8*>(dst) = h0;
+                    *reinterpret_cast<half8*>(dst + 8) = h1;
+                } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = RELU ? relu(acc[j][s][r]) : acc[j][s][r];
-                    T* dst = reinterpret_cast<T*>(a.out) + pix * G::COUT + 32 * cs + 16 * hi;
-                    if constexpr (G::MODE == C32_NATIVE) {
-                        half8 h0, h1;
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                }
+                if constexpr (G::KIND == CONV1) {
+                    if (a.out_nchw) {
+                        float* q = a.out_nchw + ((size_t)o.g * G::COUT + 32 * cs + 16 * hi) * (G::H * G::W) + o.y * G::W + o.x;
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) { h0[r] = (half_t)v[r]; h1[r] = (half_t)v[8 + r]; }
-                        *reinterpret_cast<half8*>(dst) = h0;
-                        *reinterpret_cast<half8*>(dst + 8) = h1;
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-                    }
-                    if constexpr (G::KIND == CONV1) {
-                        if (a.out_nchw) {
-                            float* q = a.out_nchw + ((size_t)o.g * G::COUT + 32 * cs + 16 * hi) * (G::H * G::W) + o.y * G::W + o.x;
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) q[(size_t)r * (G::H * G::W)] = v[r];
-                        }
+                        for (int r = 0; r < 16; ++r) q[(size_t)r * (G::H * G::W)] = v[r];
                     }
                 }
             }
         }
-        C32_T(a, 3);
+    }
+};
+
+// the tiles of one staged sub-band (KP == 1): batches of NTB tiles dealt over the waves, all slice passes of the member per batch
+template <class G, bool RELU, int NTB>
+__device__ __forceinline__ void c32_tiles(const ConvArgs& a, const uint8_t* smem, int sgm, int NT, int sb, int R) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nbatch = (NT + NTB - 1) / NTB;
+    for (int bi = wave; bi < nbatch; bi += C32_NW) {
+#pragma unroll 1
+        for (int sp = 0; sp < G::NSP; ++sp) {
+            C32Tile<G, RELU, NTB> t;
+            t.init(a, sgm, sp, bi * NTB, NT);
+            t.mma(smem, sp);
+            t.store(a, sgm, sp, bi * NTB, NT, sb, R);
+        }
+    }
+}
+// a sub-band whose channels are walked in KP parts: ONE register tile per wave (RBMAX keeps it to that), alive across the parts;
+// each part has its own weight fill and its own staged image
+template <class G, bool RELU, int NTB>
+__device__ __forceinline__ void c32_parts(const ConvArgs& a, uint8_t* smem, int member, bool filled, int NT, int sb, int R) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sgm = G::member_sgm(member);
+    const bool mine = wave * NTB < NT;
+    C32Tile<G, RELU, NTB> t;
+    t.init(a, sgm, 0, wave * NTB, NT);
+#pragma unroll 1
+    for (int part = 0; part < G::KP; ++part) {
+        if (part > 0 || !filled) {
+            __syncthreads();                               // everyone has finished with the previous weights and image
+            c32_fill<G>(a, smem, member, part);
+        }
+        c32_stage<G>(a, smem, sb, R, part);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        if (mine) t.mma(smem, 0);
+    }
+    if (mine) t.store(a, sgm, 0, wave * NTB, NT, sb, R);
+}
+
+// ---- one layer for one member of a group: `a` is already the group's image range (a.nimg = its G images); the member's
+// weights (part 0) are on their way into LDS (c32_fill, issued by the caller before its barrier).
+template <class G, bool RELU>
+__device__ __forceinline__ void c32_run(const ConvArgs& a, uint8_t* smem, int member) {
+    const int sgm = G::member_sgm(member);
+    int sA, sB, nsb, rows;
+    G::member_rows(member, a.nimg, sA, sB);
+    G::sub_bands(sA, sB, nsb, rows);
+    C32_T(a, 0);
+    for (int b = 0; b < nsb; ++b) {
+        const int sb = sA + b * rows;
+        const int R = (sB - sb) < rows ? (sB - sb) : rows;
+        const int NT = G::n_tiles(R);
+        const int ntb = G::batch_tiles(NT);
+        if constexpr (G::KP > 1) {
+            if (ntb == 1) c32_parts<G, RELU, 1>(a, smem, member, b == 0, NT, sb, R);
+            else if (ntb == 2) c32_parts<G, RELU, 2>(a, smem, member, b == 0, NT, sb, R);
+            else if constexpr (G::NTBM >= 3) c32_parts<G, RELU, 3>(a, smem, member, b == 0, NT, sb, R);
+        } else {
+            if (b > 0) __syncthreads();                    // everyone has finished reading the previous sub-band
+            c32_stage<G>(a, smem, sb, R);
+            C32_T(a, 1);
+            __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's share of the weight fill has landed
+            __syncthreads();                               // (the compiler waits for the LDS writes before the barrier)
+            C32_T(a, 2);
+            if (ntb == 1) c32_tiles<G, RELU, 1>(a, smem, sgm, NT, sb, R);
+            else if (ntb == 2) c32_tiles<G, RELU, 2>(a, smem, sgm, NT, sb, R);
+            else if constexpr (G::NTBM >= 3) c32_tiles<G, RELU, 3>(a, smem, sgm, NT, sb, R);
+            C32_T(a, 3);
+        }
     }
 }
 
@@ -315,9 +387,8 @@ __global__ __launch_bounds__(C32_NW * 64) void conv32_kernel(ConvArgs a, int nq)
     c32_group_images(q, nq, a.nimg, img0, per);
     if (per == 0) return;
     const ConvArgs ar = c32_image_range<G>(a, img0, per);
-    C32W<G> w;
-    c32_load_weights<G>(ar, w, 0);
-    c32_run<G, RELU>(ar, smem, member, w);
+    c32_fill<G>(ar, smem, member);
+    c32_run<G, RELU>(ar, smem, member);
 }
 
 inline int c32_groups(int nimg) {                     // groups of a launch: 8 per slot, up to 4 slots per XCD (as unet_mega_kernel)

@@ -500,6 +500,22 @@ __device__ __forceinline__ void xcd_barrier(unsigned* counter, unsigned target, 
 #endif
 }
 
+// the same barrier in two halves: arrive (after the workgroup's stores are acknowledged), then -- after the caller has put its next
+// weight fill in flight -- wait.  What sits between the two does not delay the other members of the group.
+__device__ __forceinline__ void xcd_arrive(unsigned* counter) {
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // performed in this XCD's L2
+}
+__device__ __forceinline__ void xcd_wait(unsigned* counter, unsigned target) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {   // an L2 read
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24)) __builtin_trap();       // fail loudly, never hang the device
+        }
+    }
+    __syncthreads();
+}
+
 // the image range [img0, img0 + n) of one layer's operands
 template <typename T, int KIND, int C0, int C1, int COUT, int H, int W>
 __device__ __forceinline__ ConvArgs conv_image_range(ConvArgs a, int img0, int n) {
@@ -615,25 +631,24 @@ __global__ __launch_bounds__(C32_NW * 64) void unet32_mega_kernel(MegaArgs m) {
     const int block = ticket - slot * MEGA_GROUP;                           // this workgroup's place inside its group
     unsigned* counter = m.sync + (8 + q) * 32;
     unsigned epoch = 0;
-    // FIRST(l): weights of layer l, no barrier.  NEXT(l): request layer l's weights (they land while the barrier is waited for),
-    // then the group barrier.  RUN(l): stage / MFMA / store; then every wave's stores are acknowledged by the L2 and every wave
-    // has left the LDS image.
+    // FIRST(l): request the weights of layer l, no barrier.  NEXT(l): arrive at the group barrier, request layer l's weights
+    // (LDS-DMA: they land while the barrier is waited for), then wait.  RUN(l): stage / MFMA / store; then every wave's stores
+    // are acknowledged by the L2 and every wave has left the LDS image.
 #define FIRST(l)                                                                                                   \
     using G##l = typename U32Layer<MODE, l>::G;                                                                    \
-    C32W<G##l> w##l;                                                                                               \
-    c32_load_weights<G##l>(m.layer[l], w##l, 0);
+    c32_fill<G##l>(m.layer[l], smem, block);
 #define NEXT(l)                                                                                                    \
     using G##l = typename U32Layer<MODE, l>::G;                                                                    \
-    C32W<G##l> w##l;                                                                                               \
     if (l < m.nlayers) {                                                                                           \
-        c32_load_weights<G##l>(m.layer[l], w##l, 0);                                                               \
+        xcd_arrive(counter);                                                                                       \
+        c32_fill<G##l>(m.layer[l], smem, block);                                                                   \
         MEGA32_T(l, 5);                                                                                            \
-        xcd_barrier(counter, ++epoch * (unsigned)MEGA_GROUP, l, img0 == 0 ? block : -1);                           \
+        xcd_wait(counter, ++epoch * (unsigned)MEGA_GROUP);                                                         \
         MEGA32_T(l, 6);                                                                                            \
     }
 #define RUN(l)                                                                                                     \
     if (l < m.nlayers) {                                                                                           \
-        c32_run<G##l, U32Layer<MODE, l>::RELU>(c32_image_range<G##l>(m.layer[l], img0, per), smem, block, w##l);   \
+        c32_run<G##l, U32Layer<MODE, l>::RELU>(c32_image_range<G##l>(m.layer[l], img0, per), smem, block);         \
         __builtin_amdgcn_s_waitcnt(0x0F70);            /* vmcnt(0): this wave's output stores are in the L2 */      \
         __syncthreads();                                                                                           \
         MEGA32_T(l, 4);                                                                                            \
@@ -757,11 +772,11 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     const bool mega = full_device && !probe_layer &&
                       (persist > 0 || (persist == 0 && (env_persist > 0 || (env_persist < 0 && by_default))));
     // conv32 (giga_conv32.h): the f16-class modes.  GIGA_CONV32=0 keeps conv16 (A/B runs).
-    constexpr int C32MODE = sizeof(T) == 2 ? C32_NATIVE : -1;
+    constexpr int C32MODE = sizeof(T) == 2 ? C32_NATIVE : MATH == MATH_SPLIT ? C32_SPLIT : -1;
     static const int env_c32 = [] { const char* e = getenv("GIGA_CONV32"); return e ? atoi(e) : 1; }();
     if constexpr (C32MODE >= 0) {
         if (env_c32) {
-            auto W32 = [&](int l) { return blob + ko.conv[l].c32h; };
+            auto W32 = [&](int l) { return blob + (C32MODE == C32_SPLIT ? ko.conv[l].c32s : C32MODE == C32_BF16 ? ko.conv[l].c32b : ko.conv[l].c32h); };
             ConvArgs M[NCONV];
             for (int l = 0; l < NCONV; ++l) { M[l] = L[l]; M[l].w = W32(l); M[l].xcd_local = 0; M[l].out_pool = nullptr; }
             M[2].in0 = b + w.S0; M[2].out_pool = b + w.Q0;      // layers 2 and 4 pool their input while staging it
@@ -781,7 +796,7 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
                 return hipGetLastError() == hipSuccess ? 0 : -10;
             }
             if (pr.stage == 15) (void)hipEventRecord(pr.ev0, s);
-#define X(l, KIND, C0, C1, COUT, H, W, POOLIN, SN, SS)                                                                      \
+#define X(l, KIND, C0, C1, COUT, H, W, POOLIN, SPW, SGN, SGS, KPS)                                                          \
             if (l < nlayers) { pre(); rc |= launch_conv32<typename U32Layer<C32MODE, l>::G, U32Layer<C32MODE, l>::RELU>(M[l], s); post(); } \
             else { pre(); post(); }
             GIGA_UNET32_LAYERS(X)

@@ -57,85 +57,101 @@ static int emu_layer(const uint8_t* wimg, const float* bias, int Gimg, const flo
         int sA, sB, nsb, rows;
         G::member_rows(member, Gimg, sA, sB);
         G::sub_bands(sA, sB, nsb, rows);
+        const int sgm = G::member_sgm(member);
         for (int b = 0; b < nsb; ++b) {
             const int sb = sA + b * rows, R = (sB - sb) < rows ? (sB - sb) : rows;
             if (G::lds_bytes(R) > C32_LDS) return -1;
             if (G::lds_bytes(R) > max_lds) max_lds = G::lds_bytes(R);
-            std::memset(lds.data(), 0xFF, lds.size());          // NaN patterns: an unwritten byte that reaches a valid output is seen
-            // ---- c32_stage: thread t takes items t, t + 256, ... of the real rows; zero pixels separately ----
-            int rrA, rrB;
-            G::real_rows(sb, R, Gimg, rrA, rrB);
-            const int nA = (rrB - rrA) * G::RI;
-            std::vector<uint8_t> wrote(G::lds_bytes(R), 0);
-            for (int tid = 0; tid < G::NTHR; ++tid) {
-                typename G::Cur k = G::cur_init(rrA, tid);
-                for (int j = tid; j < nA; j += G::NTHR, G::cur_next(k)) {
-                    float x[8];
-                    const int ch0 = G::cur_ch(k);
-                    const bool first = G::C1 == 0 || ch0 < G::C0;
+            const int NT = G::n_tiles(R);
+            ntiles_total += NT;
+            const int ntb = G::batch_tiles(NT);
+            const int nbatch = (NT + ntb - 1) / ntb;
+            if (G::KP > 1 && nbatch > C32_NW) return -7;        // channel parts: one register tile per wave
+            // accumulators of every (tile, member slice): bias, then the parts in order, taps x k-chunks inside a part
+            std::vector<double> accs((size_t)NT * G::SPM * 64 * 16);
+            std::vector<int> visits((size_t)NT * G::SPM, 0);
+            for (int tt = 0; tt < NT; ++tt)
+                for (int sl = 0; sl < G::SPM; ++sl)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int r = 0; r < 16; ++r)
+                            accs[(((size_t)tt * G::SPM + sl) * 64 + lane) * 16 + r] = bias[32 * ((sgm * G::SPM + sl) % G::CS) + 16 * (lane >> 5) + r];
+            for (int part = 0; part < G::KP; ++part) {
+                std::memset(lds.data(), 0xFF, lds.size());      // NaN patterns: an unwritten byte that reaches a valid output is seen
+                // ---- c32_fill: LDS fragment c <- blob fragment fill_src(c) ----
+                for (int c = 0; c < G::WFR; ++c)
+                    std::memcpy(lds.data() + (size_t)c * 1024, wimg + (size_t)G::fill_src(c, sgm, part) * 1024, 1024);
+                // ---- c32_stage: thread t takes items t, t + NTHR, ... of the real rows; zero pixels separately ----
+                int rrA, rrB;
+                G::real_rows(sb, R, Gimg, rrA, rrB);
+                const int nA = (rrB - rrA) * G::RI;
+                std::vector<uint8_t> wrote(G::lds_bytes(R), 0);
+                const size_t IMG = G::WBYTES;
+                for (int tid = 0; tid < G::NTHR; ++tid) {
+                    typename G::Cur k = G::cur_init(rrA, tid, sb);
+                    const int ch0 = G::thr_ch(tid);
+                    const bool first = G::KP > 1 ? G::part_tensor(part) == 0 : (G::C1 == 0 || ch0 < G::C0);
                     const float* src = first ? in0 : in1;
-                    const int C = first ? G::C0 : G::C1, ch = first ? ch0 : ch0 - G::C0;
-                    if (k.g < 0 || k.g >= Gimg || k.y < 0 || k.y >= G::H || k.rr != k.g * G::H + k.y) return -2;
-                    for (int e = 0; e < 8; ++e) {
-                        float m = -INFINITY;
-                        for (int q = 0; q < (G::POOLIN ? 4 : 1); ++q) {
-                            const int pix = G::cur_src_pixel(k, q);
-                            if (pix < 0 || pix >= Gimg * G::IH * G::IW) return -2;
-                            m = std::fmax(m, src[(size_t)pix * C + ch + e]);
+                    const int C = first ? G::C0 : G::C1;
+                    const int ch = G::KP > 1 ? G::part_ch0(part) + ch0 : (first ? ch0 : ch0 - G::C0);
+                    for (int j = tid; j < nA; j += G::NTHR, G::cur_next(k)) {
+                        float x[8];
+                        if (k.y < 0 || k.y >= G::H || k.x < 0 || k.x >= G::W || k.spix != k.rr * G::W + k.x || k.rr % G::H != k.y ||
+                            k.rr < rrA || k.rr >= rrB || ch + 8 > C) return -2;
+                        for (int e = 0; e < 8; ++e) {
+                            float m = -INFINITY;
+                            for (int q = 0; q < (G::POOLIN ? 4 : 1); ++q) {
+                                const int pix = G::cur_src_pixel(k, q);
+                                if (pix < 0 || pix >= Gimg * G::IH * G::IW) return -2;
+                                m = std::fmax(m, src[(size_t)pix * C + ch + e]);
+                            }
+                            x[e] = m;
                         }
-                        x[e] = m;
-                    }
-                    if (G::POOLIN && G::cur_own(k, sb, R) && out_pool)
-                        for (int e = 0; e < 8; ++e) out_pool[(size_t)(k.rr * G::W + G::cur_x(k)) * G::C0 + ch0 + e] = x[e];
-                    const int lo = G::cur_lds(k, sb);
-                    if (lo < 0 || lo + G::ILB > G::lds_bytes(R)) return -3;
-                    uint8_t* dst = lds.data() + lo;
-                    for (int e = 0; e < G::ILB; ++e) wrote[lo + e] += 1;
-                    for (int e = 0; e < 8; ++e) {
-                        if (MODE == C32_SPLIT) {
-                            const half_t h = (half_t)x[e];
-                            const half_t l = (half_t)(x[e] - (float)h);
-                            std::memcpy(dst + 2 * e, &h, 2);
-                            std::memcpy(dst + 16 + 2 * e, &l, 2);
-                        } else {
-                            store16(dst + 2 * e, x[e], MODE);
+                        if (G::POOLIN && G::cur_own(k, sb, R) && out_pool)
+                            for (int e = 0; e < 8; ++e) out_pool[(size_t)k.spix * G::C0 + ch0 + e] = x[e];
+                        const int lo = k.lds;
+                        if (lo < G::WBYTES || lo + G::ILB > G::lds_bytes(R)) return -3;
+                        uint8_t* dst = lds.data() + lo;
+                        for (int e = 0; e < G::ILB; ++e) wrote[lo + e] += 1;
+                        for (int e = 0; e < 8; ++e) {
+                            if (MODE == C32_SPLIT) {
+                                const half_t h = (half_t)x[e];
+                                const half_t l = (half_t)(x[e] - (float)h);
+                                std::memcpy(dst + 2 * e, &h, 2);
+                                std::memcpy(dst + 16 + 2 * e, &l, 2);
+                            } else {
+                                store16(dst + 2 * e, x[e], MODE);
+                            }
                         }
                     }
                 }
-            }
-            if (G::HALO)
-                for (int q = 0; q < G::n_buf_pixels(R); ++q)
-                    if (G::pad_pixel(q, sb, Gimg)) {
-                        std::memset(lds.data() + (size_t)q * G::PS, 0, G::IPP * G::ILB);
-                        for (int e = 0; e < G::IPP * G::ILB; ++e) wrote[(size_t)q * G::PS + e] += 1;
-                    }
-            for (int q = 0; q < G::n_buf_pixels(R); ++q)        // every channel byte of every buffer pixel exactly once
-                for (int e = 0; e < G::IPP * G::ILB; ++e)
-                    if (wrote[(size_t)q * G::PS + e] != 1) return -6;
-            // ---- c32_run: waves, tiles ----
-            const int NT = G::n_tiles(R);
-            ntiles_total += NT;
-            for (int wave = 0; wave < C32_NW; ++wave) {
-                const int sg = wave % G::SG, tl = wave / G::SG;
-                for (int t0 = tl; t0 < NT; t0 += G::TL * G::NTB)
-                    for (int j = 0; j < G::NTB; ++j) {
-                        const int tt = t0 + G::TL * j;
-                        if (tt >= NT) continue;
-                        for (int s = 0; s < G::SPW; ++s) {
-                            const int slice = sg * G::SPW + s, sub = slice / G::CS, cs = slice % G::CS;
-                            std::vector<double> acc(64 * 16);
-                            for (int lane = 0; lane < 64; ++lane)
-                                for (int r = 0; r < 16; ++r) acc[lane * 16 + r] = bias[32 * cs + 16 * (lane >> 5) + r];
-                            for (int tap = 0; tap < G::TAPS; ++tap)
-                                for (int kc = 0; kc < G::KC; ++kc) {
-                                    const int f = G::frag(slice, tap, kc);
+                if (G::HALO)
+                    for (int q = 0; q < G::n_buf_pixels(R); ++q)
+                        if (G::pad_pixel(q, sb, Gimg)) {
+                            std::memset(lds.data() + IMG + (size_t)q * G::PS, 0, G::IPP * G::ILB);
+                            for (int e = 0; e < G::IPP * G::ILB; ++e) wrote[IMG + (size_t)q * G::PS + e] += 1;
+                        }
+                for (int q = 0; q < G::n_buf_pixels(R); ++q)    // every channel byte of every buffer pixel exactly once
+                    for (int e = 0; e < G::IPP * G::ILB; ++e)
+                        if (wrote[IMG + (size_t)q * G::PS + e] != 1) return -6;
+                // ---- tiles: batches of ntb tiles dealt over the eight waves; per batch all slices of the member ----
+                for (int wave = 0; wave < C32_NW; ++wave)
+                    for (int bi = wave; bi < nbatch; bi += C32_NW)
+                        for (int j = 0; j < ntb; ++j) {
+                            const int tt = bi * ntb + j;
+                            if (tt >= NT) continue;
+                            for (int sl = 0; sl < G::SPM; ++sl) {      // (pass sp = sl / SPW, slice s = sl % SPW of the register tile)
+                                double* acc = &accs[(((size_t)tt * G::SPM + sl) * 64) * 16];
+                                visits[(size_t)tt * G::SPM + sl] += 1;
+                                for (int it = 0; it < G::NIT; ++it) {
+                                    const int tap = it / G::KCP, kcp = it % G::KCP;
                                     float A[G::NOP][64][8], B[G::NOP][64][8];
                                     for (int o = 0; o < G::NOP; ++o)
                                         for (int lane = 0; lane < 64; ++lane) {
-                                            const int off = G::lane_base(lane) + tt * G::tile_step() + G::tap_off(tap) + G::kc_off(kc) + 16 * o;
-                                            if (off < 0 || off + 16 > C32_LDS) return -4;
+                                            const int off = G::lane_base(lane) + tt * G::tile_step() + G::tap_off(tap) + G::kc_off(kcp) + 16 * o;
+                                            const int woff = lane * 16 + G::w_off(sl, it, o);      // = w_off(sp * SPW, 0, 0) + w_off(s, it, o)
+                                            if (off < G::WBYTES || off + 16 > C32_LDS || woff + 16 > G::WBYTES) return -4;
                                             for (int e = 0; e < 8; ++e) {
-                                                A[o][lane][e] = load16(wimg + ((size_t)(f * G::NOP + o) * 64 + lane) * 16 + 2 * e, MODE);
+                                                A[o][lane][e] = load16(lds.data() + woff + 2 * e, MODE);
                                                 B[o][lane][e] = load16(lds.data() + off + 2 * e, MODE);
                                             }
                                         }
@@ -158,25 +174,31 @@ static int emu_layer(const uint8_t* wimg, const float* bias, int Gimg, const flo
                                         }
                                     }
                                 }
-                            // ---- epilogue ----
-                            for (int lane = 0; lane < 64; ++lane) {
-                                const int n = lane & 31, hq = lane >> 5;
-                                const typename G::Out o = G::out_pixel(tt, n, sb, R);
-                                if (!o.valid) continue;
-                                if (o.g < 0 || o.g >= Gimg || o.y >= G::H || o.x < 0) return -5;
-                                const size_t pix = (size_t)G::out_index(o.g, o.y, o.x, sub);
-                                for (int r = 0; r < 16; ++r) {
-                                    float v = (float)acc[lane * 16 + r];
-                                    if (RELU) v = v > 0.f ? v : 0.f;
-                                    if (MODE == C32_NATIVE) v = (float)(half_t)v;
-                                    const size_t idx = pix * G::COUT + 32 * cs + 16 * hq + r;
-                                    out[idx] = v;
-                                    written[idx] += 1;
-                                }
                             }
                         }
-                    }
             }
+            // ---- epilogue ----
+            for (int tt = 0; tt < NT; ++tt)
+                for (int sl = 0; sl < G::SPM; ++sl) {
+                    if (visits[(size_t)tt * G::SPM + sl] != G::KP) return -8;
+                    const int slice = sgm * G::SPM + sl, sub = slice / G::CS, cs = slice % G::CS;
+                    const double* acc = &accs[(((size_t)tt * G::SPM + sl) * 64) * 16];
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int n = lane & 31, hq = lane >> 5;
+                        const typename G::Out o = G::out_pixel(tt, n, sb, R);
+                        if (!o.valid) continue;
+                        if (o.g < 0 || o.g >= Gimg || o.y >= G::H || o.x < 0) return -5;
+                        const size_t pix = (size_t)G::out_index(o.g, o.y, o.x, sub);
+                        for (int r = 0; r < 16; ++r) {
+                            float v = (float)acc[lane * 16 + r];
+                            if (RELU) v = v > 0.f ? v : 0.f;
+                            if (MODE == C32_NATIVE) v = (float)(half_t)v;
+                            const size_t idx = pix * G::COUT + 32 * cs + 16 * hq + r;
+                            out[idx] = v;
+                            written[idx] += 1;
+                        }
+                    }
+                }
         }
     }
     if (stats) { stats[0] = max_lds; stats[1] = ntiles_total; stats[2] = G::RBMAX; stats[3] = G::PS; }
@@ -202,7 +224,7 @@ int conv32_emu_layer(int layer, int mode, const uint8_t* blob, int Gimg, const f
     if (conv32_emu_offsets(layer, mode, &w_off, &b_off)) return -10;
     const uint8_t* wimg = blob + w_off;
     const float* bias = reinterpret_cast<const float*>(blob + b_off);
-#define X(l, KIND, C0, C1, COUT, H, W, POOLIN, SN, SS)                                                                    \
+#define X(l, KIND, C0, C1, COUT, H, W, POOLIN, SPW, SGN, SGS, KPS)                                                               \
     if (layer == l) {                                                                                                    \
         if (mode == C32_NATIVE) return emu_layer<U32Layer<C32_NATIVE, l>::G, KIND == CONV3>(wimg, bias, Gimg, in0, in1, out, out_pool, written, stats); \
         if (mode == C32_SPLIT) return emu_layer<U32Layer<C32_SPLIT, l>::G, KIND == CONV3>(wimg, bias, Gimg, in0, in1, out, out_pool, written, stats);   \

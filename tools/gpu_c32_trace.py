@@ -18,7 +18,7 @@ with torch.no_grad():
     for _ in range(5):
         net.encoder.encode_nhwc(x, fold_final=True)
 torch.cuda.synchronize()
-buf = np.zeros((13, 4, 8), np.int64)
+buf = np.zeros((13, 8, 8), np.int64)
 dbg(buf.ctypes.data_as(ctypes.c_void_p))
 t0 = buf[0, :, 0].min()
 print(f"B={B} {prec}: clocks since layer 0 entry; per layer (wave 0 / slowest wave): entry | +stage issued | +stage barrier | +tiles | +stores acked | next weights requested | group barrier released")
@@ -31,4 +31,4 @@ for l in range(12):
     w5 = int(nxt[:, 5].max() - e) if nxt is not None and (nxt[:, 5] > 0).all() else -1
     w6 = int(nxt[:, 6].max() - e) if nxt is not None and (nxt[:, 6] > 0).all() else -1
     print(f"L{l:2d} entry {int(e - t0):8d} | stage issued {cols[0]:6d} | barrier {cols[1]:6d} | tiles {cols[2]:6d} | acked {cols[3]:6d} | weights {w5:6d} | released {w6:6d}"
-          f"   (tiles per wave: {' '.join(str(int(r[w, 3] - r[w, 2])) for w in range(4))})")
+          f"   (tiles per wave: {' '.join(str(int(r[w, 3] - r[w, 2])) for w in range(8))})")
