@@ -778,7 +778,8 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
         if (env_c32) {
             auto W32 = [&](int l) { return blob + (C32MODE == C32_SPLIT ? ko.conv[l].c32s : C32MODE == C32_BF16 ? ko.conv[l].c32b : ko.conv[l].c32h); };
             ConvArgs M[NCONV];
-            for (int l = 0; l < NCONV; ++l) { M[l] = L[l]; M[l].w = W32(l); M[l].xcd_local = 0; M[l].out_pool = nullptr; }
+            static const int env_sc1 = [] { const char* e = getenv("GIGA_C32_SC1"); return e ? atoi(e) : 0; }();   // (measured: the writer pays more than the reader gains)
+            for (int l = 0; l < NCONV; ++l) { M[l] = L[l]; M[l].w = W32(l); M[l].xcd_local = 0; M[l].out_pool = nullptr; M[l].c32_flags = env_sc1 ? 1 : 0; }
             M[2].in0 = b + w.S0; M[2].out_pool = b + w.Q0;      // layers 2 and 4 pool their input while staging it
             M[4].in0 = b + w.S1; M[4].out_pool = b + w.Q1;
             if (mega) {
