@@ -20,6 +20,7 @@ ENC_BF16 = 3             # encoder `precision` 3: bf16 U-Net convolutions, fp32 
 FOLD_FINAL = 16          # GIGA_FOLD_FINAL: OR-ed into `precision` of an encoder call and of the decoder calls on its planes
 PERSIST_UNET = 32        # GIGA_PERSIST_UNET: OR-ed into `precision` of an encoder call (one persistent U-Net launch)
 LAYERWISE_UNET = 64      # GIGA_LAYERWISE_UNET: one launch per U-Net layer even for small batches
+CONV32_UNET = 128        # GIGA_CONV32_UNET: the f16-class U-Net on the conv32 kernels (opt-in)
 MAX_SCENES = 3072        # GIGA_MAX_SCENES: scenes per encoder / training call (error -7 beyond)
 HEAD_BITS = {"decoder_qual": 1, "decoder_rot": 2, "decoder_width": 4, "decoder_tsdf": 8}
 PRECISION = {"fp32": 0, "fp16": 1, "fp16x3": 2, "bf16": 3}     # include/giga_hip.h `precision` (3: encoder only)

@@ -257,7 +257,8 @@ class LocalVoxelEncoder(nn.Module):
         with torch.cuda.device(x.device):      # launch on the tensors' device and ITS current stream, whatever torch's current device is
             _capi.check(L.giga_encoder_forward_probe(_capi.ptr(x), _capi.ptr(blob), _capi.ptr(nhwc), _capi.ptr(nchw),
                                                      B, prec | (_capi.FOLD_FINAL if fold_final else 0) |
-                                                     {False: 0, True: _capi.PERSIST_UNET, "layers": _capi.LAYERWISE_UNET}[getattr(self, "persistent_unet", False)],
+                                                     {False: 0, True: _capi.PERSIST_UNET, "layers": _capi.LAYERWISE_UNET}[getattr(self, "persistent_unet", False)] |
+                                                     (_capi.CONV32_UNET if getattr(self, "unet_kernel", "conv16") == "conv32" and prec in (1, 2) else 0),
                                                      _capi.ptr(ws), ws.numel(), _capi.stream_ptr(x.device),
                                                      stage, ev0, ev1),
                         "giga_encoder_forward")
@@ -518,6 +519,14 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
         the same results as per-layer launches: bit for bit in the f16-class modes, to fp32 rounding in fp32); True = the
         persistent launch also for small fp32 batches; "layers" = one launch per layer.  hipGraph capture is fine in every form."""
         self.encoder.persistent_unet = "layers" if enabled == "layers" else bool(enabled)
+        return self
+
+    def set_unet_kernel(self, kernel="conv16"):
+        """Which convolution kernels run the f16-class U-Net (include/giga_hip.h, GIGA_CONV32_UNET): "conv16" (default) or "conv32"
+        (32x32x16 MFMA register tiles over LDS-resident row bands; 'fp16' and 'fp16x3' only -- other precisions keep conv16)."""
+        if kernel not in ("conv16", "conv32"):
+            raise ValueError(kernel)
+        self.encoder.unet_kernel = kernel
         return self
 
     def _head_present(self):

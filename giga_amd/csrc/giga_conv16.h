@@ -37,7 +37,6 @@ struct ConvArgs {
     int cs0, co0, cs1, co1;              // channel stride / first channel of in0, in1 (0 stride = dense C0 / C1)
     int trace_id;                        // layer index (diagnostic builds)
     int xcd_local;                       // 1: per-layer launches map the images onto the XCDs (conv_wg_map)
-    int c32_flags;                       // conv32: bit 0 = store outputs with sc0 sc1 (write-through: the consumer's loads of the next layer return faster)
 };
 
 constexpr int MATH_NATIVE = 0, MATH_SPLIT = 1, MATH_BF16 = 2;

@@ -24,15 +24,6 @@ __device__ __forceinline__ f32x16 mfma16_bf(bf16x8v a, bf16x8v b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// 16-byte global store, optionally with the sc0 sc1 bits (system scope: written through).  tools/l2_handoff.hip: a workgroup reads
-// what a neighbour on its XCD wrote at 9.9 B/clk/CU after plain stores, 13-16 B/clk/CU after sc0 sc1 stores (the loads of the
-// next layer's staging are bound by the latency of their L1 misses, and lines written this way come back sooner).
-typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void c32_store16(void* p, u32x4v v, bool sc) {
-    if (sc) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
-    else *reinterpret_cast<u32x4v*>(p) = v;
-}
-
 #ifdef GIGA_TRACE   // diagnostic build: s_memtime stamps of member 0 of the group that holds image 0, per layer and wave
 static __device__ long long g_c32_trace[NCONV][C32_NW][8];
 #define C32_T(a, idx) do { if ((a).trace_id >= 0 && member == 0 && (threadIdx.x & 63) == 0) \
@@ -57,26 +48,21 @@ __device__ __forceinline__ void c32_fill(const ConvArgs& a, uint8_t* smem, int m
 // Thread t takes items t, t + 256, ... of the sub-band's real rows (giga_conv32_geom.h: Cur -- source and LDS offsets advance by
 // adds).  A chunk issues ALL its loads (8 / 16 / 24 items of 16 bytes per thread, chosen by what is left) before the first LDS
 // write; the zero pixels are written under the latency of the first chunk.
-template <class G, int U>
-struct C32Regs {                                                    // what a thread holds between the issue of its loads and its LDS writes
-    uint4 v[U][G::NPOS][G::VPI];
-    int lds[U];
-    uint32_t qoff[U];
-    bool ok[U], own[U];
-};
 template <class G>
 struct C32Stage {
-    static constexpr int MODE = G::MODE, ES = G::ES, NPOS = G::NPOS, VPI = G::VPI;
+    static constexpr int MODE = G::MODE, ES = G::ES;
+    static constexpr int NPOS = G::POOLIN ? 4 : 1;                  // source pixels per staged pixel
+    static constexpr int VPI = MODE == C32_NATIVE ? 1 : 2;          // 16-byte source vectors per item (8 channels)
     static constexpr int UMAX = 24 / (VPI * NPOS);                  // items per thread in flight at most
     const ConvArgs& a;
-    uint8_t* img;                                                   // LDS + byte offset of the image buffer this sub-band goes to
+    uint8_t* smem;
     const char* src;                                                // this thread's source tensor (concat: in0 or in1)
     uint32_t pixb, chb, qchb;                                       // bytes per source pixel, byte offset of the thread's 8 channels (source / pooled copy)
     int sb, R, nA, j;
     typename G::Cur k;
     bool zero_pending;
 
-    __device__ __forceinline__ C32Stage(const ConvArgs& a_, uint8_t* img_, int sb_, int R_, int part) : a(a_), img(img_), sb(sb_), R(R_) {
+    __device__ __forceinline__ C32Stage(const ConvArgs& a_, uint8_t* smem_, int sb_, int R_, int part) : a(a_), smem(smem_), sb(sb_), R(R_) {
         const int tid = threadIdx.x;
         int rrA, rrB;
         G::real_rows(sb, R, a.nimg, rrA, rrB);
@@ -99,51 +85,53 @@ struct C32Stage {
             if (G::pad_pixel(q, sb, a.nimg)) {
 #pragma unroll
                 for (int e = 0; e < G::IPP * G::ILB / 16; ++e)
-                    *reinterpret_cast<uint4*>(img + G::WBYTES + q * G::PS + 16 * e) = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4*>(smem + G::WBYTES + q * G::PS + 16 * e) = make_uint4(0, 0, 0, 0);
             }
     }
     template <int U>
-    __device__ __forceinline__ void issue(C32Regs<G, U>& r) {
+    __device__ __forceinline__ void chunk() {
+        uint4 v[U][NPOS][VPI];
+        int lds[U];
+        uint32_t qoff[U];
+        bool ok[U], own[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            r.ok[u] = j < nA;
-            r.lds[u] = k.lds;
+            ok[u] = j < nA;
+            lds[u] = k.lds;
 #pragma unroll
             for (int q = 0; q < NPOS; ++q) {
-                const uint32_t off = r.ok[u] ? __umul24((uint32_t)G::cur_src_pixel(k, q), pixb) + chb : 0u;   // (clamped: every load is issued)
+                const uint32_t off = ok[u] ? __umul24((uint32_t)G::cur_src_pixel(k, q), pixb) + chb : 0u;   // (clamped: every load is issued)
 #pragma unroll
-                for (int e = 0; e < VPI; ++e) r.v[u][q][e] = *reinterpret_cast<const uint4*>(src + off + 16 * e);
+                for (int e = 0; e < VPI; ++e) v[u][q][e] = *reinterpret_cast<const uint4*>(src + off + 16 * e);
             }
             if constexpr (G::POOLIN) {
-                r.own[u] = r.ok[u] && G::cur_own(k, sb, R);
-                r.qoff[u] = __umul24((uint32_t)k.spix, (uint32_t)G::C0 * ES) + qchb;
+                own[u] = ok[u] && G::cur_own(k, sb, R);
+                qoff[u] = __umul24((uint32_t)k.spix, (uint32_t)G::C0 * ES) + qchb;
             }
             G::cur_next(k);
             j += G::NTHR;
         }
-    }
-    template <int U>
-    __device__ __forceinline__ void commit(const C32Regs<G, U>& r) {
+        if (zero_pending) zeros();                           // under the latency of the loads
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (!r.ok[u]) continue;
-            uint8_t* dst = img + r.lds[u];
+            if (!ok[u]) continue;
+            uint8_t* dst = smem + lds[u];
             if constexpr (MODE == C32_NATIVE) {
-                half8 x = __builtin_bit_cast(half8, r.v[u][0][0]);
+                half8 x = __builtin_bit_cast(half8, v[u][0][0]);
 #pragma unroll
-                for (int q = 1; q < NPOS; ++q) x = __builtin_elementwise_max(x, __builtin_bit_cast(half8, r.v[u][q][0]));
+                for (int q = 1; q < NPOS; ++q) x = __builtin_elementwise_max(x, __builtin_bit_cast(half8, v[u][q][0]));
                 *reinterpret_cast<half8*>(dst) = x;
                 if constexpr (G::POOLIN) {
-                    if (r.own[u] && a.out_pool) *reinterpret_cast<half8*>(reinterpret_cast<char*>(a.out_pool) + r.qoff[u]) = x;
+                    if (own[u] && a.out_pool) *reinterpret_cast<half8*>(reinterpret_cast<char*>(a.out_pool) + qoff[u]) = x;
                 }
             } else {
                 float x[8];
 #pragma unroll
                 for (int e2 = 0; e2 < 2; ++e2) {
-                    f32x4v f = __builtin_bit_cast(f32x4v, r.v[u][0][e2]);
+                    f32x4v f = __builtin_bit_cast(f32x4v, v[u][0][e2]);
 #pragma unroll
                     for (int q = 1; q < NPOS; ++q) {
-                        const f32x4v g = __builtin_bit_cast(f32x4v, r.v[u][q][e2]);
+                        const f32x4v g = __builtin_bit_cast(f32x4v, v[u][q][e2]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) f[e] = __builtin_fmaxf(f[e], g[e]);
                     }
@@ -151,8 +139,8 @@ struct C32Stage {
                     for (int e = 0; e < 4; ++e) x[4 * e2 + e] = f[e];
                 }
                 if constexpr (G::POOLIN) {
-                    if (r.own[u] && a.out_pool) {
-                        float* q = reinterpret_cast<float*>(reinterpret_cast<char*>(a.out_pool) + r.qoff[u]);
+                    if (own[u] && a.out_pool) {
+                        float* q = reinterpret_cast<float*>(reinterpret_cast<char*>(a.out_pool) + qoff[u]);
                         *reinterpret_cast<float4*>(q) = make_float4(x[0], x[1], x[2], x[3]);
                         *reinterpret_cast<float4*>(q + 4) = make_float4(x[4], x[5], x[6], x[7]);
                     }
@@ -171,29 +159,20 @@ struct C32Stage {
             }
         }
     }
-    template <int U>
-    __device__ __forceinline__ void chunk() {
-        C32Regs<G, U> r;
-        issue<U>(r);
-        if (zero_pending) zeros();                           // under the latency of the loads
-        commit<U>(r);
-    }
     __device__ __forceinline__ void run() {
-        // chunk sizes: 1/6, 1/3, 2/3 and all of UMAX items per thread (4 / 8 / 16 / 24 for f16 activations)
-        constexpr int U0 = UMAX >= 6 ? UMAX / 6 : 1, U1 = UMAX >= 3 ? UMAX / 3 : 1, U2 = UMAX >= 3 ? 2 * UMAX / 3 : (UMAX >= 2 ? 2 : 1);
+        constexpr int U1 = UMAX >= 3 ? UMAX / 3 : 1, U2 = UMAX >= 3 ? 2 * UMAX / 3 : (UMAX >= 2 ? 2 : 1);
         int rem = (nA + G::NTHR - 1) / G::NTHR;              // steps of the slowest thread (uniform)
         while (rem > 0) {
             if (rem > U2 && UMAX > U2) { chunk<UMAX>(); rem -= UMAX; }
             else if (rem > U1 && U2 > U1) { chunk<U2>(); rem -= U2; }
-            else if (rem > U0 && U1 > U0) { chunk<U1>(); rem -= U1; }
-            else { chunk<U0>(); rem -= U0; }
+            else { chunk<U1>(); rem -= U1; }
         }
         if (zero_pending) zeros();
     }
 };
 template <class G>
-__device__ __forceinline__ void c32_stage(const ConvArgs& a, uint8_t* img, int sb, int R, int part = 0) {
-    C32Stage<G> st(a, img, sb, R, part);
+__device__ __forceinline__ void c32_stage(const ConvArgs& a, uint8_t* smem, int sb, int R, int part = 0) {
+    C32Stage<G> st(a, smem, sb, R, part);
     st.run();
 }
 
@@ -248,9 +227,9 @@ struct C32Tile {
     using T = std::conditional_t<G::MODE == C32_NATIVE, half_t, float>;
     f32x16 acc[NTB][G::SPW];
     int base[NTB];
-    __device__ __forceinline__ void init(const ConvArgs& a, int sgm, int sp, int t0, int NT, int ioff) {
+    __device__ __forceinline__ void init(const ConvArgs& a, int sgm, int sp, int t0, int NT) {
         const int lane = threadIdx.x & 63, hi = lane >> 5;
-        const int lbase = ioff + G::lane_base(lane);
+        const int lbase = G::lane_base(lane);
 #pragma unroll
         for (int j = 0; j < NTB; ++j) base[j] = (t0 + j < NT ? t0 + j : t0) * G::tile_step() + lbase;   // (a missing tile repeats the first; not stored)
 #pragma unroll
@@ -272,7 +251,6 @@ struct C32Tile {
     }
     __device__ __forceinline__ void store(const ConvArgs& a, int sgm, int sp, int t0, int NT, int sb, int R) {
         const int lane = threadIdx.x & 63, n = lane & 31, hi = lane >> 5;
-        const bool sc = (a.c32_flags & 1) != 0;
 #pragma unroll
         for (int j = 0; j < NTB; ++j) {
             if (t0 + j >= NT) continue;
@@ -290,12 +268,12 @@ struct C32Tile {
                     half8 h0, h1;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) { h0[r] = (half_t)v[r]; h1[r] = (half_t)v[8 + r]; }
-                    c32_store16(dst, __builtin_bit_cast(u32x4v, h0), sc);
-                    c32_store16(dst + 8, __builtin_bit_cast(u32x4v, h1), sc);
+                    *reinterpret_cast<half8*>(dst) = h0;
+                    *reinterpret_cast<half8*>(dst + 8) = h1;
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        c32_store16(dst + 4 * q, __builtin_bit_cast(u32x4v, f32x4v{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}), sc);
+                        *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
                 }
                 if constexpr (G::KIND == CONV1) {
                     if (a.out_nchw) {
@@ -311,14 +289,14 @@ struct C32Tile {
 
 // the tiles of one staged sub-band (KP == 1): batches of NTB tiles dealt over the waves, all slice passes of the member per batch
 template <class G, bool RELU, int NTB>
-__device__ __forceinline__ void c32_tiles(const ConvArgs& a, const uint8_t* smem, int ioff, int sgm, int NT, int sb, int R) {
+__device__ __forceinline__ void c32_tiles(const ConvArgs& a, const uint8_t* smem, int sgm, int NT, int sb, int R) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nbatch = (NT + NTB - 1) / NTB;
     for (int bi = wave; bi < nbatch; bi += C32_NW) {
 #pragma unroll 1
         for (int sp = 0; sp < G::NSP; ++sp) {
             C32Tile<G, RELU, NTB> t;
-            t.init(a, sgm, sp, bi * NTB, NT, ioff);
+            t.init(a, sgm, sp, bi * NTB, NT);
             t.mma(smem, sp);
             t.store(a, sgm, sp, bi * NTB, NT, sb, R);
         }
@@ -332,7 +310,7 @@ __device__ __forceinline__ void c32_parts(const ConvArgs& a, uint8_t* smem, int 
     const int sgm = G::member_sgm(member);
     const bool mine = wave * NTB < NT;
     C32Tile<G, RELU, NTB> t;
-    t.init(a, sgm, 0, wave * NTB, NT, 0);
+    t.init(a, sgm, 0, wave * NTB, NT);
 #pragma unroll 1
     for (int part = 0; part < G::KP; ++part) {
         if (part > 0 || !filled) {
@@ -353,57 +331,30 @@ template <class G, bool RELU>
 __device__ __forceinline__ void c32_run(const ConvArgs& a, uint8_t* smem, int member) {
     const int sgm = G::member_sgm(member);
     int sA, sB, nsb, rows;
-    bool db;
     G::member_rows(member, a.nimg, sA, sB);
-    G::sub_bands(sA, sB, nsb, rows, db);
+    G::sub_bands(sA, sB, nsb, rows);
     C32_T(a, 0);
-    if constexpr (G::KP > 1) {
-        for (int b = 0; b < nsb; ++b) {
-            const int sb = sA + b * rows;
-            const int R = (sB - sb) < rows ? (sB - sb) : rows;
-            const int NT = G::n_tiles(R);
-            const int ntb = G::batch_tiles(NT);
+    for (int b = 0; b < nsb; ++b) {
+        const int sb = sA + b * rows;
+        const int R = (sB - sb) < rows ? (sB - sb) : rows;
+        const int NT = G::n_tiles(R);
+        const int ntb = G::batch_tiles(NT);
+        if constexpr (G::KP > 1) {
             if (ntb == 1) c32_parts<G, RELU, 1>(a, smem, member, b == 0, NT, sb, R);
             else if (ntb == 2) c32_parts<G, RELU, 2>(a, smem, member, b == 0, NT, sb, R);
             else if constexpr (G::NTBM >= 3) c32_parts<G, RELU, 3>(a, smem, member, b == 0, NT, sb, R);
+        } else {
+            if (b > 0) __syncthreads();                    // everyone has finished reading the previous sub-band
+            c32_stage<G>(a, smem, sb, R);
+            C32_T(a, 1);
+            __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's share of the weight fill has landed
+            __syncthreads();                               // (the compiler waits for the LDS writes before the barrier)
+            C32_T(a, 2);
+            if (ntb == 1) c32_tiles<G, RELU, 1>(a, smem, sgm, NT, sb, R);
+            else if (ntb == 2) c32_tiles<G, RELU, 2>(a, smem, sgm, NT, sb, R);
+            else if constexpr (G::NTBM >= 3) c32_tiles<G, RELU, 3>(a, smem, sgm, NT, sb, R);
+            C32_T(a, 3);
         }
-    } else {
-        // Sub-band 0 is staged with everything in flight; with double buffering (db) the loads of sub-band b + 1 are issued
-        // before the tiles of sub-band b and written to the OTHER image buffer after them (its previous readers finished before
-        // the barrier that ended sub-band b - 1).
-        c32_stage<G>(a, smem + G::buf_off(db, 0), sA, (sB - sA) < rows ? (sB - sA) : rows);
-        C32_T(a, 1);
-        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's share of the weight fill has landed
-        __syncthreads();                                   // (the compiler waits for the LDS writes before the barrier)
-        C32_T(a, 2);
-        for (int b = 0; b < nsb; ++b) {
-            const int sb = sA + b * rows;
-            const int R = (sB - sb) < rows ? (sB - sb) : rows;
-            const int NT = G::n_tiles(R);
-            const int ntb = G::batch_tiles(NT);
-            const int ioff = G::buf_off(db, b);
-            auto tiles = [&]() {
-                if (ntb == 1) c32_tiles<G, RELU, 1>(a, smem, ioff, sgm, NT, sb, R);
-                else if (ntb == 2) c32_tiles<G, RELU, 2>(a, smem, ioff, sgm, NT, sb, R);
-                else if constexpr (G::NTBM >= 3) c32_tiles<G, RELU, 3>(a, smem, ioff, sgm, NT, sb, R);
-            };
-            if (b + 1 == nsb) { tiles(); break; }
-            const int sbn = sb + rows, Rn = (sB - sbn) < rows ? (sB - sbn) : rows;
-            C32Stage<G> nx(a, smem + G::buf_off(db, b + 1), sbn, Rn, 0);
-            if (db) {
-                C32Regs<G, G::UPF> pr;
-                nx.template issue<G::UPF>(pr);
-                tiles();
-                nx.zeros();
-                nx.template commit<G::UPF>(pr);
-            } else {
-                tiles();
-                __syncthreads();                           // everyone has finished reading the single image buffer
-                nx.run();
-            }
-            __syncthreads();
-        }
-        C32_T(a, 3);
     }
 }
 

@@ -112,31 +112,14 @@ struct C32 {
         sA = HALO + (band * NR) / NBANDS;
         sB = HALO + ((band + 1) * NR) / NBANDS;
     }
-    // sub-bands of a member: n bands of `rows` rows (the last one shorter).  DOUBLE-BUFFERED (db, KP == 1, bands of 8 rows and
-    // more): at least two sub-bands, each small enough that (a) two image buffers fit behind the weights and (b) ONE prefetch
-    // of UPF items per thread holds it -- the loads of sub-band b + 1 are in flight while the tiles of sub-band b run.
-    static constexpr int NPOS = POOLIN ? 4 : 1;                  // source pixels per staged pixel
-    static constexpr int VPI = MODE == C32_NATIVE ? 1 : 2;       // 16-byte source vectors per item (8 channels)
-    static constexpr int UPF = 8 / (VPI * NPOS) > 0 ? 8 / (VPI * NPOS) : 1;   // items per thread of a prefetch
-    static constexpr int RB2 = (((C32_LDS - WBYTES) / 2) / PS - C32_TAIL) / P - 2 * HALO;
-    static constexpr int RBU = UPF * (C32_NW * 64) / (W * IPP) - 2 * HALO;
-    static constexpr int RBP = RB2 < RBU ? RB2 : RBU;            // rows per double-buffered sub-band
-    static constexpr int BUFB = (((RBP > 0 ? RBP : 0) + 2 * HALO) * P + C32_TAIL) * PS;     // bytes of one image buffer (db)
-    static constexpr bool DB_OK = KP == 1 && RBP >= 2;
-    static GIGA_HD void sub_bands(int sA, int sB, int& n, int& rows, bool& db) {
+    // sub-bands of a member: n bands of `rows` rows (the last one shorter)
+    static GIGA_HD void sub_bands(int sA, int sB, int& n, int& rows) {
         const int r = sB - sA;
-        db = DB_OK && r >= 8;
-        if (db) {
-            n = (r + RBP - 1) / RBP;
-            n = n < 2 ? 2 : n;
-        } else {
-            n = (r + RBMAX - 1) / RBMAX;
-        }
+        n = (r + RBMAX - 1) / RBMAX;
         rows = n ? (r + n - 1) / n : 0;
     }
-    static GIGA_HD int buf_off(bool db, int b) { return db ? (b & 1) * BUFB : 0; }      // byte offset of sub-band b's image buffer
     static GIGA_HD int n_tiles(int R) { return (R * P - 2 * HALO + 31) / 32; }
-    static GIGA_HD int lds_bytes(int R) { return WBYTES + ((R + 2 * HALO) * P + C32_TAIL) * PS; }      // (single buffer)
+    static GIGA_HD int lds_bytes(int R) { return WBYTES + ((R + 2 * HALO) * P + C32_TAIL) * PS; }
     // tiles of a wave's register tile for a sub-band of NT tiles: as few as keep all eight waves to one batch each
     static GIGA_HD int batch_tiles(int NT) {
         const int n = (NT + C32_NW - 1) / C32_NW;

@@ -683,7 +683,7 @@ struct Probe { int stage; hipEvent_t ev0, ev1; };
 
 template <typename T, int MATH = MATH_NATIVE>
 static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc, float* planes_nchw, int B,
-                       uint8_t* ws, hipStream_t s, const Probe& pr, bool fold_final, int persist) {
+                       uint8_t* ws, hipStream_t s, const Probe& pr, bool fold_final, int persist, bool conv32) {
     constexpr bool SPLIT = MATH == MATH_SPLIT;
     int stage_no = 0;
     auto pre = [&]() { if (pr.stage == stage_no) (void)hipEventRecord(pr.ev0, s); };
@@ -771,15 +771,14 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     const bool by_default = F16CLASS || nimg >= 24;
     const bool mega = full_device && !probe_layer &&
                       (persist > 0 || (persist == 0 && (env_persist > 0 || (env_persist < 0 && by_default))));
-    // conv32 (giga_conv32.h): the f16-class modes.  GIGA_CONV32=0 keeps conv16 (A/B runs).
+    // conv32 (giga_conv32.h): the f16-class modes, opt-in per call (GIGA_CONV32_UNET) or per process (GIGA_CONV32=1).
     constexpr int C32MODE = sizeof(T) == 2 ? C32_NATIVE : MATH == MATH_SPLIT ? C32_SPLIT : -1;
-    static const int env_c32 = [] { const char* e = getenv("GIGA_CONV32"); return e ? atoi(e) : 1; }();
+    static const int env_c32 = [] { const char* e = getenv("GIGA_CONV32"); return e ? atoi(e) : 0; }();
     if constexpr (C32MODE >= 0) {
-        if (env_c32) {
+        if (env_c32 || conv32) {
             auto W32 = [&](int l) { return blob + (C32MODE == C32_SPLIT ? ko.conv[l].c32s : C32MODE == C32_BF16 ? ko.conv[l].c32b : ko.conv[l].c32h); };
             ConvArgs M[NCONV];
-            static const int env_sc1 = [] { const char* e = getenv("GIGA_C32_SC1"); return e ? atoi(e) : 0; }();   // (measured: the writer pays more than the reader gains)
-            for (int l = 0; l < NCONV; ++l) { M[l] = L[l]; M[l].w = W32(l); M[l].xcd_local = 0; M[l].out_pool = nullptr; M[l].c32_flags = env_sc1 ? 1 : 0; }
+            for (int l = 0; l < NCONV; ++l) { M[l] = L[l]; M[l].w = W32(l); M[l].xcd_local = 0; M[l].out_pool = nullptr; }
             M[2].in0 = b + w.S0; M[2].out_pool = b + w.Q0;      // layers 2 and 4 pool their input while staging it
             M[4].in0 = b + w.S1; M[4].out_pool = b + w.Q1;
             if (mega) {
@@ -839,11 +838,12 @@ int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, fl
     Probe pr{ev0 && ev1 ? probe_stage : -1, static_cast<hipEvent_t>(ev0), static_cast<hipEvent_t>(ev1)};
     const bool fold = (precision & GIGA_FOLD_FINAL) != 0;
     const int persist = (precision & GIGA_LAYERWISE_UNET) ? -1 : (precision & GIGA_PERSIST_UNET) ? 1 : 0;   // -1 per-layer launches, 0 auto, 1 persistent
-    const int prec = precision & ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET);
-    if (prec == 2) return encoder_run<float, MATH_SPLIT>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist);
-    if (prec == 3) return encoder_run<float, MATH_BF16>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist);
-    return prec == 1 ? encoder_run<half_t>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist)
-                     : encoder_run<float>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist);
+    const int prec = precision & ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET);
+    const bool c32 = (precision & GIGA_CONV32_UNET) != 0;
+    if (prec == 2) return encoder_run<float, MATH_SPLIT>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32);
+    if (prec == 3) return encoder_run<float, MATH_BF16>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32);
+    return prec == 1 ? encoder_run<half_t>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32)
+                     : encoder_run<float>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32);
 }
 
 }  // namespace giga

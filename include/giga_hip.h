@@ -130,6 +130,14 @@ int giga_decoder_forward(const void* planes_nhwc, const float* p, const void* pa
  *   GIGA_PERSIST_UNET: the persistent launch also where the default keeps per-layer launches (precisions 0 / 3 below 8 scenes). */
 #define GIGA_PERSIST_UNET 32
 #define GIGA_LAYERWISE_UNET 64
+/* GIGA_CONV32_UNET, OR-ed into `precision` (1 or 2) of giga_encoder_forward*: the U-Net layers run on the conv32 kernels
+ * (csrc/giga_conv32.h: v_mfma_f32_32x32x16, a member of a group owns a band of ROWS of the group's images -- staged once per layer
+ * into LDS -- and one LDS-DMA copy of its weights; register tiles fed by conflict-free ds_read_b128 at `base + immediate`, no VALU
+ * in the MFMA loop) instead of conv16 (16x16x32, wave-private patches).  Same arithmetic per layer (f16 / f16x3 operands, fp32
+ * accumulation, outputs within one rounding of conv16's), same launch forms, same workspace.  Opt-in (the environment variable
+ * GIGA_CONV32=1 does the same for a whole process): measured equal to conv16 end to end -- both are bound by the four dependent
+ * L2 / fabric round trips of a layer boundary, not by the matrix pipe. */
+#define GIGA_CONV32_UNET 128
 
 /* Inference fast path for the FIXED QUERY LATTICE of VGNImplicit (detection_implicit.py:28-31,107):
  * the R^3 points meshgrid(lin, lin, lin, 'ij') with z fastest, shared by all B scenes.  Each plane is

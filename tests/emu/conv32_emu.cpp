@@ -55,16 +55,13 @@ static int emu_layer(const uint8_t* wimg, const float* bias, int Gimg, const flo
     int max_lds = 0, ntiles_total = 0;
     for (int member = 0; member < C32_GROUP; ++member) {
         int sA, sB, nsb, rows;
-        bool db;
         G::member_rows(member, Gimg, sA, sB);
-        G::sub_bands(sA, sB, nsb, rows, db);
+        G::sub_bands(sA, sB, nsb, rows);
         const int sgm = G::member_sgm(member);
         for (int b = 0; b < nsb; ++b) {
             const int sb = sA + b * rows, R = (sB - sb) < rows ? (sB - sb) : rows;
-            const int IOFF = G::buf_off(db, b);                 // double buffering: sub-bands alternate between two image buffers
-            if (IOFF + G::lds_bytes(R) > C32_LDS) return -1;
-            if (db && G::lds_bytes(R) - G::WBYTES > G::BUFB) return -9;
-            if (IOFF + G::lds_bytes(R) > max_lds) max_lds = IOFF + G::lds_bytes(R);
+            if (G::lds_bytes(R) > C32_LDS) return -1;
+            if (G::lds_bytes(R) > max_lds) max_lds = G::lds_bytes(R);
             const int NT = G::n_tiles(R);
             ntiles_total += NT;
             const int ntb = G::batch_tiles(NT);
@@ -87,9 +84,8 @@ static int emu_layer(const uint8_t* wimg, const float* bias, int Gimg, const flo
                 int rrA, rrB;
                 G::real_rows(sb, R, Gimg, rrA, rrB);
                 const int nA = (rrB - rrA) * G::RI;
-                if (db && b > 0 && (nA + G::NTHR - 1) / G::NTHR > G::UPF) return -9;     // a prefetch holds UPF items per thread
-                std::vector<uint8_t> wrote(IOFF + G::lds_bytes(R), 0);
-                const size_t IMG = IOFF + G::WBYTES;
+                std::vector<uint8_t> wrote(G::lds_bytes(R), 0);
+                const size_t IMG = G::WBYTES;
                 for (int tid = 0; tid < G::NTHR; ++tid) {
                     typename G::Cur k = G::cur_init(rrA, tid, sb);
                     const int ch0 = G::thr_ch(tid);
@@ -112,8 +108,8 @@ static int emu_layer(const uint8_t* wimg, const float* bias, int Gimg, const flo
                         }
                         if (G::POOLIN && G::cur_own(k, sb, R) && out_pool)
                             for (int e = 0; e < 8; ++e) out_pool[(size_t)k.spix * G::C0 + ch0 + e] = x[e];
-                        const int lo = IOFF + k.lds;
-                        if (lo < G::WBYTES || lo + G::ILB > IOFF + G::lds_bytes(R)) return -3;
+                        const int lo = k.lds;
+                        if (lo < G::WBYTES || lo + G::ILB > G::lds_bytes(R)) return -3;
                         uint8_t* dst = lds.data() + lo;
                         for (int e = 0; e < G::ILB; ++e) wrote[lo + e] += 1;
                         for (int e = 0; e < 8; ++e) {
@@ -151,7 +147,7 @@ static int emu_layer(const uint8_t* wimg, const float* bias, int Gimg, const flo
                                     float A[G::NOP][64][8], B[G::NOP][64][8];
                                     for (int o = 0; o < G::NOP; ++o)
                                         for (int lane = 0; lane < 64; ++lane) {
-                                            const int off = IOFF + G::lane_base(lane) + tt * G::tile_step() + G::tap_off(tap) + G::kc_off(kcp) + 16 * o;
+                                            const int off = G::lane_base(lane) + tt * G::tile_step() + G::tap_off(tap) + G::kc_off(kcp) + 16 * o;
                                             const int woff = lane * 16 + G::w_off(sl, it, o);      // = w_off(sp * SPW, 0, 0) + w_off(s, it, o)
                                             if (off < G::WBYTES || off + 16 > C32_LDS || woff + 16 > G::WBYTES) return -4;
                                             for (int e = 0; e < 8; ++e) {
