@@ -301,6 +301,8 @@ def main():
     # that one rank never enters (an exception elsewhere, a wedged RCCL ring) must not cost the scaling run its numbers.
     out = core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, dec_occ_ms, dom, dom_ms, step_ms, named_ms, bracket_ms,
                       launches_per_step, unet_ms, persistent_unet) if rank == 0 else None
+    if rank == 0:                          # (untimed) scene 0 of the headline step's own output against the CPU oracle
+        out["checked_vs_oracle"] = check_c2_scene(step(), sd, x, pos, pos_occ)
     extra = dict(multi)
     if dist is not None and not args.no_extra:
         import threading
@@ -681,6 +683,79 @@ def check_c4_scene(out, prec, synth):
     return {"scene": 1000, "points": 64000, "max_abs_err": errs, "tolerance": C4_TOL[prec]}
 
 
+def check_c2_scene(out, sd, x, pos, pos_occ):
+    """The oracle as the CHECKER of the headline step (c2, strict fp32): the first scene of this rank's batch, its single grasp query
+    (qual, rot, width) and its 2048 occupancy logits, against `O.model_forward` (conv_onet/models/__init__.py:42-67 restated) at the
+    fp32 tolerance of tests/test_gpu_parity.py.  Raises if out of tolerance."""
+    from oracle import giga_oracle as O
+    with torch.no_grad():
+        ref = O.model_forward(sd, x[0:1].cpu(), pos[0:1].cpu(), p_tsdf=pos_occ[0:1].cpu())
+    errs = {}
+    for name, got, want, tol in zip(("qual", "rot", "width", "tsdf"), out, ref, (1e-4, 2e-4, 2e-4, 2e-4)):
+        e = float((got[0:1].float().cpu() - want).abs().max())
+        errs[name] = e
+        if not e < tol:
+            raise AssertionError(f"c2 fp32: {name} of scene 0 is {e:.3e} off the oracle (tolerance {tol:.0e})")
+    return {"scene": "first scene of rank 0's shard", "max_abs_err": errs, "tolerance": 1e-4}
+
+
+def bench_c4_generic(net, dev, L, _capi, synth, decode_heads, prec, Bc=32, steps=8):
+    """c4 with ARBITRARY query points: 64 000 random queries per scene (each scene its own set) instead of the 40^3 inference lattice,
+    i.e. LocalDecoder.forward with a general `p` (decoder.py:133-176): bilinear gathers from the planes, no separable-fc_c shortcut.
+    The decoder here is `decoder_f16_kernel` (fp16: shared-feature kernel) / `decoder_f16s_kernel` (fp16x3: head-resident), the
+    kernels the lattice legs do NOT time.  Scene 0 of the step's own output is checked against the oracle afterwards."""
+    N = 64000
+    net.set_precision(prec)
+    blob = net.packed_blob(dev)
+    x = torch.from_numpy(synth.tsdf_batch(1000, Bc)).to(dev)
+    p = torch.from_numpy(synth.query_points(1000, Bc, N, stream=5)).to(dev)
+    ev = [(L.giga_event_create(), L.giga_event_create()) for _ in range(steps)]
+
+    def step(pr=None):
+        with torch.no_grad():
+            nhwc, _ = net.encoder.encode_nhwc(x, blob=blob, precision=prec, fold_final=True)
+            return decode_heads(nhwc, p, blob, 7, prec, True, probe=pr, folded=True)
+
+    _settle()
+    _rewarm(step, 6)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(ev[i])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ms = ctypes.c_float()
+    dms = []
+    for a, b in ev:
+        _capi.check(L.giga_event_elapsed_ms(a, b, ctypes.byref(ms)), "event")
+        dms.append(ms.value)
+        L.giga_event_destroy(a); L.giga_event_destroy(b)
+    dec_ms = float(np.median(dms))
+    out = step()
+    from oracle import giga_oracle as O
+    from giga_amd import weights
+    with torch.no_grad():
+        ref = O.model_forward(weights.make_state_dict(7), x[0:1].cpu(), p[0:1].cpu())
+    errs = {}
+    for name, key, want, scale in zip(("qual", "rot", "width"), ("decoder_qual", "decoder_rot", "decoder_width"), ref, (1.0, 2.0, 2.0)):
+        e = float((out[key][0:1].float().cpu() - want).abs().max())
+        errs[name] = e
+        if not e < C4_TOL[prec] * scale:
+            raise AssertionError(f"c4 generic {prec}: {name} of scene 0 is {e:.3e} off the oracle (tolerance {C4_TOL[prec] * scale:.0e})")
+    net.set_precision("fp32")
+    flops = Bc * N * FLOP_GRASP3
+    ach = flops / (dec_ms * 1e-3) / 1e12
+    split = prec == "fp16x3"
+    return {"workload": f"c4 with arbitrary queries: batch={Bc} scenes x 64000 random query points each, 3 grasp heads, {prec}",
+            "checked_vs_oracle": {"scene": 1000, "points": N, "max_abs_err": errs, "tolerance": C4_TOL[prec]},
+            "within_1e-3_contract": split,
+            "scenes_per_sec": Bc * steps / el, "query_points_per_sec": Bc * steps * N / el, "ms_per_step": el / steps * 1e3,
+            "roofline": {"kernel": "decoder_f16s_kernel" if split else "decoder_f16_kernel", "bound": "mfma", "achieved": ach,
+                         "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+                         "avg_launch_ms": dec_ms, "flops_per_launch": flops,
+                         "issued_mfma_frac_of_peak": ach * (162.0 / 58.0 if split else 1.0) / PEAK_F16_MFMA_TFLOPS,
+                         "note": "generic gather path: 58 f16 MFMAs per 32-point tile and head (162 in the split mode: three per operand pair)"}}
+
+
 def bench_c4_all(net, dev, L, _capi, synth, decode_heads):
     out = {}
     # for comparison: the same legs with one launch per U-Net layer (GIGA_LAYERWISE_UNET) instead of the default persistent launch
@@ -703,6 +778,17 @@ def bench_c4_all(net, dev, L, _capi, synth, decode_heads):
                           "checked_vs_oracle_max_abs_err": r["checked_vs_oracle"]["max_abs_err"]})
         out[key + "_sweep"] = sweep
         out[key + "_single_scene_graph_replay"] = bench_c4_graph(net, dev, synth, decode_heads, prec)
+        out[key + "_generic_queries"] = bench_c4_generic(net, dev, L, _capi, synth, decode_heads, prec)
+    # Which of the two c4 modes is inside the north star's 1e-3: ONLY the split mode.  Plain f16 (`c4`) is a throughput mode: its
+    # head outputs are 1e-3 ... 1e-2 off the fp32 reference (11-bit operands in encoder and decoder; tests/test_f16_error_budget.py),
+    # so the >= 40 % of MFMA peak it reaches is not a contract-grade figure; `c4_fp16x3` (<= 1e-5) is.
+    out["c4"]["within_1e-3_contract"] = False
+    out["c4_fp16x3"]["within_1e-3_contract"] = True
+    out["c4_contract_note"] = ("c4 (plain f16): decoder %.3f of the f16 MFMA peak, NOT within the 1e-3 contract (max errors vs oracle %s); "
+                               "c4_fp16x3: %.3f algorithmic (%.3f issued), within the contract (max errors %s)" % (
+                                   out["c4"]["roofline"]["frac"], out["c4"]["checked_vs_oracle"]["max_abs_err"],
+                                   out["c4_fp16x3"]["roofline"]["frac"], out["c4_fp16x3"]["roofline"].get("issued_mfma_frac_of_peak", 0.0),
+                                   out["c4_fp16x3"]["checked_vs_oracle"]["max_abs_err"]))
     return out
 
 

@@ -41,10 +41,11 @@ def build(force=False, verbose=False):
             sys.stderr.write((r.stdout or "") + (r.stderr or ""))
             raise RuntimeError("hipcc build of examples/c_abi_demo.cpp failed")
     # the standalone micro-benchmarks behind the hardware figures quoted in DESIGN.md (tools/*.hip): sustained MFMA / HBM
-    # peaks, fp32 MFMA vs VALU co-execution and per-instruction issue cost, the XCD-local barrier, f16 MFMA denormals
+    # peaks, fp32 MFMA vs VALU co-execution and per-instruction issue cost, the XCD-local barrier, f16 MFMA denormals, the issue cost
+    # of the f16 chains' VALU instructions, the read rate of a layer-to-layer hand-off through one XCD's L2
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tools = os.path.join(os.path.dirname(HERE), "tools")
-    for name in ("mfma_peak", "mfma_valu_overlap", "mfma_issue_cost", "xcd_barrier", "mfma_denorm"):
+    for name in ("mfma_peak", "mfma_valu_overlap", "mfma_issue_cost", "xcd_barrier", "mfma_denorm", "valu_f16_cost", "l2_handoff"):
         src, out = os.path.join(tools, name + ".hip"), os.path.join(HERE, "lib", name)
         if os.path.exists(src) and (force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src)):
             r = subprocess.run([hipcc, "-O2", "--offload-arch=gfx950", src, "-o", out], capture_output=not verbose, text=True)

@@ -517,7 +517,9 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
         """How the U-Net layers are launched (include/giga_hip.h, GIGA_PERSIST_UNET / GIGA_LAYERWISE_UNET): False = the default
         (one persistent launch for the whole U-Net -- every batch size in the f16-class modes, from 8 scenes up in fp32 -- with
         the same results as per-layer launches: bit for bit in the f16-class modes, to fp32 rounding in fp32); True = the
-        persistent launch also for small fp32 batches; "layers" = one launch per layer.  hipGraph capture is fine in every form."""
+        persistent launch also for small fp32 batches; "layers" = one launch per layer.  hipGraph capture is fine in every form.
+        At most four persistent launches are in flight per device: the library gives a fifth concurrent call (other streams) one
+        launch per layer on its own; other processes sharing the device and concurrent replays of captured graphs are not seen."""
         self.encoder.persistent_unet = "layers" if enabled == "layers" else bool(enabled)
         return self
 
@@ -690,6 +692,8 @@ class ConvolutionalOccupancyNetworkGeometry(_ParamListCache, nn.Module):
         self._packed = _PackedWeights()
 
     def set_precision(self, precision):
+        if precision not in _capi.PRECISION:
+            raise ValueError(precision)
         self.precision = precision
         self.decoder_tsdf.precision = precision
         self.encoder.precision = precision

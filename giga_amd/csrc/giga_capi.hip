@@ -340,6 +340,7 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
         const bool runs = (head_present >> h & 1) && (h < 3 ? N > 0 : (M > 0 && p_tsdf != nullptr));
         if (runs && (!outs[h] || !douts[h])) return -6;
     }
+    if ((head_present & 7) && N > 0 && !p) return -1;                   // (every argument is checked before anything is enqueued)
     if (workspace_bytes < giga_backward_workspace_bytes(B, N, M, head_present)) return -4;
     hipStream_t s = static_cast<hipStream_t>(stream);
     uint8_t* ws = static_cast<uint8_t*>(workspace);
@@ -361,7 +362,6 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
                                       detach_occ ? nullptr : gplanes, grads, head_present, scratch, B, M, s, occ_writes);
     }
     if ((head_present & 7) && N > 0) {
-        if (!p) return -1;
         rc |= launch_decoder_backward(static_cast<const float*>(planes_nhwc), p, blob, bblob, head_present & 7, outs,
                                       douts, gplanes, grads, head_present, scratch, B, N, s, false);
     }

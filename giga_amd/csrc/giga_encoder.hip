@@ -6,6 +6,7 @@
 // Kernel 1 (convin_project_kernel) fuses the 3-D conv, the ReLU and the three axis means, so the
 // 32x40^3 feature volume (8.2 MB/scene in the reference) is never written to memory.  Kernel 2
 // (conv16_kernel) is one LDS-staged implicit-GEMM convolution used for every U-Net layer.
+#include <atomic>
 #include <cstdlib>
 
 #include "../../include/giga_hip.h"
@@ -466,6 +467,11 @@ constexpr int MEGA_GROUP = 8;                     // workgroups per group
 constexpr int MEGA_SLOTS = 4;                     // group slots per XCD at most: 8 x 4 x 8 = 256 workgroups, one per CU
 constexpr int MEGA_GROUP_MAX_IMG = 32;            // default form of the f16-class modes up to 32 images (one image per group)
 constexpr int MEGA_NW = CONV_NW;                  // waves per workgroup of the persistent kernel
+// A barrier wait is bounded by WALL CLOCK (s_memrealtime, 100 MHz): 20 s.  A group's partners can be late for honest reasons -- a long
+// kernel of another stream holding the CUs they need -- and a spin COUNT (rounds 2-3: 2^24 polls, a few seconds) does not
+// distinguish that from a group that can never fill.
+constexpr unsigned long long MEGA_SPIN_TICKS = 20ull * 100000000ull;
+constexpr int MEGA_MAX_IN_FLIGHT = 4;             // persistent launches in flight per device (see persistent_slot below)
 
 template <typename T, int MATH>
 constexpr size_t mega_lds_bytes() {
@@ -488,10 +494,10 @@ __device__ __forceinline__ void xcd_barrier(unsigned* counter, unsigned target, 
     //  release -- measured no gain for groups of 8 workgroups and made a barrier among 32 workgroups slower: 384 pollers on one L2 line.)
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // performed in this XCD's L2
-        unsigned spins = 0;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz, independent of the shader clock
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {   // an L2 read
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 24)) __builtin_trap();       // a few seconds (an L2 round trip + s_sleep per spin): fail loudly, never hang the device
+            if (__builtin_amdgcn_s_memrealtime() - t0 > MEGA_SPIN_TICKS) __builtin_trap();   // fail loudly, never hang the device
         }
     }
     __syncthreads();
@@ -507,10 +513,10 @@ __device__ __forceinline__ void xcd_arrive(unsigned* counter) {
 }
 __device__ __forceinline__ void xcd_wait(unsigned* counter, unsigned target) {
     if (threadIdx.x == 0) {
-        unsigned spins = 0;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {   // an L2 read
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 24)) __builtin_trap();       // fail loudly, never hang the device
+            if (__builtin_amdgcn_s_memrealtime() - t0 > MEGA_SPIN_TICKS) __builtin_trap();   // fail loudly, never hang the device
         }
     }
     __syncthreads();
@@ -677,6 +683,50 @@ __global__ __launch_bounds__(C32_NW * 64) void unet32_mega_kernel(MegaArgs m) {
 #undef RUN
 }
 
+// ----------------------------------------------------------------------------------------------------
+// How many persistent U-Net launches may be in flight on one device.  A launch holds at most ONE unfilled group (<= 7 workgroups)
+// per XCD while its remaining workgroups wait to become resident, and an XCD has 32 workgroup slots for these kernels (one per CU:
+// 100-160 KiB of LDS each).  Four launches can park at most 4 x 7 = 28 < 32 slots in unfilled groups, so some group can always
+// fill and finish; five or more could park 35 > 32 and every barrier would run into its time-out.  The library therefore keeps,
+// per device, the completion events of its last MEGA_MAX_IN_FLIGHT persistent launches; when the oldest of them has not finished,
+// the call takes one launch per layer instead (same results).  This is process-local: other PROCESSES sharing the device are not
+// seen (include/giga_hip.h states the bound).  Streams that are being captured into a hipGraph are not tracked (an event cannot
+// be queried there): a captured call keeps the persistent form, and replays on several streams at once are the caller's to bound.
+// ----------------------------------------------------------------------------------------------------
+struct MegaSlots {
+    std::atomic_flag busy = ATOMIC_FLAG_INIT;
+    hipEvent_t ev[MEGA_MAX_IN_FLIGHT] = {};
+    bool used[MEGA_MAX_IN_FLIGHT] = {};
+    int head = 0;
+};
+static MegaSlots g_mega_slots[16];
+// returns the slot to record after the launch (>= 0), -1 if the persistent form must not be used now, -2 if untracked (capture)
+static int persistent_slot(hipStream_t s) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return -2;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -1;
+    MegaSlots& m = g_mega_slots[dev];
+    while (m.busy.test_and_set(std::memory_order_acquire)) {}
+    int slot = m.head;
+    if (m.used[slot] && hipEventQuery(m.ev[slot]) != hipSuccess) slot = -1;         // the oldest tracked launch is still running
+    else {
+        if (!m.ev[slot] && hipEventCreateWithFlags(&m.ev[slot], hipEventDisableTiming) != hipSuccess) slot = -1;
+        else { m.used[slot] = false; m.head = (slot + 1) % MEGA_MAX_IN_FLIGHT; }
+    }
+    m.busy.clear(std::memory_order_release);
+    return slot;
+}
+static void persistent_launched(int slot, hipStream_t s) {
+    if (slot < 0) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
+    MegaSlots& m = g_mega_slots[dev];
+    while (m.busy.test_and_set(std::memory_order_acquire)) {}
+    if (hipEventRecord(m.ev[slot], s) == hipSuccess) m.used[slot] = true;
+    m.busy.clear(std::memory_order_release);
+}
+
 // probe: if probe_stage == k, ev0/ev1 (hipEvent_t) are recorded right before / after launch k
 // (k = 0 conv_in+project, 1 plane_finalize, 2..14 = U-Net layers 0..12).
 struct Probe { int stage; hipEvent_t ev0, ev1; };
@@ -769,8 +819,10 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     constexpr bool F16CLASS = sizeof(T) == 2 || MATH == MATH_SPLIT;
     const bool probe_layer = pr.stage >= 2 && pr.stage <= 14;
     const bool by_default = F16CLASS || nimg >= 24;
-    const bool mega = full_device && !probe_layer &&
-                      (persist > 0 || (persist == 0 && (env_persist > 0 || (env_persist < 0 && by_default))));
+    bool mega = full_device && !probe_layer &&
+                (persist > 0 || (persist == 0 && (env_persist > 0 || (env_persist < 0 && by_default))));
+    int mega_slot = -2;
+    if (mega) { mega_slot = persistent_slot(s); mega = mega_slot != -1; }        // at most MEGA_MAX_IN_FLIGHT persistent launches in flight
     // conv32 (giga_conv32.h): the f16-class modes, opt-in per call (GIGA_CONV32_UNET) or per process (GIGA_CONV32=1).
     constexpr int C32MODE = sizeof(T) == 2 ? C32_NATIVE : MATH == MATH_SPLIT ? C32_SPLIT : -1;
     static const int env_c32 = [] { const char* e = getenv("GIGA_CONV32"); return e ? atoi(e) : 0; }();
@@ -792,6 +844,7 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
                 stage_no = 15;
                 pre();
                 GIGA_LAUNCH(kern, dim3(grid), dim3(C32_NW * 64), C32_LDS, s, m);
+                persistent_launched(mega_slot, s);
                 post();
                 return hipGetLastError() == hipSuccess ? 0 : -10;
             }
@@ -819,6 +872,7 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
         stage_no = 15;                                        // probe stage 15 = the whole U-Net
         pre();
         GIGA_LAUNCH(kern, dim3(grid), dim3(MEGA_NW * 64), lds, s, m);
+        persistent_launched(mega_slot, s);
         post();
         return hipGetLastError() == hipSuccess ? 0 : -10;
     }

@@ -33,8 +33,12 @@ inline void dyn_lds_once(const void* kern, int bytes) {
             if (keys[h].compare_exchange_strong(expect, key, std::memory_order_acq_rel) || expect == key) break;
         }
     }
-    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (keys[h].load(std::memory_order_relaxed) == key) vals[h].store(bytes, std::memory_order_relaxed);
+    // (recorded only when the runtime accepted it: a failed set is retried by the next launch instead of being remembered as done.
+    //  The record lives as long as the process: after hipDeviceReset the attribute is gone while the record stays -- a caller that
+    //  resets devices must reload the library.)
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+        keys[h].load(std::memory_order_relaxed) == key)
+        vals[h].store(bytes, std::memory_order_relaxed);
 }
 }  // namespace giga
 #define GIGA_LAUNCH(...) \

@@ -386,11 +386,15 @@ class GraspOccRing:
                 self._free(slot)
             ready.clear()
             import queue as _queue
+            waited = 0.0
             while received < submitted and self._procs:
                 try:
-                    ep, _k, slot, _n, _err = self._done.get(timeout=30.0 if not failed else 5.0)
+                    ep, _k, slot, _n, _err = self._done.get(timeout=0.25)
                 except _queue.Empty:
-                    break                                     # a reader died: its slot is lost, the ring keeps the others
+                    waited += 0.25                            # a dead reader never answers: its slot is lost, the ring keeps the
+                    if waited >= (5.0 if failed else 30.0) or not all(p.is_alive() for p in self._procs):   # others; do not sit out the
+                        break                                 # whole time-out for it
+                    continue
                 self._free(slot)
                 if ep == epoch:
                     received += 1

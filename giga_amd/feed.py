@@ -94,10 +94,7 @@ class TSDFFeed:
                     if stop.is_set():                         # the consumer left: hand every host slot we still hold back
                         if hasattr(item, "release"):
                             item.release()
-                        for ev, rb in pending:
-                            ev.synchronize()
-                            rb.release()
-                        return
+                        return                                # (the `finally` below releases the pending slots)
                     while pending and (pending[0][0].query() or len(pending) >= 2):   # hand host slots back early: the ring must not run dry
                         ev, rb = pending.pop(0)
                         ev.synchronize()
@@ -116,12 +113,17 @@ class TSDFFeed:
                         pending.append((slot.copied, item))
                     out.put(("ok", (dev_item, slot)))         # blocks while `depth` batches are waiting: the ring never laps
                     n += 1
-                for ev, rb in pending:
-                    ev.synchronize()
-                    rb.release()
             out.put(("end", None))
         except BaseException as e:  # noqa: BLE001  (re-raised in the consumer)
             out.put(("err", e))
+        finally:                                              # on EVERY path -- end of data, stop, an error in a DMA or stage step --
+            for ev, rb in pending:                            # the ring slots whose copies are still in flight go back to the readers
+                try:
+                    ev.synchronize()
+                except Exception:  # noqa: BLE001  (a failed copy must not strand the slot)
+                    pass
+                rb.release()
+            pending.clear()
 
     # -- consumer -----------------------------------------------------------------------------------------
     def __iter__(self):

@@ -8,8 +8,10 @@
  *
  * Conventions
  *   - plain pointers and sizes only; every device buffer is owned by the caller (PyTorch);
- *     the library never allocates device memory and keeps no mutable global state, so it is
- *     re-entrant per (stream, workspace);
+ *     the library never allocates device memory and is re-entrant per (stream, workspace).  Its only
+ *     process-wide mutable state is bookkeeping, never read by the arithmetic: the launch counter
+ *     (giga_launch_count), the per-kernel record of raised dynamic-LDS limits, and per device the
+ *     completion events of its last four persistent U-Net launches (see GIGA_PERSIST_UNET);
  *   - every launch is asynchronous on the caller's HIP stream `stream` (a hipStream_t);
  *   - return value 0 = success, negative = error (giga_strerror); nothing throws across the ABI;
  *   - at most GIGA_MAX_SCENES scenes per encoder / training call (the convolution kernels address activations with
@@ -122,9 +124,14 @@ int giga_decoder_forward(const void* planes_nhwc, const float* p, const void* pa
  * costs a 1-us barrier instead of a launch: the whole encoder takes 75 instead of 94 us for one scene in precision 1 (the
  * planner of detection_implicit.py:99-113 runs one scene at a time), 130 instead of 150 us at 32 scenes, 361 instead of 378 in
  * precision 0.  The workgroups of a group find each other by ticket among the workgroups already resident on their XCD, so
- * several such launches may be in flight on one device (other streams, other processes) without waiting on each other's CUs;
- * a group that cannot fill (an XCD that is handed fewer workgroups than the others) traps after a few seconds instead of
- * returning stale data.
+ * such launches may be in flight on several streams of one device without waiting on each other's CUs -- UP TO FOUR of them: a
+ * launch can hold one unfilled group (<= 7 workgroups) per XCD, an XCD has 32 slots for these workgroups, and 5 x 7 > 32 could
+ * park every slot in groups that never fill.  The library enforces the bound inside a process: it tracks the completion events of
+ * its last four persistent launches per device, and a call that would be the fifth in flight takes one launch per layer instead
+ * (same results).  It cannot see OTHER PROCESSES that share the device, nor replays of captured hipGraphs on several streams at
+ * once: keep those to four concurrent encoder calls, or pass GIGA_LAYERWISE_UNET.  The kernel also assumes that every XCD
+ * receives an eighth of the grid (no CU mask on the stream, a whole MI355X: 256 CUs -- checked -- in one partition).  A barrier
+ * that is not released within 20 s of wall clock (s_memrealtime) traps instead of returning stale data or hanging the device.
  *   GIGA_LAYERWISE_UNET, OR-ed into `precision` of giga_encoder_forward*: one launch per layer (A/B comparisons; the environment
  *   variable GIGA_UNET_PERSIST=0 does the same for a whole process).
  *   GIGA_PERSIST_UNET: the persistent launch also where the default keeps per-layer launches (precisions 0 / 3 below 8 scenes). */
@@ -264,13 +271,13 @@ int giga_grasp_select(const float* tsdf, const float* qual, const float* rot, co
                       float* cand_score, float* cand_rot, float* cand_width, void* workspace,
                       size_t workspace_bytes, void* stream);
 
-/* ---- measurement hooks (bench.py roofline): HIP events recorded on `stream` right before and
- * after ONE kernel launch, so the kernel's duration is measured live on the stream it runs on.
- * probe_stage: 0 conv_in+project, 1 plane_finalize, 2..14 = U-Net layers 0..12 (giga_layout.h kConv).
- * The decoder variant brackets the single fused decoder launch. */
 /* Number of kernel launches the library has enqueued in this process so far (all streams): the difference around a call is
  * that call's launch count.  Diagnostic only. */
 unsigned long long giga_launch_count(void);
+/* ---- measurement hooks (bench.py roofline): HIP events recorded on `stream` right before and
+ * after ONE kernel launch, so the kernel's duration is measured live on the stream it runs on.
+ * probe_stage: 0 conv_in+project, 1 plane_finalize, 2..14 = U-Net layers 0..12 (giga_layout.h kConv), 15 = the whole U-Net.
+ * The decoder variant brackets the single fused decoder launch. */
 void* giga_event_create(void);
 void giga_event_destroy(void* ev);
 int giga_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises on ev_stop */

@@ -156,20 +156,26 @@ def test_unregistered_reference_lattice_is_detected_from_data(net, dev, sd7):
     assert convonet.LATTICE_STATS["generic"] - before["generic"] == 2
 
 
-@pytest.mark.parametrize("prec", ["fp32", "fp16x3"])
-def test_edge_cases_g5(net, dev, sd7, golden, prec):
+@pytest.mark.parametrize("prec,tol", [("fp32", 1e-4), ("fp16x3", 1e-4), ("fp16", 1e-2)])
+def test_edge_cases_g5(net, dev, sd7, golden, prec, tol):
+    """All-zero / all-one volumes, query points exactly on +-0.5 and on cell centres (bilinear weights 0 / 1).  Plain fp16 is held
+    to its stated envelope (1e-2: a throughput mode outside the 1e-3 contract), the fp32-grade modes to 1e-4."""
     net.set_precision(prec)
     g = golden("g5_edges.npz")
-    with torch.no_grad():
-        for name, val in (("zeros", 0.0), ("ones", 1.0)):
-            pl = net.encode_inputs(torch.full((1, 40, 40, 40), val, device=dev))
-            for k in O.PLANES:
-                assert maxerr(pl[k][:, :, ::4, ::4], g[f"{name}_plane_{k}_s4"]) < 1e-4
-        pe = torch.from_numpy(g["edge_points"]).to(dev)
-        x = torch.from_numpy(synth.tsdf_batch(int(g["edge_scene"]), 1)).to(dev)
-        q, r, w, t = net(x, pe, p_tsdf=pe)
-    assert maxerr(q, g["edge_qual"]) < 1e-4 and maxerr(r, g["edge_rot"]) < 1e-4
-    assert maxerr(w, g["edge_width"]) < 2e-4 and maxerr(t, g["edge_tsdf"]) < 2e-4
+    try:
+        with torch.no_grad():
+            for name, val in (("zeros", 0.0), ("ones", 1.0)):
+                pl = net.encode_inputs(torch.full((1, 40, 40, 40), val, device=dev))
+                for k in O.PLANES:
+                    want = g[f"{name}_plane_{k}_s4"]
+                    assert maxerr(pl[k][:, :, ::4, ::4], want) < tol * max(1.0, float(np.abs(want).max()))
+            pe = torch.from_numpy(g["edge_points"]).to(dev)
+            x = torch.from_numpy(synth.tsdf_batch(int(g["edge_scene"]), 1)).to(dev)
+            q, r, w, t = net(x, pe, p_tsdf=pe)
+        assert maxerr(q, g["edge_qual"]) < tol and maxerr(r, g["edge_rot"]) < 2 * tol
+        assert maxerr(w, g["edge_width"]) < 2 * tol and maxerr(t, g["edge_tsdf"]) < 2 * tol
+    finally:
+        net.set_precision("fp32")
 
 
 @pytest.mark.parametrize("prec", ["fp32", "fp16x3"])
@@ -462,6 +468,33 @@ def test_persistent_unet_launches_in_flight_on_several_streams(net, dev):
                     assert torch.equal(g, want[k]), (prec, k)
     finally:
         net.set_persistent_unet(False)
+        net.set_precision("fp32")
+
+
+def test_more_encoder_calls_in_flight_than_persistent_launches_allowed(net, dev):
+    """Eight streams, no synchronisation in between: more than the four persistent U-Net launches the library allows in flight per
+    device (a launch can park one unfilled group of <= 7 workgroups per XCD; 5 x 7 > 32 slots).  The library tracks the completion
+    events of its last four persistent launches and gives the fifth concurrent call one launch per layer instead
+    (csrc/giga_encoder.hip::persistent_slot) -- same results bit for bit in the f16-class modes -- so nothing may trap and every
+    result must equal the same call made alone."""
+    streams = [torch.cuda.Stream(device=dev) for _ in range(8)]
+    xs = [torch.from_numpy(synth.tsdf_batch(1300 + 40 * k, (32, 2, 11, 1)[k % 4])).to(dev) for k in range(8)]
+    try:
+        for prec in ("fp16", "fp16x3"):
+            net.set_precision(prec)
+            with torch.no_grad():
+                want = [net.encode_inputs(x)["yz"].clone() for x in xs]
+                torch.cuda.synchronize()
+                got = [[] for _ in xs]
+                for rep in range(12):
+                    for k, (st, x) in enumerate(zip(streams, xs)):
+                        with torch.cuda.stream(st):
+                            got[k].append(net.encode_inputs(x)["yz"])
+                torch.cuda.synchronize()
+            for k in range(8):
+                for g in got[k]:
+                    assert torch.equal(g, want[k]), (prec, k)
+    finally:
         net.set_precision("fp32")
 
 
