@@ -58,6 +58,7 @@ _SIGNATURES = {
                                              ctypes.c_size_t]),
     "giga_pack_bwd_map": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]),
     "giga_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "giga_backward_workspace_layout": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
     "giga_backward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,

@@ -322,6 +322,15 @@ size_t giga_backward_workspace_bytes(int B, int N, int M, int head_present) {
            train_dec_scratch_bytes(B, N, M, head_present);
 }
 
+int giga_backward_workspace_layout(int B, size_t* offsets) {
+    if (B <= 0 || !offsets) return -1;
+    const BwdWs g = enc_bwd_workspace(B);
+    const size_t base = align_up((size_t)3 * B * RES * RES * CD * sizeof(float), 256);     // the plane gradients come first
+    const size_t o[15] = {g.gA6, g.gA5, g.gC1, g.gA4, g.gA3, g.gC0, g.gS2, g.gA2, g.gQ1, g.gS1, g.gA1, g.gQ0, g.gS0, g.gA0, g.gP0};
+    for (int i = 0; i < 15; ++i) offsets[i] = base + o[i];
+    return 0;
+}
+
 int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed, const void* enc_workspace_fwd,
                   const void* planes_nhwc, const float* p, const float* p_tsdf, const float* const* outs,
                   const float* const* douts, float* grads, size_t n_params, int head_present, int B, int N, int M,

@@ -1117,6 +1117,179 @@ __global__ __launch_bounds__(256, 1) void decoder_f32_kernel(DecArgs a) {
     }
 }
 
+// ------------------------------- exact fp32 path for a HANDFUL of points --------------------------------
+// train_giga's literal call has ONE grasp query per scene (scripts/train_giga.py:141-151: pos is (B, 1, 3)): 32 point-heads per
+// head at 32 scenes, i.e. one 32-point tile.  In decoder_f32_kernel that tile is a serial chain of 440 v_mfma_f32_32x32x2_f32 on
+// ONE wave (28 k clocks) behind a 111-KiB weight fill: 22 us per launch for 0.1 % of the step's FLOPs.  Here a workgroup of four
+// waves takes ONE tile of ONE head and splits the chain where it is not a chain: the contribution of the plane features and of the
+// query point to block b's stream, FC_b = fc_c[b](c) + aux_b (12 + 1 fragments, 51 MFMAs), does not depend on the stream, so the
+// four waves compute FC_0 .. FC_4 side by side (wave 1 takes two of them) while wave 0 walks the 5 x 32 + 5 dependent MFMAs of
+// fc_0 / fc_1 / fc_out and adds FC_b when it reaches block b.  Weight fragments are read straight from the packed blob (global /
+// L2, one 16-byte load per lane and fragment): nothing waits for a weight image in LDS.  Same fragments, same k-slot maps and
+// the same operands as decoder_f32_kernel; the stream is summed as (stream + FC_b) instead of one running fma chain, an fp32
+// rounding-level difference (1e-7 relative).
+__global__ __launch_bounds__(256) void decoder_f32_tile_kernel(DecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y;
+    const long long tile0 = (long long)blockIdx.x * 32;
+    const float4* W = reinterpret_cast<const float4*>(a.blob + a.head_off[h]);          // fragments in global memory
+    const float* ctab = reinterpret_cast<const float*>(a.blob + a.head_off[h] + (size_t)DEC32_FRAGS * FRAG);
+    const float* planes = reinterpret_cast<const float*>(a.planes);
+    const size_t plane_stride = (size_t)a.B * RES * RES * CD;
+    constexpr int BLKF = 21;                                   // fragments per block: 12 features, 1 aux, 4 fc_0, 4 fc_1
+    // which FC blocks this wave computes: wave 0 -> 0, wave 1 -> 1 and 4, wave 2 -> 2, wave 3 -> 3
+    const int blk_a = wave, blk_b = wave == 1 ? 4 : -1;
+    // ---- the first FC block's fragments are requested before the gather (they do not depend on it)
+    float4 fa[13];
+#pragma unroll
+    for (int q = 0; q < 13; ++q) fa[q] = W[(size_t)(BLKF * blk_a + q) * 64 + lane];
+    // ---- gather: every wave gathers the tile for itself (decoder_f32_kernel's line-friendly gather, wave-private LDS stage)
+    long long g = tile0 + n;
+    const bool valid = g < a.P;
+    if (!valid) g = a.P - 1;
+    float cf[48];
+    const float ax0 = hi ? a.p[3 * g + 1] : a.p[3 * g + 0];     // aux MFMA 0: slots (px, py)
+    const float ax1 = hi ? 1.0f : a.p[3 * g + 2];               // aux MFMA 1: slots (pz, 1)
+    {
+        float* S = reinterpret_cast<float*>(smem) + wave * (32 * 96);      // [point][96]
+#pragma unroll
+        for (int part = 0; part < 4; ++part) {
+            const int pair = part * 16 + (lane >> 2), pt = pair >> 1, hf = pair & 1, qd = lane & 3;
+            long long gp = tile0 + pt;
+            if (gp >= a.P) gp = a.P - 1;
+            int bp, rp;
+            split_scene(gp, a.N, a.invN, bp, rp);
+            const float nx = norm_coord(a.p[3 * gp + 0]), ny = norm_coord(a.p[3 * gp + 1]), nz = norm_coord(a.p[3 * gp + 2]);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const Bilin bl = bilin_setup(pl == 2 ? ny : nx, pl == 1 ? ny : nz);
+                const float* base = planes + pl * plane_stride + (size_t)bp * RES * RES * CD + 16 * hf + 4 * qd;
+                const float4 v00 = *reinterpret_cast<const float4*>(base + (size_t)bl.o00 * CD);
+                const float4 v01 = *reinterpret_cast<const float4*>(base + (size_t)bl.o01 * CD);
+                const float4 v10 = *reinterpret_cast<const float4*>(base + (size_t)bl.o10 * CD);
+                const float4 v11 = *reinterpret_cast<const float4*>(base + (size_t)bl.o11 * CD);
+                float4 o;
+                o.x = fmaf(v11.x, bl.w11, fmaf(v10.x, bl.w10, fmaf(v01.x, bl.w01, v00.x * bl.w00)));
+                o.y = fmaf(v11.y, bl.w11, fmaf(v10.y, bl.w10, fmaf(v01.y, bl.w01, v00.y * bl.w00)));
+                o.z = fmaf(v11.z, bl.w11, fmaf(v10.z, bl.w10, fmaf(v01.z, bl.w01, v00.z * bl.w00)));
+                o.w = fmaf(v11.w, bl.w11, fmaf(v10.w, bl.w10, fmaf(v01.w, bl.w01, v00.w * bl.w00)));
+                *reinterpret_cast<float4*>(S + pt * 96 + pl * 32 + 16 * hf + 4 * qd) = o;
+            }
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(S + n * 96 + pl * 32 + 16 * hi + 4 * q);
+                cf[16 * pl + 4 * q + 0] = v.x; cf[16 * pl + 4 * q + 1] = v.y; cf[16 * pl + 4 * q + 2] = v.z; cf[16 * pl + 4 * q + 3] = v.w;
+            }
+    }
+    const float one0 = hi ? 0.0f : 1.0f;                        // aux MFMA 2: slots (1, 0)
+    auto fc_block = [&](const float4 (&A)[13]) {                // FC_b: 12 feature fragments + the aux fragment, from zero
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            acc = mfma32(A[q].x, cf[4 * q + 0], acc);
+            acc = mfma32(A[q].y, cf[4 * q + 1], acc);
+            acc = mfma32(A[q].z, cf[4 * q + 2], acc);
+            acc = mfma32(A[q].w, cf[4 * q + 3], acc);
+        }
+        acc = mfma32(A[12].x, ax0, acc);
+        acc = mfma32(A[12].y, ax1, acc);
+        acc = mfma32(A[12].z, one0, acc);
+        return acc;
+    };
+    // FC exchange area behind the four gather stages: FC_b as [4 quads][64 lanes] float4
+    float4* FCX = reinterpret_cast<float4*>(smem + 4 * 32 * 96 * sizeof(float));
+    auto put_fc = [&](int blk, const f32x16& v) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) FCX[(blk * 4 + q) * 64 + lane] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    };
+    f32x16 net = fc_block(fa);                                  // FC of this wave's first block
+    if (wave != 0) put_fc(blk_a, net);
+    float4 w0[4], w1[4];                                        // wave 0: fc_0 / fc_1 fragments of the block ahead
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { w0[q] = W[(size_t)(13 + q) * 64 + lane]; w1[q] = W[(size_t)(17 + q) * 64 + lane]; }
+    }
+    if (blk_b >= 0) {                                           // (wave 1) the second FC block's fragments
+#pragma unroll
+        for (int q = 0; q < 13; ++q) fa[q] = W[(size_t)(BLKF * blk_b + q) * 64 + lane];
+    }
+    __syncthreads();                                            // FC_1 .. FC_3 are in LDS
+    if (blk_b >= 0) put_fc(blk_b, fc_block(fa));
+    if (wave == 0) {
+#pragma unroll
+        for (int blk = 0; blk < NBLK; ++blk) {
+            if (blk == NBLK - 1) __syncthreads();               // FC_4 (wave 1's second block) is in LDS
+            if (blk > 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = FCX[(blk * 4 + q) * 64 + lane];
+                    net[4 * q] += v.x; net[4 * q + 1] += v.y; net[4 * q + 2] += v.z; net[4 * q + 3] += v.w;
+                }
+            }
+            float4 a0[4], a1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a0[q] = w0[q]; a1[q] = w1[q]; }
+            if (blk + 1 < NBLK) {                               // request the next block's fragments before this block's chain
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    w0[q] = W[(size_t)(BLKF * (blk + 1) + 13 + q) * 64 + lane];
+                    w1[q] = W[(size_t)(BLKF * (blk + 1) + 17 + q) * 64 + lane];
+                }
+            } else {                                            // ... or the tail: aux (b1 of block 4) and fc_out
+                w0[0] = W[(size_t)(BLKF * NBLK) * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w1[q] = W[(size_t)(BLKF * NBLK + 1 + q) * 64 + lane];
+            }
+            f32x16 hh;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(ctab + blk * 32 + 8 * q + 4 * hi);
+                hh[4 * q + 0] = v.x; hh[4 * q + 1] = v.y; hh[4 * q + 2] = v.z; hh[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                hh = mfma32(a0[q].x, relu(net[4 * q + 0]), hh);
+                hh = mfma32(a0[q].y, relu(net[4 * q + 1]), hh);
+                hh = mfma32(a0[q].z, relu(net[4 * q + 2]), hh);
+                hh = mfma32(a0[q].w, relu(net[4 * q + 3]), hh);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                net = mfma32(a1[q].x, relu(hh[4 * q + 0]), net);
+                net = mfma32(a1[q].y, relu(hh[4 * q + 1]), net);
+                net = mfma32(a1[q].z, relu(hh[4 * q + 2]), net);
+                net = mfma32(a1[q].w, relu(hh[4 * q + 3]), net);
+            }
+        }
+        net = mfma32(w0[0].y, ax1, net);                        // + b1 of block 4 (slot "1.0")
+        f32x16 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(ctab + NBLK * 32 + 8 * q + 4 * hi);
+            o[4 * q + 0] = v.x; o[4 * q + 1] = v.y; o[4 * q + 2] = v.z; o[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            o = mfma32(w1[q].x, relu(net[4 * q + 0]), o);
+            o = mfma32(w1[q].y, relu(net[4 * q + 1]), o);
+            o = mfma32(w1[q].z, relu(net[4 * q + 2]), o);
+            o = mfma32(w1[q].w, relu(net[4 * q + 3]), o);
+        }
+        if (hi == 0 && valid) store_head(a, h, g, o[0], o[1], o[2], o[3]);
+    } else {
+        __syncthreads();                                        // (the barrier wave 0 takes before block 4)
+    }
+}
+constexpr size_t DEC32_TILE_LDS = 4 * 32 * 96 * sizeof(float) + NBLK * 4 * 64 * sizeof(float4);   // 4 gather stages + FC exchange
+
 // ------------------------------- plane repack NCHW fp32 -> NHWC T ---------------------------------
 // Used when the planes arrive through the Python boundary as the reference's (B,32,40,40) tensors
 // (LocalDecoder.forward(p, c_plane), decoder.py:133).  One thread per (image, pixel, 4 channels).
@@ -1321,6 +1494,11 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
         auto kern = decoder_f16_kernel<T, false, NW>;
         giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)(2 * DEC16_BYTES));
         GIGA_LAUNCH(kern, dim3(grid), dim3(NW * 64), 2 * DEC16_BYTES, s, a);
+    } else if (!lat && tiles * a.nheads <= 96 && [] { const char* e = getenv("GIGA_DEC32_TILE"); return e ? atoi(e) != 0 : true; }()) {
+        // a handful of points (train_giga's one grasp query per scene): one tile and head per workgroup, four waves per chain
+        auto kern = decoder_f32_tile_kernel;
+        giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)DEC32_TILE_LDS);
+        GIGA_LAUNCH(kern, dim3((unsigned)tiles, a.nheads), dim3(256), DEC32_TILE_LDS, s, a);
     } else if (tiles >= 2 * 4 * 256) {
         // enough work for two tiles per wave on every CU: the 111 KiB weight image is staged half as often
         constexpr int T = 2;

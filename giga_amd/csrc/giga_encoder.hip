@@ -688,19 +688,23 @@ __global__ __launch_bounds__(C32_NW * 64) void unet32_mega_kernel(MegaArgs m) {
 // per XCD while its remaining workgroups wait to become resident, and an XCD has 32 workgroup slots for these kernels (one per CU:
 // 100-160 KiB of LDS each).  Four launches can park at most 4 x 7 = 28 < 32 slots in unfilled groups, so some group can always
 // fill and finish; five or more could park 35 > 32 and every barrier would run into its time-out.  The library therefore keeps,
-// per device, the completion events of its last MEGA_MAX_IN_FLIGHT persistent launches; when the oldest of them has not finished,
-// the call takes one launch per layer instead (same results).  This is process-local: other PROCESSES sharing the device are not
+// per device, the completion event of the last persistent launch of every stream that has one pending; a call on a stream that
+// would be the FIFTH with an unfinished persistent launch takes one launch per layer instead (same results; launches queued on one
+// stream run one after the other and count once).  This is process-local: other PROCESSES sharing the device are not
 // seen (include/giga_hip.h states the bound).  Streams that are being captured into a hipGraph are not tracked (an event cannot
 // be queried there): a captured call keeps the persistent form, and replays on several streams at once are the caller's to bound.
 // ----------------------------------------------------------------------------------------------------
-struct MegaSlots {
+struct MegaSlots {                                 // per device: the last persistent launch of up to MEGA_TRACKED streams
+    static constexpr int MEGA_TRACKED = 16;
     std::atomic_flag busy = ATOMIC_FLAG_INIT;
-    hipEvent_t ev[MEGA_MAX_IN_FLIGHT] = {};
-    bool used[MEGA_MAX_IN_FLIGHT] = {};
-    int head = 0;
+    hipStream_t stream[MEGA_TRACKED] = {};
+    hipEvent_t ev[MEGA_TRACKED] = {};
+    bool used[MEGA_TRACKED] = {};
 };
 static MegaSlots g_mega_slots[16];
-// returns the slot to record after the launch (>= 0), -1 if the persistent form must not be used now, -2 if untracked (capture)
+// Launches on ONE stream run one after the other, so what counts is the number of STREAMS whose last persistent launch has not
+// finished.  Returns the table slot to record after the launch (>= 0), -1 if the persistent form must not be used now (four other
+// streams are busy with one, or the table is full), -2 if untracked (the stream is being captured).
 static int persistent_slot(hipStream_t s) {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return -2;
@@ -708,12 +712,16 @@ static int persistent_slot(hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -1;
     MegaSlots& m = g_mega_slots[dev];
     while (m.busy.test_and_set(std::memory_order_acquire)) {}
-    int slot = m.head;
-    if (m.used[slot] && hipEventQuery(m.ev[slot]) != hipSuccess) slot = -1;         // the oldest tracked launch is still running
-    else {
-        if (!m.ev[slot] && hipEventCreateWithFlags(&m.ev[slot], hipEventDisableTiming) != hipSuccess) slot = -1;
-        else { m.used[slot] = false; m.head = (slot + 1) % MEGA_MAX_IN_FLIGHT; }
+    int mine = -1, spare = -1, others = 0;
+    for (int i = 0; i < MegaSlots::MEGA_TRACKED; ++i) {
+        if (m.used[i] && m.stream[i] == s) { mine = i; continue; }
+        if (m.used[i] && hipEventQuery(m.ev[i]) == hipSuccess) m.used[i] = false;     // that stream's last launch has finished
+        if (m.used[i]) ++others;
+        else if (spare < 0) spare = i;
     }
+    int slot = mine >= 0 ? mine : spare;
+    if (others >= MEGA_MAX_IN_FLIGHT || slot < 0) slot = -1;
+    else if (!m.ev[slot] && hipEventCreateWithFlags(&m.ev[slot], hipEventDisableTiming) != hipSuccess) slot = -1;
     m.busy.clear(std::memory_order_release);
     return slot;
 }
@@ -723,7 +731,7 @@ static void persistent_launched(int slot, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return;
     MegaSlots& m = g_mega_slots[dev];
     while (m.busy.test_and_set(std::memory_order_acquire)) {}
-    if (hipEventRecord(m.ev[slot], s) == hipSuccess) m.used[slot] = true;
+    if (hipEventRecord(m.ev[slot], s) == hipSuccess) { m.used[slot] = true; m.stream[slot] = s; }
     m.busy.clear(std::memory_order_release);
 }
 

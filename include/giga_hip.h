@@ -11,7 +11,7 @@
  *     the library never allocates device memory and is re-entrant per (stream, workspace).  Its only
  *     process-wide mutable state is bookkeeping, never read by the arithmetic: the launch counter
  *     (giga_launch_count), the per-kernel record of raised dynamic-LDS limits, and per device the
- *     completion events of its last four persistent U-Net launches (see GIGA_PERSIST_UNET);
+ *     completion events of the streams' last persistent U-Net launches (see GIGA_PERSIST_UNET);
  *   - every launch is asynchronous on the caller's HIP stream `stream` (a hipStream_t);
  *   - return value 0 = success, negative = error (giga_strerror); nothing throws across the ABI;
  *   - at most GIGA_MAX_SCENES scenes per encoder / training call (the convolution kernels address activations with
@@ -126,9 +126,9 @@ int giga_decoder_forward(const void* planes_nhwc, const float* p, const void* pa
  * precision 0.  The workgroups of a group find each other by ticket among the workgroups already resident on their XCD, so
  * such launches may be in flight on several streams of one device without waiting on each other's CUs -- UP TO FOUR of them: a
  * launch can hold one unfilled group (<= 7 workgroups) per XCD, an XCD has 32 slots for these workgroups, and 5 x 7 > 32 could
- * park every slot in groups that never fill.  The library enforces the bound inside a process: it tracks the completion events of
- * its last four persistent launches per device, and a call that would be the fifth in flight takes one launch per layer instead
- * (same results).  It cannot see OTHER PROCESSES that share the device, nor replays of captured hipGraphs on several streams at
+ * park every slot in groups that never fill.  The library enforces the bound inside a process: per device it tracks the
+ * completion event of every stream's last persistent launch, and a call on a stream that would be the fifth with an unfinished one
+ * takes one launch per layer instead (same results; launches queued on one stream run one after the other and count once).  It cannot see OTHER PROCESSES that share the device, nor replays of captured hipGraphs on several streams at
  * once: keep those to four concurrent encoder calls, or pass GIGA_LAYERWISE_UNET.  The kernel also assumes that every XCD
  * receives an eighth of the grid (no CU mask on the stream, a whole MI355X: 256 CUs -- checked -- in one partition).  A barrier
  * that is not released within 20 s of wall clock (s_memrealtime) traps instead of returning stale data or hanging the device.
@@ -190,6 +190,12 @@ int giga_pack_bwd_weights(const float* params_host, size_t n_params, int head_pr
                           size_t packed_bytes);
 int giga_pack_bwd_map(int head_present, int32_t* map_host, size_t nwords);
 size_t giga_backward_workspace_bytes(int B, int N, int M, int head_present);
+/* Introspection for tests: byte offsets, inside the backward workspace, of the 15 activation-gradient tensors the encoder backward
+ * leaves there (fp32 NHWC [3B][H][W][C], in order gA6 gA5 gC1 gA4 gA3 gC0 gS2 gA2 gQ1 gS1 gA1 gQ0 gS0 gA0 gP0: g<X> = gradient of
+ * the loss w.r.t. activation X of giga_encoder_workspace_layout; gC1 / gC0 = w.r.t. the concatenated inputs of up1.conv1 /
+ * up0.conv1).  gA6 gA5 gA4 gA3 gS2 gA2 gS1 gA1 gS0 gA0 are, with the ReLU mask already applied, the dY operands of the weight
+ * gradients of layers 11, 10, 8, 7, 5, 4, 3, 2, 1, 0.  offsets must have room for 15 entries. */
+int giga_backward_workspace_layout(int B, size_t* offsets);
 int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed, const void* enc_workspace_fwd,
                   const void* planes_nhwc, const float* p, const float* p_tsdf, const float* const* outs,
                   const float* const* douts, float* grads, size_t n_params, int head_present, int B, int N, int M,

@@ -502,3 +502,78 @@ def test_flat_adam_matches_torch_adam(wd):
     # moments: fp32 rounding of two formulations of the same update (lerp vs b1 m + (1 - b1) g)
     assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-5, atol=1e-6)
     assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("B", [2, 32])
+def test_bf16_weight_gradient_kernels_with_rounded_operands(sd7, B):
+    """Every bf16 3x3 weight-gradient kernel (csrc/giga_encoder_bwd.hip: conv3_wgrad_bf16_kernel and the tap-per-wave variant
+    conv3_wgrad_bf16_taps_kernel, selected per layer) held to what it is supposed to compute, layer by layer, on the operands the
+    GPU itself used:  dW[co][ci][ky][kx] = sum over images and pixels of bf16(dY[y, x, co]) * bf16(X[y + ky - 1, x + kx - 1, ci])
+    with fp32 accumulation, X zero outside the image (encoder/unet.py:14-23: padding 1) -- so a dropped tap at an image border, a
+    wrong strip boundary or a stale operand shows as a large relative error of ONE tap, which the 2 % whole-network bound of
+    test_bf16_training_step cannot see.  dY and X are read back from the workspaces the C ABI exposes
+    (giga_encoder_workspace_layout, giga_backward_workspace_layout); bias gradients are the column sums of the UNROUNDED dY.
+    Tolerance: 2e-5 of the tensor's range + the fp32 summation noise of ~1e5 products (1e-5 relative of the sum of |products|).
+    B = 2 runs the small-batch strip schedules, B = 32 the c5 shape."""
+    import ctypes
+
+    import torch.nn.functional as F
+    from giga_amd import _capi
+    dev = torch.device("cuda:0")
+    x, pos, pos_occ, y = _batch(700, B, 256)
+    net = networks.get_network("giga"); net.load_state_dict(sd7); net = net.to(dev).train().set_train_precision("bf16")
+    g5 = torch.Generator().manual_seed(11)
+    R = [torch.randn(B, 1, generator=g5), torch.randn(B, 1, 4, generator=g5), torch.randn(B, 1, generator=g5),
+         torch.randn(B, 256, generator=g5) / 16]
+    out = net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev))
+    sum((o * r.to(dev)).sum() for o, r in zip(out, R)).backward()
+    torch.cuda.synchronize()
+    st = net._train_state
+    sb = [b for b in st._pool if b.key == (B, 1, 256)][-1]
+    fo, bo = (ctypes.c_size_t * 17)(), (ctypes.c_size_t * 15)()
+    assert _capi.lib().giga_encoder_workspace_layout(B, _capi.PRECISION["bf16"], fo) == 0
+    assert _capi.lib().giga_backward_workspace_layout(B, bo) == 0
+    fn = ["P0", "A0", "S0", "Q0", "A1", "S1", "Q1", "A2", "S2", "U0", "A3", "A4", "U1", "A5", "A6"]
+    bn = ["gA6", "gA5", "gC1", "gA4", "gA3", "gC0", "gS2", "gA2", "gQ1", "gS1", "gA1", "gQ0", "gS0", "gA0", "gP0"]
+    ch = dict(zip(fn, (32, 32, 32, 32, 64, 64, 64, 128, 128, 64, 64, 64, 32, 32, 32)))
+    hw = dict(zip(fn, (40, 40, 40, 20, 20, 20, 10, 10, 10, 20, 20, 20, 40, 40, 40)))
+
+    def act(nm):                                             # forward activation, NCHW fp64 with bf16-rounded values
+        n = 3 * B * hw[nm] * hw[nm] * ch[nm]
+        o = fo[fn.index(nm)]
+        t = sb.ws[o:o + 4 * n].view(torch.float32).view(3 * B, hw[nm], hw[nm], ch[nm]).permute(0, 3, 1, 2)
+        return t.bfloat16().double().cpu()
+
+    def grad_of(nm):                                         # dLoss / d(activation nm), NCHW fp32 as the GPU left it
+        n = 3 * B * hw[nm] * hw[nm] * ch[nm]
+        o = bo[bn.index("g" + nm)]
+        return sb.wsb[o:o + 4 * n].view(torch.float32).view(3 * B, hw[nm], hw[nm], ch[nm]).permute(0, 3, 1, 2).cpu()
+
+    grads = dict(net.named_parameters())
+    # (layer key, dY = gradient of its output activation, inputs in concatenation order)
+    layers = [("down_convs.0.conv1", "A0", ("P0",)), ("down_convs.0.conv2", "S0", ("A0",)), ("down_convs.1.conv1", "A1", ("Q0",)),
+              ("down_convs.1.conv2", "S1", ("A1",)), ("down_convs.2.conv1", "A2", ("Q1",)), ("down_convs.2.conv2", "S2", ("A2",)),
+              ("up_convs.0.conv1", "A3", ("U0", "S1")), ("up_convs.0.conv2", "A4", ("A3",)),
+              ("up_convs.1.conv1", "A5", ("U1", "S0")), ("up_convs.1.conv2", "A6", ("A5",))]
+    worst = 0.0
+    for key, ynm, xs in layers:
+        dy32 = grad_of(ynm)
+        dy = dy32.bfloat16().double()
+        xin = torch.cat([act(nm) for nm in xs], 1)
+        want = torch.nn.grad.conv2d_weight(xin, (dy.shape[1], xin.shape[1], 3, 3), dy, padding=1)
+        # the sum of |products|: what fp32 accumulation noise scales with
+        mag = torch.nn.grad.conv2d_weight(xin.abs(), (dy.shape[1], xin.shape[1], 3, 3), dy.abs(), padding=1)
+        got = grads[f"encoder.unet.{key}.weight"].grad.double().cpu()
+        err = (got - want).abs()
+        tol = 2e-5 * float(want.abs().max()) + 1e-5 * mag
+        bad = err > tol
+        assert not bool(bad.any()), (key, B, int(bad.sum()), float(err.max()), float(want.abs().max()),
+                                     [tuple(int(v) for v in i) for i in bad.nonzero()[:4]])
+        # per-tap check: no tap of any (co, ci) pair may be off as a whole (a dropped border tap shifts a tap's mean)
+        tap_err = (got - want).abs().mean(dim=(0, 1)) / want.abs().mean(dim=(0, 1))
+        assert float(tap_err.max()) < 2e-3, (key, B, tap_err)
+        worst = max(worst, float((err / (mag * 1e-5 + 2e-5 * want.abs().max())).max()))
+        gb = grads[f"encoder.unet.{key}.bias"].grad.double().cpu()
+        wb = dy32.double().sum(dim=(0, 2, 3))
+        assert float((gb - wb).abs().max()) <= 2e-5 * max(1.0, float(wb.abs().max())) + 1e-6 * float(dy32.double().abs().sum(dim=(0, 2, 3)).max()), key
+    print("bf16 weight gradients with rounded operands: worst error / tolerance", worst)
