@@ -1124,8 +1124,10 @@ __global__ __launch_bounds__(256, 1) void decoder_f32_kernel(DecArgs a) {
 // waves takes ONE tile of ONE head and splits the chain where it is not a chain: the contribution of the plane features and of the
 // query point to block b's stream, FC_b = fc_c[b](c) + aux_b (12 + 1 fragments, 51 MFMAs), does not depend on the stream, so the
 // four waves compute FC_0 .. FC_4 side by side (wave 1 takes two of them) while wave 0 walks the 5 x 32 + 5 dependent MFMAs of
-// fc_0 / fc_1 / fc_out and adds FC_b when it reaches block b.  Weight fragments are read straight from the packed blob (global /
-// L2, one 16-byte load per lane and fragment): nothing waits for a weight image in LDS.  Same fragments, same k-slot maps and
+// fc_0 / fc_1 / fc_out and adds FC_b when it reaches block b.  The FC fragments are read straight from the packed blob (global /
+// L2, one 16-byte load per lane and fragment, all of a block in flight at once); the 45 fragments of the dependent chain are
+// copied into LDS by waves 1-3 (LDS-DMA) while wave 0 computes FC_0 (read from global inside the chain they cost a load latency
+// each: the compiler sinks every load to its use).  Same fragments, same k-slot maps and
 // the same operands as decoder_f32_kernel; the stream is summed as (stream + FC_b) instead of one running fma chain, an fp32
 // rounding-level difference (1e-7 relative).
 __global__ __launch_bounds__(256) void decoder_f32_tile_kernel(DecArgs a) {
@@ -1142,6 +1144,16 @@ __global__ __launch_bounds__(256) void decoder_f32_tile_kernel(DecArgs a) {
     constexpr int BLKF = 21;                                   // fragments per block: 12 features, 1 aux, 4 fc_0, 4 fc_1
     // which FC blocks this wave computes: wave 0 -> 0, wave 1 -> 1 and 4, wave 2 -> 2, wave 3 -> 3
     const int blk_a = wave, blk_b = wave == 1 ? 4 : -1;
+    // ---- waves 1-3: the chain's fragments (fc_0, fc_1 of the five blocks, the tail, the C table) -> LDS slots 0 .. 45
+    uint8_t* CHW = smem + 4 * 32 * 96 * sizeof(float) + NBLK * 4 * 64 * sizeof(float4);
+    if (wave != 0) {
+        const uint8_t* hb = a.blob + a.head_off[h] + lane * 16;
+        for (int c = wave - 1; c < 46; c += 3) {
+            const int frag = c < 40 ? BLKF * (c >> 3) + 13 + (c & 7) : BLKF * NBLK + (c - 40);     // (c = 45: the C table chunk)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hb + (size_t)frag * FRAG),
+                                             (__attribute__((address_space(3))) void*)(CHW + c * FRAG), 16, 0, 0);
+        }
+    }
     // ---- the first FC block's fragments are requested before the gather (they do not depend on it)
     float4 fa[13];
 #pragma unroll
@@ -1212,18 +1224,16 @@ __global__ __launch_bounds__(256) void decoder_f32_tile_kernel(DecArgs a) {
     };
     f32x16 net = fc_block(fa);                                  // FC of this wave's first block
     if (wave != 0) put_fc(blk_a, net);
-    float4 w0[4], w1[4];                                        // wave 0: fc_0 / fc_1 fragments of the block ahead
-    if (wave == 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { w0[q] = W[(size_t)(13 + q) * 64 + lane]; w1[q] = W[(size_t)(17 + q) * 64 + lane]; }
-    }
     if (blk_b >= 0) {                                           // (wave 1) the second FC block's fragments
 #pragma unroll
         for (int q = 0; q < 13; ++q) fa[q] = W[(size_t)(BLKF * blk_b + q) * 64 + lane];
     }
-    __syncthreads();                                            // FC_1 .. FC_3 are in LDS
+    __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0): this wave's share of the chain fragments has landed
+    __syncthreads();                                            // FC_1 .. FC_3 and the chain's fragments are in LDS
     if (blk_b >= 0) put_fc(blk_b, fc_block(fa));
     if (wave == 0) {
+        const float4* CW = reinterpret_cast<const float4*>(CHW);
+        const float* ctab_l = reinterpret_cast<const float*>(CHW + 45 * FRAG);
 #pragma unroll
         for (int blk = 0; blk < NBLK; ++blk) {
             if (blk == NBLK - 1) __syncthreads();               // FC_4 (wave 1's second block) is in LDS
@@ -1234,61 +1244,50 @@ __global__ __launch_bounds__(256) void decoder_f32_tile_kernel(DecArgs a) {
                     net[4 * q] += v.x; net[4 * q + 1] += v.y; net[4 * q + 2] += v.z; net[4 * q + 3] += v.w;
                 }
             }
-            float4 a0[4], a1[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { a0[q] = w0[q]; a1[q] = w1[q]; }
-            if (blk + 1 < NBLK) {                               // request the next block's fragments before this block's chain
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    w0[q] = W[(size_t)(BLKF * (blk + 1) + 13 + q) * 64 + lane];
-                    w1[q] = W[(size_t)(BLKF * (blk + 1) + 17 + q) * 64 + lane];
-                }
-            } else {                                            // ... or the tail: aux (b1 of block 4) and fc_out
-                w0[0] = W[(size_t)(BLKF * NBLK) * 64 + lane];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) w1[q] = W[(size_t)(BLKF * NBLK + 1 + q) * 64 + lane];
-            }
             f32x16 hh;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(ctab + blk * 32 + 8 * q + 4 * hi);
+                const float4 v = *reinterpret_cast<const float4*>(ctab_l + blk * 32 + 8 * q + 4 * hi);
                 hh[4 * q + 0] = v.x; hh[4 * q + 1] = v.y; hh[4 * q + 2] = v.z; hh[4 * q + 3] = v.w;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                hh = mfma32(a0[q].x, relu(net[4 * q + 0]), hh);
-                hh = mfma32(a0[q].y, relu(net[4 * q + 1]), hh);
-                hh = mfma32(a0[q].z, relu(net[4 * q + 2]), hh);
-                hh = mfma32(a0[q].w, relu(net[4 * q + 3]), hh);
+                const float4 A = CW[(blk * 8 + q) * 64 + lane];
+                hh = mfma32(A.x, relu(net[4 * q + 0]), hh);
+                hh = mfma32(A.y, relu(net[4 * q + 1]), hh);
+                hh = mfma32(A.z, relu(net[4 * q + 2]), hh);
+                hh = mfma32(A.w, relu(net[4 * q + 3]), hh);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                net = mfma32(a1[q].x, relu(hh[4 * q + 0]), net);
-                net = mfma32(a1[q].y, relu(hh[4 * q + 1]), net);
-                net = mfma32(a1[q].z, relu(hh[4 * q + 2]), net);
-                net = mfma32(a1[q].w, relu(hh[4 * q + 3]), net);
+                const float4 A = CW[(blk * 8 + 4 + q) * 64 + lane];
+                net = mfma32(A.x, relu(hh[4 * q + 0]), net);
+                net = mfma32(A.y, relu(hh[4 * q + 1]), net);
+                net = mfma32(A.z, relu(hh[4 * q + 2]), net);
+                net = mfma32(A.w, relu(hh[4 * q + 3]), net);
             }
         }
-        net = mfma32(w0[0].y, ax1, net);                        // + b1 of block 4 (slot "1.0")
+        net = mfma32(CW[40 * 64 + lane].y, ax1, net);           // + b1 of block 4 (slot "1.0")
         f32x16 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(ctab + NBLK * 32 + 8 * q + 4 * hi);
+            const float4 v = *reinterpret_cast<const float4*>(ctab_l + NBLK * 32 + 8 * q + 4 * hi);
             o[4 * q + 0] = v.x; o[4 * q + 1] = v.y; o[4 * q + 2] = v.z; o[4 * q + 3] = v.w;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            o = mfma32(w1[q].x, relu(net[4 * q + 0]), o);
-            o = mfma32(w1[q].y, relu(net[4 * q + 1]), o);
-            o = mfma32(w1[q].z, relu(net[4 * q + 2]), o);
-            o = mfma32(w1[q].w, relu(net[4 * q + 3]), o);
+            const float4 A = CW[(41 + q) * 64 + lane];
+            o = mfma32(A.x, relu(net[4 * q + 0]), o);
+            o = mfma32(A.y, relu(net[4 * q + 1]), o);
+            o = mfma32(A.z, relu(net[4 * q + 2]), o);
+            o = mfma32(A.w, relu(net[4 * q + 3]), o);
         }
         if (hi == 0 && valid) store_head(a, h, g, o[0], o[1], o[2], o[3]);
     } else {
         __syncthreads();                                        // (the barrier wave 0 takes before block 4)
     }
 }
-constexpr size_t DEC32_TILE_LDS = 4 * 32 * 96 * sizeof(float) + NBLK * 4 * 64 * sizeof(float4);   // 4 gather stages + FC exchange
+constexpr size_t DEC32_TILE_LDS = 4 * 32 * 96 * sizeof(float) + NBLK * 4 * 64 * sizeof(float4) + 46 * FRAG;   // 4 gather stages, FC exchange, chain fragments
 
 // ------------------------------- plane repack NCHW fp32 -> NHWC T ---------------------------------
 // Used when the planes arrive through the Python boundary as the reference's (B,32,40,40) tensors
@@ -1494,8 +1493,10 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
         auto kern = decoder_f16_kernel<T, false, NW>;
         giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)(2 * DEC16_BYTES));
         GIGA_LAUNCH(kern, dim3(grid), dim3(NW * 64), 2 * DEC16_BYTES, s, a);
-    } else if (!lat && tiles * a.nheads <= 96 && [] { const char* e = getenv("GIGA_DEC32_TILE"); return e ? atoi(e) != 0 : true; }()) {
-        // a handful of points (train_giga's one grasp query per scene): one tile and head per workgroup, four waves per chain
+    } else if (!lat && a.N == 1 && tiles * a.nheads <= 96 && [] { const char* e = getenv("GIGA_DEC32_TILE"); return e ? atoi(e) != 0 : true; }()) {
+        // ONE query per scene (train_giga's literal call) and few scenes: one tile and head per workgroup, four waves per chain.
+        // (Only for N == 1: the kernel sums the stream in a different order than decoder_f32_kernel, and callers that split a
+        // query set into chunks -- Generator3D.eval_points -- rely on a point's result not depending on the chunk it is in.)
         auto kern = decoder_f32_tile_kernel;
         giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)DEC32_TILE_LDS);
         GIGA_LAUNCH(kern, dim3((unsigned)tiles, a.nheads), dim3(256), DEC32_TILE_LDS, s, a);

@@ -1,6 +1,7 @@
 """Input side of the hot path: a batched reader for the reference's training data.
 
-Counterpart of `vgn.dataset_voxel.DatasetVoxelOccFile` (reference src/vgn/dataset_voxel.py:55-106, `augment=False`) and
+Counterpart of `vgn.dataset_voxel.DatasetVoxelOccFile` (reference src/vgn/dataset_voxel.py:55-106; `augment=True` = its
+`apply_transform`, :114-135, restated below) and
 `vgn.io.read_voxel_grid` (src/vgn/io.py:97-99) for the data layout `scripts/train_giga.py:118-138` trains on:
 
     <root>/scenes/<scene_id>.npz            key "grid":  (1, 40, 40, 40) float32 TSDF          (io.py:88-99)
@@ -32,17 +33,53 @@ def read_voxel_grid(root, scene_id):
     return np.load(Path(root) / "scenes" / (scene_id + ".npz"))["grid"]
 
 
+def apply_transform(voxel_grid, orientation, position, rng="global"):
+    """dataset_voxel.py:114-135 (`scripts/train_giga.py:260 --augment`): a random quarter turn about z and a random shift along z,
+    about the centre (20, 20, 20) of the voxel grid, applied to the TSDF (scipy's nearest-neighbour `affine_transform`, the
+    reference's own dependency) and to the grasp pose.  voxel_grid (1, 40, 40, 40) is modified in place like the reference's;
+    orientation is a scipy Rotation, position the (3,) array __getitem__ hands over -- the METRIC position of the grasp table
+    (:72), which the reference transforms with these voxel-unit offsets before it normalises it (:80); restated as it is.
+    rng == "global": the reference's draws from numpy's global generator, in its order (choice(4), then uniform(6, 34))."""
+    from scipy import ndimage
+    from scipy.spatial.transform import Rotation
+    if rng == "global":
+        angle = np.pi / 2.0 * np.random.choice(4)
+        z_offset = np.random.uniform(6, 34) - position[2]
+    else:
+        angle = np.pi / 2.0 * int(rng.integers(4))
+        z_offset = rng.uniform(6, 34) - position[2]
+    r_aug = Rotation.from_rotvec(np.r_[0.0, 0.0, angle])
+    t_aug = np.asarray(np.r_[0.0, 0.0, z_offset], np.double)
+    centre = np.asarray(np.r_[20.0, 20.0, 20.0], np.double)
+    ident = Rotation.from_quat([0.0, 0.0, 0.0, 1.0])
+    # utils/transform.py:44-60: (R1, t1) * (R2, t2) = (R1 R2, R1 t2 + t1); inverse = (R^-1, -R^-1 t)
+    def mul(a, b):
+        return a[0] * b[0], a[0].apply(b[1]) + a[1]
+
+    def inv(a):
+        r = a[0].inv()
+        return r, -r.apply(a[1])
+
+    T = mul(mul((ident, centre), (r_aug, t_aug)), inv((ident, centre)))      # T_center * T_augment * T_center^-1
+    Ti = inv(T)
+    voxel_grid[0] = ndimage.affine_transform(voxel_grid[0], Ti[0].as_matrix(), Ti[1], order=0)
+    position = T[0].apply(position) + T[1]
+    orientation = T[0] * orientation
+    return voxel_grid, orientation, position
+
+
 class GraspOccDataset:
-    def __init__(self, root, raw_root, num_point_occ=2048, cache_scenes=4096, workers=8):
+    def __init__(self, root, raw_root, num_point_occ=2048, cache_scenes=4096, workers=8, augment=False):
         import pandas as pd
         from scipy.spatial.transform import Rotation
         self.root, self.raw_root = Path(root), Path(raw_root)
         self.num_point_occ = num_point_occ
+        self.augment = augment
         df = pd.read_csv(self.raw_root / "grasps.csv")                       # io.py:80-81
         with (self.raw_root / "setup.json").open("r") as f:                  # io.py:19-26
             self.size = json.load(f)["size"]
         self.scene_ids = df["scene_id"].astype(str).tolist()
-        quat = df.loc[:, "qx":"qw"].to_numpy(np.single)                      # dataset_voxel.py:71
+        quat = self._quat = df.loc[:, "qx":"qw"].to_numpy(np.single)         # dataset_voxel.py:71
         self._pos = df.loc[:, "x":"z"].to_numpy(np.single)                   # :72
         self._width = df["width"].to_numpy().astype(np.single)               # :73
         self.label = df["label"].to_numpy().astype(np.int64)                 # :74 (np.long)
@@ -121,9 +158,25 @@ class GraspOccDataset:
         """DatasetVoxelOccFile.__getitem__ (dataset_voxel.py:69-91): x (40,40,40), (label, rotations (2,4), width), pos (3,),
         occ_points (M,3), occ (M,)."""
         sid = self.scene_ids[i]
+        if self.augment:
+            x, rot, pos = self._augmented(i, rng)
+            occ_points, occ = self._read_occ(sid, rng)
+            return x, (self.label[i], rot, self.width[i]), pos, occ_points, occ
         x = self.grid(sid)[0]
         occ_points, occ = self._read_occ(sid, rng)
         return x, (self.label[i], self.rotations[i], self.width[i]), self.pos[i], occ_points, occ
+
+    def _augmented(self, i, rng):
+        """dataset_voxel.py:77-87 with augment: the transformed grid (a copy: the cache keeps the file's), the two gripper
+        rotations of the transformed orientation and the normalised transformed position (float64, as the reference's)."""
+        from scipy.spatial.transform import Rotation
+        grid = np.array(self.grid(self.scene_ids[i]), copy=True)
+        grid, ori, pos = apply_transform(grid, Rotation.from_quat(self._quat[i]), self._pos[i], rng)
+        pos = pos / self.size - 0.5
+        rot = np.empty((2, 4), dtype=np.single)
+        rot[0] = ori.as_quat()
+        rot[1] = (ori * Rotation.from_rotvec(np.pi * np.r_[0.0, 0.0, 1.0])).as_quat()
+        return grid[0], rot, pos
 
     # -- whole batches -------------------------------------------------------------------------------------
     def batch(self, indices, rng="global"):
@@ -131,6 +184,13 @@ class GraspOccDataset:
         x (B,40,40,40) f32, (label (B,) i64, rotations (B,2,4) f32, width (B,) f32), pos (B,3) f32, occ_points (B,M,3), occ (B,M)."""
         indices = np.asarray(indices, dtype=np.int64)
         sids = [self.scene_ids[i] for i in indices]
+        if self.augment:                                     # per item: augmentation draws, then the occupancy draws (reference order)
+            subs = [rng] * len(sids) if rng == "global" else (
+                rng.spawn(len(sids)) if hasattr(rng, "spawn") else [np.random.default_rng(rng.integers(1 << 62)) for _ in sids])
+            items = [self.item(int(i), r) for i, r in zip(indices, subs)]
+            x = np.stack([it[0] for it in items]).astype(np.float32, copy=False)
+            y = (self.label[indices], np.stack([it[1][1] for it in items]), self.width[indices])
+            return x, y, np.stack([it[2] for it in items]), np.stack([it[3] for it in items]), np.stack([it[4] for it in items])
         if rng == "global":                                  # reference order: item by item, sequential draws
             occ = [self._read_occ(s, rng) for s in sids]
             grids = [self.grid(s) for s in sids]

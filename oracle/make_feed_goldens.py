@@ -2,7 +2,7 @@
 `DatasetVoxelOccFile.__getitem__` (src/vgn/dataset_voxel.py:55-106) on the synthetic on-disk dataset of
 oracle/make_dataset.py (seed 1), with torch/numpy seeded before every item.
 
-    python -m oracle.make_feed_goldens        ->  tests/golden/g12_dataset_items.npz
+    python -m oracle.make_feed_goldens        ->  tests/golden/g12_dataset_items.npz, g13_dataset_items_augmented.npz (augment=True)
 """
 import os
 import tempfile
@@ -14,13 +14,14 @@ import torch
 from oracle import make_dataset, ref_bootstrap
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g12_dataset_items.npz")
+OUT_AUG = os.path.join(os.path.dirname(OUT), "g13_dataset_items_augmented.npz")
 DATASET_SEED, NUM_POINT_OCC, ITEMS = 1, 64, (0, 3, 7, 11, 29)
 
 
-def reference_items(root, raw_root, items, num_point_occ):
+def reference_items(root, raw_root, items, num_point_occ, augment=False):
     ref_bootstrap.install()
     from vgn.dataset_voxel import DatasetVoxelOccFile  # type: ignore
-    ds = DatasetVoxelOccFile(Path(root), Path(raw_root), num_point_occ=num_point_occ)
+    ds = DatasetVoxelOccFile(Path(root), Path(raw_root), num_point_occ=num_point_occ, augment=augment)
     out = []
     for i in items:
         torch.manual_seed(100 + i); np.random.seed(200 + i)
@@ -33,6 +34,7 @@ def main():
         root, raw = os.path.join(tmp, "data"), os.path.join(tmp, "raw")
         make_dataset.write_dataset(root, raw, seed=DATASET_SEED, occ_files=(1, 1))     # one occupancy file per scene: the
         n, items = reference_items(root, raw, ITEMS, NUM_POINT_OCC)                     # glob order cannot matter
+        _, aug_items = reference_items(root, raw, ITEMS, NUM_POINT_OCC, augment=True)   # G13: the same items with augment=True
     rec = {"n": n, "items": np.array(ITEMS), "num_point_occ": NUM_POINT_OCC, "dataset_seed": DATASET_SEED}
     for k, (x, (label, rot, width), pos, op, occ) in zip(ITEMS, items):
         rec[f"x_sub_{k}"] = np.asarray(x)[::5, ::5, ::5]
@@ -41,6 +43,14 @@ def main():
         rec[f"pos_{k}"] = np.asarray(pos); rec[f"occ_points_{k}"] = np.asarray(op); rec[f"occ_{k}"] = np.asarray(occ)
     np.savez_compressed(OUT, **rec)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
+    rec = {"n": n, "items": np.array(ITEMS), "num_point_occ": NUM_POINT_OCC, "dataset_seed": DATASET_SEED}
+    for k, (x, (label, rot, width), pos, op, occ) in zip(ITEMS, aug_items):
+        rec[f"x_sub_{k}"] = np.asarray(x)[::3, ::3, ::3]
+        rec[f"x_sum_{k}"] = np.float64(np.asarray(x, np.float64).sum())
+        rec[f"label_{k}"] = np.asarray(label); rec[f"rot_{k}"] = np.asarray(rot); rec[f"width_{k}"] = np.asarray(width)
+        rec[f"pos_{k}"] = np.asarray(pos); rec[f"occ_points_{k}"] = np.asarray(op); rec[f"occ_{k}"] = np.asarray(occ)
+    np.savez_compressed(OUT_AUG, **rec)
+    print("wrote", OUT_AUG, os.path.getsize(OUT_AUG), "bytes")
 
 
 if __name__ == "__main__":

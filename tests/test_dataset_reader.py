@@ -146,3 +146,55 @@ def test_items_match_live_reference_class(tmp_path):
     for i, r in zip(idx, ref):
         torch.manual_seed(100 + i); np.random.seed(200 + i)
         _same_item(ds.item(i), r)
+
+
+def test_augmented_items_match_golden_g13(tmp_path, golden):
+    """augment=True (scripts/train_giga.py:260; dataset_voxel.py:77-78,114-135): golden G13 is the reference's own class with
+    augment=True on the same synthetic dataset and seeds as G12 -- transformed grid (nearest-neighbour quarter turn about z plus a
+    z shift), transformed position (float64, normalised AFTER the transform as the reference does) and the two gripper rotations;
+    values AND dtypes must match, the numpy draws happen in the reference's order (choice(4), uniform, then the point sample)."""
+    g = golden("g13_dataset_items_augmented.npz")
+    root, raw = str(tmp_path / "data"), str(tmp_path / "raw")
+    n = make_dataset.write_dataset(root, raw, seed=int(g["dataset_seed"]), occ_files=(1, 1))
+    ds = dataset.GraspOccDataset(root, raw, num_point_occ=int(g["num_point_occ"]), augment=True)
+    plain = dataset.GraspOccDataset(root, raw, num_point_occ=int(g["num_point_occ"]))
+    assert len(ds) == n == int(g["n"])
+    moved = 0
+    for k in g["items"]:
+        k = int(k)
+        torch.manual_seed(100 + k); np.random.seed(200 + k)
+        x, (label, rot, width), pos, op, occ = ds.item(k)
+        assert x.shape == (40, 40, 40) and x.dtype == np.float32
+        assert np.array_equal(x[::3, ::3, ::3], g[f"x_sub_{k}"]) and abs(x.astype(np.float64).sum() - float(g[f"x_sum_{k}"])) < 1e-9
+        for got, key in ((label, "label"), (rot, "rot"), (width, "width"), (pos, "pos"), (op, "occ_points"), (occ, "occ")):
+            ref = g[f"{key}_{k}"]
+            got = np.asarray(got)
+            assert got.shape == ref.shape and got.dtype == ref.dtype and np.array_equal(got, ref), (k, key)
+        moved += int(not np.array_equal(x, plain.grid(plain.scene_ids[k])[0]))
+        assert np.array_equal(plain.grid(plain.scene_ids[k]), np.load(os.path.join(root, "scenes", plain.scene_ids[k] + ".npz"))["grid"])
+    assert moved >= 3                                          # (the transform really changes the grids; the cache keeps the originals)
+    # whole batches: item by item with the global generators, i.e. what a 0-worker DataLoader would collate
+    torch.manual_seed(9); np.random.seed(10)
+    b = ds.batch([2, 5, 2])
+    torch.manual_seed(9); np.random.seed(10)
+    items = [ds.item(i) for i in (2, 5, 2)]
+    for r, it in enumerate(items):
+        assert np.array_equal(b[0][r], it[0]) and np.array_equal(b[1][1][r], it[1][1]) and np.array_equal(b[2][r], it[2])
+        assert np.array_equal(b[3][r], it[3]) and np.array_equal(b[4][r], it[4])
+    assert not np.array_equal(b[0][0], b[0][2]) or np.array_equal(b[2][0], b[2][2])     # the same grasp twice: independent draws
+    rb = ds.batch([1, 4], rng=np.random.default_rng(3))        # the generator form used by the batch iterators
+    assert rb[0].shape == (2, 40, 40, 40) and rb[2].shape == (2, 3) and rb[1][1].shape == (2, 2, 4)
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not ref_bootstrap.reference_available(), reason="/root/reference not present")
+def test_augmented_items_match_live_reference_class(tmp_path):
+    from oracle.make_feed_goldens import reference_items
+    root, raw = str(tmp_path / "data"), str(tmp_path / "raw")
+    make_dataset.write_dataset(root, raw, seed=5, occ_files=(2, 3))
+    idx = (1, 6, 12, 20)
+    _, ref = reference_items(root, raw, idx, 96, augment=True)
+    ds = dataset.GraspOccDataset(root, raw, num_point_occ=96, augment=True)
+    for i, r in zip(idx, ref):
+        torch.manual_seed(100 + i); np.random.seed(200 + i)
+        _same_item(ds.item(i), r)

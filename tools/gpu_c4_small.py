@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 net = networks.get_network("giga"); net.load_state_dict(weights.make_state_dict(7)); net = net.to(dev).eval()
 L = _capi.lib()
 modes = os.environ.get("GIGA_C4_MODES", "default").split(",")        # "layers" = one launch per U-Net layer, "default"
-for prec in os.environ.get("GIGA_C4_PRECS", "fp16,fp16x3").split(","):
+for prec in [q for q in os.environ.get("GIGA_C4_PRECS", "fp16,fp16x3").split(",") if q and q != "none"]:
     for B in scenes:
         for rep in range(int(os.environ.get("GIGA_C4_REPS", "1"))):
             for mode in modes:
