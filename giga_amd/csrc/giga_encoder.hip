@@ -494,10 +494,15 @@ __device__ __forceinline__ void xcd_barrier(unsigned* counter, unsigned target, 
     //  release -- measured no gain for groups of 8 workgroups and made a barrier among 32 workgroups slower: 384 pollers on one L2 line.)
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // performed in this XCD's L2
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz, independent of the shader clock
+        unsigned spins = 0;
+        unsigned long long t0 = 0;                             // (the clock is read every 1024 polls only: the read itself is slow)
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {   // an L2 read
             __builtin_amdgcn_s_sleep(1);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > MEGA_SPIN_TICKS) __builtin_trap();   // fail loudly, never hang the device
+            if ((++spins & 1023u) == 0) {
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();     // 100 MHz, independent of the shader clock
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > MEGA_SPIN_TICKS) __builtin_trap();               // fail loudly, never hang the device
+            }
         }
     }
     __syncthreads();
@@ -513,10 +518,15 @@ __device__ __forceinline__ void xcd_arrive(unsigned* counter) {
 }
 __device__ __forceinline__ void xcd_wait(unsigned* counter, unsigned target) {
     if (threadIdx.x == 0) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
+        unsigned long long t0 = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {   // an L2 read
             __builtin_amdgcn_s_sleep(1);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > MEGA_SPIN_TICKS) __builtin_trap();   // fail loudly, never hang the device
+            if ((++spins & 1023u) == 0) {
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > MEGA_SPIN_TICKS) __builtin_trap();               // fail loudly, never hang the device
+            }
         }
     }
     __syncthreads();
