@@ -596,27 +596,19 @@ constexpr int LAT_MAX_R = 40;
 // magnitude class, so lo is a NORMAL f16 number whenever the value itself is above 2^-13 (unscaled it would be subnormal for
 // every |value| < 2^-3), and the product lo * 2^-11 is exact
 constexpr float LAT_LO_SCALE = 2048.0f, LAT_LO_INV = 1.0f / 2048.0f;
-// groups of 4 line pixels one line set holds: every row over the whole line, or (HALF: a unit is half a slab, iy in one half)
-// the xz rows whole and the xy rows over the unit's half
-template <bool HALF>
-constexpr int lat_groups(int R) { return HALF ? NBLK * (R / 4) + (NBLK + 1) * (R / 8) : LAT_ROWS * (R / 4); }
-template <bool SPLIT, bool DBUF, bool HALF = false>
+template <bool SPLIT, bool DBUF>
 constexpr size_t lat_lds_bytes(int R) {
-    return (size_t)(32 * (SPLIT ? 2 : 1) + 1) * FRAG + (size_t)(DBUF ? 2 : 1) * lat_groups<HALF>(R) * 32 * 16 + 16;
+    return (size_t)(32 * (SPLIT ? 2 : 1) + 1) * FRAG + (size_t)(DBUF ? 2 : 1) * LAT_ROWS * (R / 4) * 32 * 16 + 16;
 }
 
 // WORK DISTRIBUTION inside a workgroup is DYNAMIC: tiles (and, with two line buffers, the next slab's line jobs) are items of a
 // pool that the waves drain through one LDS counter.  A static tile -> wave map loses a third of the slab: the SIMD arbiter
 // favours its older waves (s_memtime trace, profiles/r03: per tile 4.8 k clocks on waves 0-3, 5.5 k on 4-7, 7.6 k on 8-11), so
 // the old waves idle at the slab barrier while the young ones still owe two tiles.
-// DBUF: two line buffers (whole-slab line sets fit beside the 33-KiB image of the plain mode, not beside the 65 KiB of f16x3).
-// Pool s = the tiles of slab s + the line jobs of slab s + 1 (they fill the other buffer); ONE workgroup barrier per slab.  Single
-// buffer: pool s = the tiles of slab s; barrier, line phase of slab s + 1 (all waves), barrier.
-// HALF (round 4, the f16x3 mode's way to two buffers): a unit is HALF a slab -- the 25 tiles with iy in one half (a.lat_parts == 2)
-// -- and its line set holds the xz rows whole and the xy rows over that half only: 40 instead of 56 KiB, two of them fit beside the
-// 65-KiB image.  The xz rows are evaluated once per half (16 instead of 11 real line jobs per 25 tiles), but now under the tiles
-// of the previous unit instead of between two barriers with every matrix pipe idle.
-template <bool SPLIT, int NW, bool DBUF, bool HALF = false>
+// DBUF: two line buffers (fits beside the 33-KiB image of the plain mode, not beside the 65 KiB of f16x3).  Pool s = the tiles of
+// slab s + the line jobs of slab s + 1 (they fill the other buffer); ONE workgroup barrier per slab.  Single buffer: pool s = the
+// tiles of slab s; barrier, line phase of slab s + 1 (all waves), barrier.
+template <bool SPLIT, int NW, bool DBUF>
 __global__ __launch_bounds__(NW * 64) void decoder_lat_kernel(DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int PR = SPLIT ? 2 : 1;                          // fragments per weight chunk ([hi, lo] pair or single)
@@ -662,10 +654,7 @@ __global__ __launch_bounds__(NW * 64) void decoder_lat_kernel(DecArgs a) {
     const float* ctab = reinterpret_cast<const float*>(smem + (size_t)WF * FRAG);
     // lines: [row][group of 4 pixels][feature 0..31][pixel % 4] x (hi, lo * 2^11) halfs = 16 bytes per (row, group, feature)
     uint8_t* G0 = smem + (size_t)(WF + 1) * FRAG;
-    const int RGH = RG >> 1, RH = R >> 1;                      // (HALF) groups / pixels of half a line
-    const size_t gbytes = (size_t)lat_groups<HALF>(R) * 32 * 16;
-    // first group of line row `row` inside a line set
-    auto row_base = [&](int row) -> int { return HALF ? (row < NBLK ? row * RG : NBLK * RG + (row - NBLK) * RGH) : row * RG; };
+    const size_t gbytes = (size_t)LAT_ROWS * RG * 32 * 16;
     unsigned* counter = reinterpret_cast<unsigned*>(G0 + (DBUF ? 2 : 1) * gbytes);
     const half8* Wg = reinterpret_cast<const half8*>(img);
     const half_t* planes = reinterpret_cast<const half_t*>(a.planes);
@@ -739,11 +728,8 @@ __global__ __launch_bounds__(NW * 64) void decoder_lat_kernel(DecArgs a) {
         if (32 * ct >= R) return;
         const bool xy = row >= NBLK;
         const int blk = xy ? row - NBLK : row;
-        const bool halfrow = HALF && xy;                       // an xy row of a half-slab unit: the RH pixels of the unit's half
-        if (halfrow && ct != 0) return;
-        const int px0 = halfrow ? RH * (unit - slab * NP) : 32 * ct;
-        int px = px0 + n;
-        const bool pvalid = halfrow ? n < RH : px < R;
+        int px = 32 * ct + n;
+        const bool pvalid = px < R;
         px = pvalid ? px : R - 1;
         f32x16 acc;
 #pragma unroll
@@ -772,7 +758,7 @@ __global__ __launch_bounds__(NW * 64) void decoder_lat_kernel(DecArgs a) {
             acc = mfma16(Wg[(blk < NBLK ? BLK * blk + F_AUX : F_TAIL) * 64 + lane], av, acc);
         }
         if (pvalid) {                                           // this lane: pixel px, features 8q + 4hi + j  ->  (hi, 2^11 lo) pairs
-            uint8_t* g = G + ((size_t)(row_base(row) + (halfrow ? n >> 2 : px >> 2)) * 32) * 16 + (px & 3) * 4;
+            uint8_t* g = G + ((size_t)(row * RG + (px >> 2)) * 32) * 16 + (px & 3) * 4;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const half_t h = (half_t)acc[r];
@@ -857,8 +843,7 @@ __global__ __launch_bounds__(NW * 64) void decoder_lat_kernel(DecArgs a) {
         const uint8_t* G = G0 + (DBUF ? (size_t)(pool & 1) * gbytes : 0);
         // net += line row `row`, pixel group `grp` (this lane: feature n, the group's 4 pixels as (hi, lo) pairs) through `sel`
         auto add_line = [&](int row, int grp, const half8& sel, f32x16& net) {
-            const int gl = (HALF && row >= NBLK) ? grp - RGH * (slab - sl * NP) : grp;     // (HALF) xy rows hold the unit's half only
-            const half8 A = *reinterpret_cast<const half8*>(G + ((size_t)(row_base(row) + gl) * 32 + n) * 16);
+            const half8 A = *reinterpret_cast<const half8*>(G + ((size_t)(row * RG + grp) * 32 + n) * 16);
             net = mfma16(A, sel, net);
         };
         {
@@ -1445,10 +1430,6 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
                 if (cost < best - 1e-9) { best = cost; np = c; }
             }
         }
-        // f16x3 with half-slab units (two line sets in LDS): always two parts per slab (tuning knob GIGA_LAT_HALF=0: the single line
-        // buffer of round 3)
-        const bool half = precision == 2 && (a.R / 4) % 2 == 0 && [] { const char* e = getenv("GIGA_LAT_HALF"); return e ? atoi(e) != 0 : true; }();
-        if (half) np = 2;
         a.lat_parts = np;
         const int nslab = a.B * a.R * np;
         int slots = nslab < cap ? nslab : (nslab >= 2 * cap8 && cap8 > 0 ? cap8 : cap);
@@ -1459,10 +1440,7 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
             giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
             GIGA_LAUNCH(kern, dim3(slots * a.nheads), dim3(NWv * 64), lds, s, a);
         };
-        if (precision == 2 && half) {
-            if (nw == 16) go(decoder_lat_kernel<true, 16, true, true>, 16, lat_lds_bytes<true, true, true>(a.R));
-            else go(decoder_lat_kernel<true, 12, true, true>, 12, lat_lds_bytes<true, true, true>(a.R));
-        } else if (precision == 2) {
+        if (precision == 2) {
             if (nw == 16) go(decoder_lat_kernel<true, 16, false>, 16, lat_lds_bytes<true, false>(a.R));
             else go(decoder_lat_kernel<true, 12, false>, 12, lat_lds_bytes<true, false>(a.R));
         } else {
