@@ -80,7 +80,7 @@ def traffic_lookup(workload, fragment):
     (bytes or None, provenance or None)."""
     if not fragment:
         return None, None
-    for rnd in ("r03", "r02"):                             # the newest committed table that knows the kernel
+    for rnd in ("r04", "r03", "r02"):                             # the newest committed table that knows the kernel
         try:
             tab = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_traffic_{workload}.json")))
         except (OSError, ValueError):

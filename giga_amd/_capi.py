@@ -20,7 +20,9 @@ ENC_BF16 = 3             # encoder `precision` 3: bf16 U-Net convolutions, fp32 
 FOLD_FINAL = 16          # GIGA_FOLD_FINAL: OR-ed into `precision` of an encoder call and of the decoder calls on its planes
 PERSIST_UNET = 32        # GIGA_PERSIST_UNET: OR-ed into `precision` of an encoder call (one persistent U-Net launch)
 LAYERWISE_UNET = 64      # GIGA_LAYERWISE_UNET: one launch per U-Net layer even for small batches
-CONV32_UNET = 128        # GIGA_CONV32_UNET: the f16-class U-Net on the conv32 kernels (opt-in)
+CONV32_UNET = 128        # GIGA_CONV32_UNET: the f16-class U-Net on the conv32 kernels (the library's default)
+CONV16_UNET = 256        # GIGA_CONV16_UNET: ... on the conv16 kernels
+PATH_PERSISTENT, PATH_CONV32, PATH_FUSED_PAIRS = 1, 2, 4          # giga_encoder_last_path()
 MAX_SCENES = 3072        # GIGA_MAX_SCENES: scenes per encoder / training call (error -7 beyond)
 HEAD_BITS = {"decoder_qual": 1, "decoder_rot": 2, "decoder_width": 4, "decoder_tsdf": 8}
 PRECISION = {"fp32": 0, "fp16": 1, "fp16x3": 2, "bf16": 3}     # include/giga_hip.h `precision` (3: encoder only)
@@ -75,6 +77,7 @@ _SIGNATURES = {
                                       ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int,
                                       ctypes.c_void_p]),
     "giga_launch_count": (ctypes.c_ulonglong, []),
+    "giga_encoder_last_path": (ctypes.c_int, []),
     "giga_event_create": (ctypes.c_void_p, []),
     "giga_event_destroy": (None, [ctypes.c_void_p]),
     "giga_event_record": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

@@ -258,7 +258,7 @@ class LocalVoxelEncoder(nn.Module):
             _capi.check(L.giga_encoder_forward_probe(_capi.ptr(x), _capi.ptr(blob), _capi.ptr(nhwc), _capi.ptr(nchw),
                                                      B, prec | (_capi.FOLD_FINAL if fold_final else 0) |
                                                      {False: 0, True: _capi.PERSIST_UNET, "layers": _capi.LAYERWISE_UNET}[getattr(self, "persistent_unet", False)] |
-                                                     (_capi.CONV32_UNET if getattr(self, "unet_kernel", "conv16") == "conv32" and prec in (1, 2) else 0),
+                                                     ({"conv32": _capi.CONV32_UNET, "conv16": _capi.CONV16_UNET}.get(getattr(self, "unet_kernel", "auto"), 0) if prec in (1, 2) else 0),
                                                      _capi.ptr(ws), ws.numel(), _capi.stream_ptr(x.device),
                                                      stage, ev0, ev1),
                         "giga_encoder_forward")
@@ -523,10 +523,11 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
         self.encoder.persistent_unet = "layers" if enabled == "layers" else bool(enabled)
         return self
 
-    def set_unet_kernel(self, kernel="conv16"):
-        """Which convolution kernels run the f16-class U-Net (include/giga_hip.h, GIGA_CONV32_UNET): "conv16" (default) or "conv32"
-        (32x32x16 MFMA register tiles over LDS-resident row bands; 'fp16' and 'fp16x3' only -- other precisions keep conv16)."""
-        if kernel not in ("conv16", "conv32"):
+    def set_unet_kernel(self, kernel="auto"):
+        """Which convolution kernels run the f16-class U-Net ('fp16', 'fp16x3'; include/giga_hip.h, GIGA_CONV32_UNET / GIGA_CONV16_UNET):
+        "auto" (the library's default: conv32 -- 32x32x16 MFMA register tiles over LDS-resident row bands -- unless the environment
+        says GIGA_CONV32=0), "conv32" or "conv16" (16x16x32, wave-private patches; the only kernels of 'fp32' / 'bf16')."""
+        if kernel not in ("auto", "conv16", "conv32"):
             raise ValueError(kernel)
         self.encoder.unet_kernel = kernel
         return self

@@ -33,8 +33,15 @@ static __device__ long long g_c32_trace[NCONV][C32_NW][8];
 #endif
 
 // the member's WFR fragments of channel part `part` -> LDS bytes [0, WBYTES): 1 KiB per wave instruction (all waves take part)
+// The layer's biases ride along (part 0; float `boff` of the bias block behind the images): a register tile starts from them, and
+// fetching them from memory at the start of every tile costs a global-load latency per tile (1.5-2 k clocks: as long as the
+// MFMAs of a one-scene tile).
+__device__ __forceinline__ float* c32_bias_lds() {
+    extern __shared__ __attribute__((aligned(16))) uint8_t c32_dyn_lds[];                  // (every dynamic LDS array starts at the same byte)
+    return reinterpret_cast<float*>(c32_dyn_lds + C32_LDS);
+}
 template <class G>
-__device__ __forceinline__ void c32_fill(const ConvArgs& a, uint8_t* smem, int member, int part = 0) {
+__device__ __forceinline__ void c32_fill(const ConvArgs& a, uint8_t* smem, int member, int part = 0, int boff = 0) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sgm = G::member_sgm(member);
@@ -42,6 +49,14 @@ __device__ __forceinline__ void c32_fill(const ConvArgs& a, uint8_t* smem, int m
     for (int c = wave; c < G::WFR; c += C32_NW)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)G::fill_src(c, sgm, part) * FRAG),
                                          (__attribute__((address_space(3))) void*)(smem + c * FRAG), 16, 0, 0);
+    static_assert(G::COUT * 4 <= C32_BIAS_BYTES, "bias block");
+    if (part == 0 && wave == C32_NW - 1) {
+#pragma unroll
+        for (int c = 0; c < (G::COUT + 63) / 64; ++c)
+            if (64 * c + lane < G::COUT)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.bias + 64 * c + lane),
+                                                 (__attribute__((address_space(3))) void*)(c32_bias_lds() + boff + 64 * c), 4, 0, 0);
+    }
 }
 
 // ---- staging: the haloed sub-band [sb - HALO, sb + R + HALO) x P pixels -> LDS ------------------------------------------------
@@ -180,7 +195,11 @@ __device__ __forceinline__ void c32_stage(const ConvArgs& a, uint8_t* smem, int 
 // wl: this lane's LDS byte offset of the first A fragment of the slice pass (lane * 16 + pass base); base[j]: its B offset of tile j
 template <class G, int NTB>
 __device__ __forceinline__ void c32_mma(const uint8_t* smem, const int wl, const int (&base)[NTB], f32x16 (&acc)[NTB][G::SPW]) {
-    constexpr int NIT = G::NIT, PD = NIT < 3 ? NIT : 3;
+    // ring depth: operands are requested ~400 clocks of MFMA work ahead (an LDS read under load takes 150-300 clocks; a step
+    // of a small register tile is a single 32-clock MFMA, and with one wave per SIMD at small batches nobody else hides it)
+    constexpr int MPS = NTB * G::SPW * (G::MODE == C32_SPLIT ? 3 : 1);
+    constexpr int PDW = (12 + MPS - 1) / MPS < 3 ? 3 : (12 + MPS - 1) / MPS > 8 ? 8 : (12 + MPS - 1) / MPS;
+    constexpr int NIT = G::NIT, PD = NIT < PDW ? NIT : PDW;
     uint4 ra[PD][G::SPW][G::NOP], rb[PD][NTB][G::NOP];
     auto rd = [&](const int it, const int slot) {
         const int off = G::tap_off(it / G::KCP) + G::kc_off(it % G::KCP);
@@ -227,15 +246,16 @@ struct C32Tile {
     using T = std::conditional_t<G::MODE == C32_NATIVE, half_t, float>;
     f32x16 acc[NTB][G::SPW];
     int base[NTB];
-    __device__ __forceinline__ void init(const ConvArgs& a, int sgm, int sp, int t0, int NT) {
+    // ioff: byte offset of the staged image behind the weights (a fused pair keeps two images)
+    __device__ __forceinline__ void init(const ConvArgs& a, int sgm, int sp, int t0, int NT, int ioff = 0, int boff = 0) {
         const int lane = threadIdx.x & 63, hi = lane >> 5;
-        const int lbase = G::lane_base(lane);
+        const int lbase = G::lane_base(lane) + ioff;
 #pragma unroll
         for (int j = 0; j < NTB; ++j) base[j] = (t0 + j < NT ? t0 + j : t0) * G::tile_step() + lbase;   // (a missing tile repeats the first; not stored)
 #pragma unroll
         for (int s = 0; s < G::SPW; ++s) {                 // accumulator init = bias of the lane's 16 output channels
             const int cs = (sgm * G::SPM + sp * G::SPW + s) % G::CS;
-            const float4* bp = reinterpret_cast<const float4*>(a.bias + 32 * cs + 16 * hi);
+            const float4* bp = reinterpret_cast<const float4*>(c32_bias_lds() + boff + 32 * cs + 16 * hi);   // (LDS: c32_fill)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 b4 = bp[q];
@@ -287,16 +307,141 @@ struct C32Tile {
     }
 };
 
+// ---- fused pair A -> B (giga_conv32_geom.h: C32Pair): A's epilogue writes B's input image in LDS ------------------------------------
+// the register tile of A (sgm = 0): values -> B's image (every row of A's sub-band) and, for the rows the member owns, memory
+template <class GA, class GB, bool RELU, int NTB>
+__device__ __forceinline__ void c32_store_mid(const C32Tile<GA, RELU, NTB>& t, const ConvArgs& a, uint8_t* mid, int sp, int t0, int NT,
+                                              int sbA, int RA, int R) {
+    using T = std::conditional_t<GA::MODE == C32_NATIVE, half_t, float>;
+    using PR = C32Pair<GA, GB>;
+    const int lane = threadIdx.x & 63, n = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NTB; ++j) {
+        if (t0 + j >= NT) continue;
+        const typename GA::Out o = GA::out_pixel(t0 + j, n, sbA, RA);
+        if (!o.valid) continue;
+        const bool own = o.orow >= 1 && o.orow <= R;           // (A's sub-band = the member's rows + one above and one below)
+#pragma unroll
+        for (int s = 0; s < GA::SPW; ++s) {
+            const int cs = (sp * GA::SPW + s) % GA::CS;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = RELU ? relu(t.acc[j][s][r]) : t.acc[j][s][r];
+            uint8_t* d = mid + PR::mid_off(o.orow, o.x, 4 * cs + 2 * hi);
+            T* dst = reinterpret_cast<T*>(a.out) + (size_t)GA::out_index(o.g, o.y, o.x, 0) * GA::COUT + 32 * cs + 16 * hi;
+            if constexpr (GA::MODE == C32_NATIVE) {
+                half8 h0, h1;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { h0[r] = (half_t)v[r]; h1[r] = (half_t)v[8 + r]; }
+                *reinterpret_cast<half8*>(d) = h0;
+                *reinterpret_cast<half8*>(d + 16) = h1;
+                if (own) { *reinterpret_cast<half8*>(dst) = h0; *reinterpret_cast<half8*>(dst + 8) = h1; }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float x8[8] = {v[8 * k], v[8 * k + 1], v[8 * k + 2], v[8 * k + 3], v[8 * k + 4], v[8 * k + 5], v[8 * k + 6], v[8 * k + 7]};
+                    if constexpr (GA::MODE == C32_SPLIT) {
+                        half8 xh, xl;
+                        split8(x8, xh, xl);
+                        *reinterpret_cast<half8*>(d + 32 * k) = xh;
+                        *reinterpret_cast<half8*>(d + 32 * k + 16) = xl;
+                    } else {
+                        bf16x8v b8;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) b8[e] = (__bf16)x8[e];
+                        *reinterpret_cast<bf16x8v*>(d + 16 * k) = b8;
+                    }
+                }
+                if (own) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                }
+            }
+        }
+    }
+}
+template <class GA, class GB, bool RELU, int NTB>
+__device__ __forceinline__ void c32_tiles_mid(const ConvArgs& a, uint8_t* smem, int ioff, uint8_t* mid, int NT, int sbA, int RA, int R) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nbatch = (NT + NTB - 1) / NTB;
+    for (int bi = wave; bi < nbatch; bi += C32_NW) {
+#pragma unroll 1
+        for (int sp = 0; sp < GA::NSP; ++sp) {
+            C32Tile<GA, RELU, NTB> t;
+            t.init(a, 0, sp, bi * NTB, NT, ioff);
+            t.mma(smem, sp);
+            c32_store_mid<GA, GB, RELU, NTB>(t, a, mid, sp, bi * NTB, NT, sbA, RA, R);
+        }
+    }
+}
+// can A -> B run as a fused pair?  (same-resolution 3x3 layers, whole weights of both in LDS, room for sub-bands of 6 rows and more)
+template <class GA, class GB>
+constexpr bool c32_pair_ok() {
+    if constexpr (GA::KIND == CONV3 && GB::KIND == CONV3 && GA::H == GB::H && GA::COUT == GB::CIN && GB::C1 == 0 && !GB::POOLIN &&
+                  GA::SGM == 1 && GB::SGM == 1 && GA::KP == 1 && GB::KP == 1)
+        return (C32_LDS - GA::WBYTES - GB::WBYTES - (4 * GA::ROWB + 2 * GB::ROWB + C32_TAIL * (GA::PS + GB::PS))) / (GA::ROWB + GB::ROWB) >= 6;
+    else
+        return false;
+}
+// both weight sets: A's at LDS byte 0, B's behind them
+template <class GA, class GB>
+__device__ __forceinline__ void c32_fill_pair(const ConvArgs& a, const ConvArgs& b, uint8_t* smem, int member) {
+    c32_fill<GA>(a, smem, member, 0, 0);
+    c32_fill<GB>(b, smem + GA::WBYTES, member, 0, 64);
+}
+// layers A and B for one member of a group, no group barrier between them
+template <class GA, class GB, bool RELU_A, bool RELU_B>
+__device__ __forceinline__ void c32_run_pair(const ConvArgs& a, const ConvArgs& b, uint8_t* smem, int member) {
+    using PR = C32Pair<GA, GB>;
+    int sA, sB, nsb, rows;
+    GB::member_rows(member, b.nimg, sA, sB);
+    PR::sub_bands(sA, sB, nsb, rows);
+    C32_T(a, 0);
+    for (int bi = 0; bi < nsb; ++bi) {
+        const int sb = sA + bi * rows;
+        const int R = (sB - sb) < rows ? (sB - sb) : rows;
+        uint8_t* mid = smem + PR::mid0(R);
+        if (bi > 0) __syncthreads();                       // everyone has finished reading the previous sub-band's images
+        {
+            C32Stage<GA> st(a, smem + PR::WB, sb - 1, R + 2, 0);      // A's input: the member's rows with a halo of two
+            st.run();
+            C32Stage<GB> zb(b, mid - GB::WBYTES, sb, R, 0);           // the zero rows / columns of B's image
+            zb.zeros();
+        }
+        C32_T(a, 1);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's share of both weight fills has landed
+        __syncthreads();
+        C32_T(a, 2);
+        {
+            const int NT = GA::n_tiles(R + 2), ntb = GA::batch_tiles(NT);
+            if (ntb == 1) c32_tiles_mid<GA, GB, RELU_A, 1>(a, smem, PR::WB, mid, NT, sb - 1, R + 2, R);
+            else if (ntb == 2) c32_tiles_mid<GA, GB, RELU_A, 2>(a, smem, PR::WB, mid, NT, sb - 1, R + 2, R);
+            else if constexpr (GA::NTBM >= 3) c32_tiles_mid<GA, GB, RELU_A, 3>(a, smem, PR::WB, mid, NT, sb - 1, R + 2, R);
+        }
+        C32_T(a, 3);
+        __syncthreads();                                   // B's image is complete
+        C32_T(b, 2);
+        {
+            const int NT = GB::n_tiles(R), ntb = GB::batch_tiles(NT);
+            if (ntb == 1) c32_tiles<GB, RELU_B, 1>(b, smem + PR::WA, 0, NT, sb, R, PR::imgA_bytes(R), 64);
+            else if (ntb == 2) c32_tiles<GB, RELU_B, 2>(b, smem + PR::WA, 0, NT, sb, R, PR::imgA_bytes(R), 64);
+            else if constexpr (GB::NTBM >= 3) c32_tiles<GB, RELU_B, 3>(b, smem + PR::WA, 0, NT, sb, R, PR::imgA_bytes(R), 64);
+        }
+        C32_T(b, 3);
+    }
+}
+
 // the tiles of one staged sub-band (KP == 1): batches of NTB tiles dealt over the waves, all slice passes of the member per batch
 template <class G, bool RELU, int NTB>
-__device__ __forceinline__ void c32_tiles(const ConvArgs& a, const uint8_t* smem, int sgm, int NT, int sb, int R) {
+__device__ __forceinline__ void c32_tiles(const ConvArgs& a, const uint8_t* smem, int sgm, int NT, int sb, int R, int ioff = 0, int boff = 0) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nbatch = (NT + NTB - 1) / NTB;
     for (int bi = wave; bi < nbatch; bi += C32_NW) {
 #pragma unroll 1
         for (int sp = 0; sp < G::NSP; ++sp) {
             C32Tile<G, RELU, NTB> t;
-            t.init(a, sgm, sp, bi * NTB, NT);
+            t.init(a, sgm, sp, bi * NTB, NT, ioff, boff);
             t.mma(smem, sp);
             t.store(a, sgm, sp, bi * NTB, NT, sb, R);
         }
@@ -310,7 +455,6 @@ __device__ __forceinline__ void c32_parts(const ConvArgs& a, uint8_t* smem, int 
     const int sgm = G::member_sgm(member);
     const bool mine = wave * NTB < NT;
     C32Tile<G, RELU, NTB> t;
-    t.init(a, sgm, 0, wave * NTB, NT);
 #pragma unroll 1
     for (int part = 0; part < G::KP; ++part) {
         if (part > 0 || !filled) {
@@ -320,6 +464,7 @@ __device__ __forceinline__ void c32_parts(const ConvArgs& a, uint8_t* smem, int 
         c32_stage<G>(a, smem, sb, R, part);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
+        if (part == 0) t.init(a, sgm, 0, wave * NTB, NT);  // (the biases arrived with part 0's weights)
         if (mine) t.mma(smem, 0);
     }
     if (mine) t.store(a, sgm, 0, wave * NTB, NT, sb, R);
@@ -328,31 +473,41 @@ __device__ __forceinline__ void c32_parts(const ConvArgs& a, uint8_t* smem, int 
 // ---- one layer for one member of a group: `a` is already the group's image range (a.nimg = its G images); the member's
 // weights (part 0) are on their way into LDS (c32_fill, issued by the caller before its barrier).
 template <class G, bool RELU>
+__device__ __forceinline__ void c32_tiles_any(const ConvArgs& a, const uint8_t* smem, int sgm, int NT, int sb, int R, int ioff) {
+    const int ntb = G::batch_tiles(NT);
+    if (ntb == 1) c32_tiles<G, RELU, 1>(a, smem, sgm, NT, sb, R, ioff);
+    else if (ntb == 2) c32_tiles<G, RELU, 2>(a, smem, sgm, NT, sb, R, ioff);
+    else if constexpr (G::NTBM >= 3) c32_tiles<G, RELU, 3>(a, smem, sgm, NT, sb, R, ioff);
+}
+template <class G, bool RELU>
 __device__ __forceinline__ void c32_run(const ConvArgs& a, uint8_t* smem, int member) {
     const int sgm = G::member_sgm(member);
     int sA, sB, nsb, rows;
     G::member_rows(member, a.nimg, sA, sB);
-    G::sub_bands(sA, sB, nsb, rows);
     C32_T(a, 0);
-    for (int b = 0; b < nsb; ++b) {
-        const int sb = sA + b * rows;
-        const int R = (sB - sb) < rows ? (sB - sb) : rows;
-        const int NT = G::n_tiles(R);
-        const int ntb = G::batch_tiles(NT);
-        if constexpr (G::KP > 1) {
+    if constexpr (G::KP > 1) {
+        G::sub_bands(sA, sB, nsb, rows);
+        for (int b = 0; b < nsb; ++b) {
+            const int sb = sA + b * rows;
+            const int R = (sB - sb) < rows ? (sB - sb) : rows;
+            const int NT = G::n_tiles(R);
+            const int ntb = G::batch_tiles(NT);
             if (ntb == 1) c32_parts<G, RELU, 1>(a, smem, member, b == 0, NT, sb, R);
             else if (ntb == 2) c32_parts<G, RELU, 2>(a, smem, member, b == 0, NT, sb, R);
             else if constexpr (G::NTBM >= 3) c32_parts<G, RELU, 3>(a, smem, member, b == 0, NT, sb, R);
-        } else {
+        }
+    } else {
+        G::sub_bands(sA, sB, nsb, rows);
+        for (int b = 0; b < nsb; ++b) {
+            const int sb = sA + b * rows;
+            const int R = (sB - sb) < rows ? (sB - sb) : rows;
             if (b > 0) __syncthreads();                    // everyone has finished reading the previous sub-band
             c32_stage<G>(a, smem, sb, R);
             C32_T(a, 1);
             __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's share of the weight fill has landed
             __syncthreads();                               // (the compiler waits for the LDS writes before the barrier)
             C32_T(a, 2);
-            if (ntb == 1) c32_tiles<G, RELU, 1>(a, smem, sgm, NT, sb, R);
-            else if (ntb == 2) c32_tiles<G, RELU, 2>(a, smem, sgm, NT, sb, R);
-            else if constexpr (G::NTBM >= 3) c32_tiles<G, RELU, 3>(a, smem, sgm, NT, sb, R);
+            c32_tiles_any<G, RELU>(a, smem, sgm, G::n_tiles(R), sb, R, 0);
             C32_T(a, 3);
         }
     }
@@ -400,8 +555,8 @@ template <class G, bool RELU>
 inline int launch_conv32(const ConvArgs& a, hipStream_t s) {
     const int nq = c32_groups(a.nimg);
     auto kern = conv32_kernel<G, RELU>;
-    giga::dyn_lds_once(reinterpret_cast<const void*>(kern), C32_LDS);
-    GIGA_LAUNCH(kern, dim3(nq * C32_GROUP), dim3(C32_NW * 64), C32_LDS, s, a, nq);
+    giga::dyn_lds_once(reinterpret_cast<const void*>(kern), C32_LDS_TOTAL);
+    GIGA_LAUNCH(kern, dim3(nq * C32_GROUP), dim3(C32_NW * 64), C32_LDS_TOTAL, s, a, nq);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 

@@ -49,6 +49,8 @@ constexpr int C32_BF16 = 2;       // fp32 activations in memory, bf16 operands, 
 constexpr int C32_NW = 8;                          // waves per workgroup: two per SIMD, up to 256 VGPRs each
 constexpr int C32_GROUP = 8;                       // workgroups per group (unet_mega_kernel's groups)
 constexpr int C32_LDS = 160 * 1024 - 1024;         // dynamic LDS of the kernels (the persistent kernel keeps a few static words)
+constexpr int C32_BIAS_BYTES = 512;                // behind the C32_LDS bytes of weights + images: the layer's biases (two sets of 64 for a fused pair)
+constexpr int C32_LDS_TOTAL = C32_LDS + C32_BIAS_BYTES;
 constexpr int C32_TAIL = 32;                       // pixels a tile may read past the staged sub-band (discarded lanes only)
 constexpr int C32_NTB_MAX = 3;                     // tiles of a wave's register tile at most
 
@@ -203,6 +205,7 @@ struct C32 {
         if (HALO == 0) return false;
         const int brow = q / P, col = q - brow * P;
         const int s = sb - HALO + brow;
+        if (s < 0) return true;                          // (above the first zero row: the upper halo of a fused pair's first member)
         const int g = s / SR, r = s - g * SR;
         return r == 0 || g >= G || col == 0 || col == P - 1;
     }
@@ -215,11 +218,12 @@ struct C32 {
     static constexpr int kc_off(int kc) { return kc * KB; }
 
     // output pixel of lane column n of tile t
-    struct Out { int g, y, x; bool valid; };
+    struct Out { int g, y, x, orow; bool valid; };
     static GIGA_HD Out out_pixel(int t, int n, int sb, int R) {
         Out o;
         const int lin = 32 * t + n;
         const int orow = lin / P;
+        o.orow = orow;
         o.x = lin - orow * P;
         const int s = sb + orow;
         o.g = s / SR;
@@ -231,6 +235,34 @@ struct C32 {
     static GIGA_HD int out_index(int g, int y, int x, int sub) {
         return KIND == UPCONV ? (g * OH + 2 * y + (sub >> 1)) * OW + 2 * x + (sub & 1) : (g * H + y) * W + x;
     }
+};
+
+// ---- FUSED PAIRS --------------------------------------------------------------------------------------------------------------------
+// Two consecutive 3x3 layers A -> B of the same resolution whose weights both fit (SGM = 1, KP = 1): a member computes A for its
+// band PLUS one row above and below (A's input staged with a halo of two), writes those rows into LDS as B's input image -- zero
+// rows and columns in place, in B's pixel format -- and computes B from there.  No group barrier, no store acknowledgement, no
+// reload between the two layers: one layer boundary less, paid with (R + 2) / R of A's MFMAs.  A's own rows still go to memory
+// (the workspace layout of the C ABI exposes them); the two recomputed rows do not (the neighbours write theirs).
+// LDS: [weights A | weights B | image A: (R + 4) rows | image B ("mid"): (R + 2) rows].
+template <class GA, class GB>
+struct C32Pair {
+    static_assert(GA::KIND == CONV3 && GB::KIND == CONV3 && GA::H == GB::H && GA::W == GB::W, "same-resolution 3x3 layers");
+    static_assert(GA::COUT == GB::CIN && GB::C1 == 0 && !GB::POOLIN, "B reads A's output");
+    static_assert(GA::SGM == 1 && GB::SGM == 1 && GA::KP == 1 && GB::KP == 1 && GA::MODE == GB::MODE, "whole pixels, whole weights");
+    static constexpr int WA = GA::WBYTES, WB = GB::WBYTES;
+    static constexpr int FIX = 4 * GA::ROWB + 2 * GB::ROWB + C32_TAIL * (GA::PS + GB::PS);
+    static constexpr int RBMAX = (C32_LDS - WA - WB - FIX) / (GA::ROWB + GB::ROWB);      // rows of B per sub-band
+    static_assert(RBMAX >= 1, "a fused pair must fit at least one row");
+    static GIGA_HD int imgA_bytes(int R) { return ((R + 4) * GA::P + C32_TAIL) * GA::PS; }
+    static GIGA_HD int mid0(int R) { return WA + WB + imgA_bytes(R); }                    // first byte of B's image
+    static GIGA_HD int lds_bytes(int R) { return mid0(R) + ((R + 2) * GB::P + C32_TAIL) * GB::PS; }
+    static GIGA_HD void sub_bands(int sA, int sB, int& n, int& rows) {
+        const int r = sB - sA;
+        n = (r + RBMAX - 1) / RBMAX;
+        rows = n ? (r + n - 1) / n : 0;
+    }
+    // LDS byte offset (from the start of B's image) of the 8-channel group `v` of A's output pixel (row orow of A's sub-band, column x)
+    static GIGA_HD int mid_off(int orow, int x, int v) { return (orow * GB::P + x + 1) * GB::PS + v * GB::ILB; }
 };
 
 // The U-Net on conv32.  X(layer, KIND, C0, C1, COUT, H, W, POOLIN, SPW, SGM f16 / bf16, SGM f16x3, KP f16x3): layer order of

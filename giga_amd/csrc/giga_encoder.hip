@@ -627,7 +627,7 @@ __global__ __launch_bounds__(MEGA_NW * 64) void unet_mega_kernel(MegaArgs m) {
 // (all output channels), keeps its sub-band of the layer's input resident in LDS and its weights in registers.  4 waves of up to
 // 512 VGPRs.  The layer table (GIGA_UNET32_LAYERS) lives in giga_conv32_geom.h.
 // ----------------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool FUSE>
 __global__ __launch_bounds__(C32_NW * 64) void unet32_mega_kernel(MegaArgs m) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // placement by ticket: see unet_mega_kernel
@@ -650,9 +650,6 @@ __global__ __launch_bounds__(C32_NW * 64) void unet32_mega_kernel(MegaArgs m) {
     // FIRST(l): request the weights of layer l, no barrier.  NEXT(l): arrive at the group barrier, request layer l's weights
     // (LDS-DMA: they land while the barrier is waited for), then wait.  RUN(l): stage / MFMA / store; then every wave's stores
     // are acknowledged by the L2 and every wave has left the LDS image.
-#define FIRST(l)                                                                                                   \
-    using G##l = typename U32Layer<MODE, l>::G;                                                                    \
-    c32_fill<G##l>(m.layer[l], smem, block);
 #define NEXT(l)                                                                                                    \
     using G##l = typename U32Layer<MODE, l>::G;                                                                    \
     if (l < m.nlayers) {                                                                                           \
@@ -675,20 +672,43 @@ __global__ __launch_bounds__(C32_NW * 64) void unet32_mega_kernel(MegaArgs m) {
 #else
 #define MEGA32_T(l, idx) do {} while (0)
 #endif
-    FIRST(0) RUN(0)
-    NEXT(1) RUN(1)
-    NEXT(2) RUN(2)
-    NEXT(3) RUN(3)
+    // PAIR(a, b): two same-resolution 3x3 layers without the barrier between them (C32Pair) where the mode's weights fit side by side
+#define PAIR(la, lb, FIRSTA)                                                                                       \
+    using G##la = typename U32Layer<MODE, la>::G;                                                                  \
+    using G##lb = typename U32Layer<MODE, lb>::G;                                                                  \
+    if constexpr (FUSE && c32_pair_ok<G##la, G##lb>()) {                                                           \
+        if (!(FIRSTA)) xcd_arrive(counter);                                                                        \
+        c32_fill_pair<G##la, G##lb>(m.layer[la], m.layer[lb], smem, block);                                        \
+        if (!(FIRSTA)) { MEGA32_T(la, 5); xcd_wait(counter, ++epoch * (unsigned)MEGA_GROUP); MEGA32_T(la, 6); }    \
+        c32_run_pair<G##la, G##lb, U32Layer<MODE, la>::RELU, U32Layer<MODE, lb>::RELU>(                            \
+            c32_image_range<G##la>(m.layer[la], img0, per), c32_image_range<G##lb>(m.layer[lb], img0, per), smem, block); \
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                                                        \
+        __syncthreads();                                                                                           \
+        MEGA32_T(lb, 4);                                                                                           \
+    } else {                                                                                                       \
+        if (FIRSTA) { c32_fill<G##la>(m.layer[la], smem, block); } else { NEXT_(la) }                              \
+        RUN(la) NEXT_(lb) RUN(lb)                                                                                  \
+    }
+#define NEXT_(l)                                                                                                   \
+    {                                                                                                              \
+        xcd_arrive(counter);                                                                                       \
+        c32_fill<G##l>(m.layer[l], smem, block);                                                                   \
+        MEGA32_T(l, 5);                                                                                            \
+        xcd_wait(counter, ++epoch * (unsigned)MEGA_GROUP);                                                         \
+        MEGA32_T(l, 6);                                                                                            \
+    }
+    PAIR(0, 1, true)
+    PAIR(2, 3, false)
     NEXT(4) RUN(4)
     NEXT(5) RUN(5)
     NEXT(6) RUN(6)
     NEXT(7) RUN(7)
     NEXT(8) RUN(8)
     NEXT(9) RUN(9)
-    NEXT(10) RUN(10)
-    NEXT(11) RUN(11)
+    PAIR(10, 11, false)
     NEXT(12) RUN(12)
-#undef FIRST
+#undef PAIR
+#undef NEXT_
 #undef NEXT
 #undef RUN
 }
@@ -749,9 +769,12 @@ static void persistent_launched(int slot, hipStream_t s) {
 // (k = 0 conv_in+project, 1 plane_finalize, 2..14 = U-Net layers 0..12).
 struct Probe { int stage; hipEvent_t ev0, ev1; };
 
+// what the last encoder call of this process ran its U-Net on (giga_encoder_last_path: tests pin the kernel-choice flags to it)
+static std::atomic<int> g_last_unet_path{0};
+
 template <typename T, int MATH = MATH_NATIVE>
 static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc, float* planes_nchw, int B,
-                       uint8_t* ws, hipStream_t s, const Probe& pr, bool fold_final, int persist, bool conv32) {
+                       uint8_t* ws, hipStream_t s, const Probe& pr, bool fold_final, int persist, int conv32) {
     constexpr bool SPLIT = MATH == MATH_SPLIT;
     int stage_no = 0;
     auto pre = [&]() { if (pr.stage == stage_no) (void)hipEventRecord(pr.ev0, s); };
@@ -841,11 +864,12 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
                 (persist > 0 || (persist == 0 && (env_persist > 0 || (env_persist < 0 && by_default))));
     int mega_slot = -2;
     if (mega) { mega_slot = persistent_slot(s); mega = mega_slot != -1; }        // at most MEGA_MAX_IN_FLIGHT persistent launches in flight
-    // conv32 (giga_conv32.h): the f16-class modes, opt-in per call (GIGA_CONV32_UNET) or per process (GIGA_CONV32=1).
+    // conv32 (giga_conv32.h) runs the f16-class modes unless the call (GIGA_CONV16_UNET) or the process (GIGA_CONV32=0) asks for
+    // conv16; never chosen by batch size (a scene's result must not depend on the batch it is in).
     constexpr int C32MODE = sizeof(T) == 2 ? C32_NATIVE : MATH == MATH_SPLIT ? C32_SPLIT : -1;
-    static const int env_c32 = [] { const char* e = getenv("GIGA_CONV32"); return e ? atoi(e) : 0; }();
+    static const int env_c32 = [] { const char* e = getenv("GIGA_CONV32"); return e ? (atoi(e) ? 1 : -1) : 0; }();
     if constexpr (C32MODE >= 0) {
-        if (env_c32 || conv32) {
+        if (conv32 > 0 || (conv32 == 0 && env_c32 >= 0)) {
             auto W32 = [&](int l) { return blob + (C32MODE == C32_SPLIT ? ko.conv[l].c32s : C32MODE == C32_BF16 ? ko.conv[l].c32b : ko.conv[l].c32h); };
             ConvArgs M[NCONV];
             for (int l = 0; l < NCONV; ++l) { M[l] = L[l]; M[l].w = W32(l); M[l].xcd_local = 0; M[l].out_pool = nullptr; }
@@ -857,15 +881,26 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
                 m.sync = reinterpret_cast<unsigned*>(b + w.SYNC);
                 m.nlayers = nlayers;
                 const unsigned grid = (unsigned)c32_groups(nimg) * MEGA_GROUP;
-                auto kern = unet32_mega_kernel<C32MODE>;
-                giga::dyn_lds_once(reinterpret_cast<const void*>(kern), C32_LDS);
+                // fused same-resolution pairs (C32Pair) while a member's rows fit ONE sub-band of the pair (up to two images per
+                // group: the halo rows a member recomputes are 2 of ~12; beyond that the pair needs smaller sub-bands than the
+                // single layers and measured slower, profiles/r04/conv32_fused_pairs.txt).  Bit-identical either way;
+                // GIGA_C32_FUSE=0 / 1 forces one form (A/B runs).
+                static const int env_fuse = [] { const char* e = getenv("GIGA_C32_FUSE"); return e ? atoi(e) : -1; }();
+                const int groups = c32_groups(nimg);
+                const bool fuse = env_fuse >= 0 ? env_fuse != 0 : (nimg + groups - 1) / groups <= 2;
                 stage_no = 15;
                 pre();
-                GIGA_LAUNCH(kern, dim3(grid), dim3(C32_NW * 64), C32_LDS, s, m);
+                auto go = [&](auto kern) {
+                    giga::dyn_lds_once(reinterpret_cast<const void*>(kern), C32_LDS_TOTAL);
+                    GIGA_LAUNCH(kern, dim3(grid), dim3(C32_NW * 64), C32_LDS_TOTAL, s, m);
+                };
+                if (fuse) go(unet32_mega_kernel<C32MODE, true>); else go(unet32_mega_kernel<C32MODE, false>);
+                g_last_unet_path.store(GIGA_PATH_CONV32 | GIGA_PATH_PERSISTENT | (fuse ? GIGA_PATH_FUSED_PAIRS : 0), std::memory_order_relaxed);
                 persistent_launched(mega_slot, s);
                 post();
                 return hipGetLastError() == hipSuccess ? 0 : -10;
             }
+            g_last_unet_path.store(GIGA_PATH_CONV32, std::memory_order_relaxed);
             if (pr.stage == 15) (void)hipEventRecord(pr.ev0, s);
 #define X(l, KIND, C0, C1, COUT, H, W, POOLIN, SPW, SGN, SGS, KPS)                                                          \
             if (l < nlayers) { pre(); rc |= launch_conv32<typename U32Layer<C32MODE, l>::G, U32Layer<C32MODE, l>::RELU>(M[l], s); post(); } \
@@ -876,6 +911,7 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
             return rc;
         }
     }
+    g_last_unet_path.store(mega ? GIGA_PATH_PERSISTENT : 0, std::memory_order_relaxed);
     if (mega) {
         MegaArgs m{};
         for (int l = 0; l < NCONV; ++l) { m.layer[l] = L[l]; m.layer[l].xcd_local = 0; }   // (the kernel hands every group its images itself)
@@ -910,8 +946,8 @@ int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, fl
     Probe pr{ev0 && ev1 ? probe_stage : -1, static_cast<hipEvent_t>(ev0), static_cast<hipEvent_t>(ev1)};
     const bool fold = (precision & GIGA_FOLD_FINAL) != 0;
     const int persist = (precision & GIGA_LAYERWISE_UNET) ? -1 : (precision & GIGA_PERSIST_UNET) ? 1 : 0;   // -1 per-layer launches, 0 auto, 1 persistent
-    const int prec = precision & ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET);
-    const bool c32 = (precision & GIGA_CONV32_UNET) != 0;
+    const int prec = precision & ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET);
+    const int c32 = (precision & GIGA_CONV32_UNET) ? 1 : (precision & GIGA_CONV16_UNET) ? -1 : 0;      // 1 conv32, -1 conv16, 0 default
     if (prec == 2) return encoder_run<float, MATH_SPLIT>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32);
     if (prec == 3) return encoder_run<float, MATH_BF16>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32);
     return prec == 1 ? encoder_run<half_t>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32)
@@ -919,6 +955,8 @@ int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, fl
 }
 
 }  // namespace giga
+
+extern "C" int giga_encoder_last_path(void) { return giga::g_last_unet_path.load(std::memory_order_relaxed); }
 
 #ifdef GIGA_TRACE
 // diagnostic build only: select the traced U-Net layer (host_out == nullptr) or read the timeline back

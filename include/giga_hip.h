@@ -137,14 +137,20 @@ int giga_decoder_forward(const void* planes_nhwc, const float* p, const void* pa
  *   GIGA_PERSIST_UNET: the persistent launch also where the default keeps per-layer launches (precisions 0 / 3 below 8 scenes). */
 #define GIGA_PERSIST_UNET 32
 #define GIGA_LAYERWISE_UNET 64
-/* GIGA_CONV32_UNET, OR-ed into `precision` (1 or 2) of giga_encoder_forward*: the U-Net layers run on the conv32 kernels
- * (csrc/giga_conv32.h: v_mfma_f32_32x32x16, a member of a group owns a band of ROWS of the group's images -- staged once per layer
- * into LDS -- and one LDS-DMA copy of its weights; register tiles fed by conflict-free ds_read_b128 at `base + immediate`, no VALU
- * in the MFMA loop) instead of conv16 (16x16x32, wave-private patches).  Same arithmetic per layer (f16 / f16x3 operands, fp32
- * accumulation, outputs within one rounding of conv16's), same launch forms, same workspace.  Opt-in (the environment variable
- * GIGA_CONV32=1 does the same for a whole process): measured equal to conv16 end to end -- both are bound by the four dependent
- * L2 / fabric round trips of a layer boundary, not by the matrix pipe. */
+/* Which convolution kernels run the U-Net of the f16-class precisions (1 and 2):
+ *   conv32 (csrc/giga_conv32.h; the DEFAULT since round 4): v_mfma_f32_32x32x16, a member of a group owns a band of ROWS of the
+ *     group's images -- staged once per layer into LDS -- and one LDS-DMA copy of its weights; register tiles fed by conflict-free
+ *     ds_read_b128 at `base + immediate`, no VALU in the MFMA loop; at up to two images per group the same-resolution layer
+ *     pairs (0,1), (2,3), (10,11) of plain f16 run without the group barrier between them (the second layer reads the first one's
+ *     output from LDS; one halo row recomputed per side; bit-identical to the unfused form).
+ *   conv16 (csrc/giga_conv16.h): 16x16x32, wave-private haloed patches; the only kernels of precisions 0 and 3.
+ * Same arithmetic per layer (f16 / f16x3 operands, fp32 accumulation, outputs within one rounding of each other), same launch
+ * forms, same workspace.  Measured (tools/gpu_unet_small.py): conv32 is 2-5 % faster up to 32 scenes and
+ * 4 % slower at 128; the choice does NOT depend on the batch size, so that a scene's result does not either.
+ *   GIGA_CONV32_UNET / GIGA_CONV16_UNET, OR-ed into `precision` (1 or 2) of giga_encoder_forward*: force the one or the other for
+ *   this call; the environment variable GIGA_CONV32=1 / 0 does the same for a whole process (the flag of a call wins). */
 #define GIGA_CONV32_UNET 128
+#define GIGA_CONV16_UNET 256
 
 /* Inference fast path for the FIXED QUERY LATTICE of VGNImplicit (detection_implicit.py:28-31,107):
  * the R^3 points meshgrid(lin, lin, lin, 'ij') with z fastest, shared by all B scenes.  Each plane is
@@ -280,6 +286,13 @@ int giga_grasp_select(const float* tsdf, const float* qual, const float* rot, co
 /* Number of kernel launches the library has enqueued in this process so far (all streams): the difference around a call is
  * that call's launch count.  Diagnostic only. */
 unsigned long long giga_launch_count(void);
+/* How the LAST encoder call of this process ran its U-Net (diagnostic: tests pin the launch-form and kernel flags to it):
+ * an OR of GIGA_PATH_PERSISTENT (one persistent launch; else one launch per layer), GIGA_PATH_CONV32 (conv32 kernels; else
+ * conv16) and GIGA_PATH_FUSED_PAIRS (the persistent conv32 launch ran its same-resolution layer pairs fused). */
+#define GIGA_PATH_PERSISTENT 1
+#define GIGA_PATH_CONV32 2
+#define GIGA_PATH_FUSED_PAIRS 4
+int giga_encoder_last_path(void);
 /* ---- measurement hooks (bench.py roofline): HIP events recorded on `stream` right before and
  * after ONE kernel launch, so the kernel's duration is measured live on the stream it runs on.
  * probe_stage: 0 conv_in+project, 1 plane_finalize, 2..14 = U-Net layers 0..12 (giga_layout.h kConv), 15 = the whole U-Net.

@@ -32,18 +32,24 @@ def test_python_constants_equal_the_header_defines():
     hdr = open(os.path.join(ROOT, "include", "giga_hip.h")).read()
     defines = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"^#define\s+(GIGA_[A-Z0-9_]+)\s+(0x[0-9a-fA-F]+|\d+)\s*$", hdr, re.M)}
     for name, value in (("GIGA_FOLD_FINAL", _capi.FOLD_FINAL), ("GIGA_PERSIST_UNET", _capi.PERSIST_UNET),
-                        ("GIGA_LAYERWISE_UNET", _capi.LAYERWISE_UNET), ("GIGA_MAX_SCENES", _capi.MAX_SCENES)):
+                        ("GIGA_LAYERWISE_UNET", _capi.LAYERWISE_UNET), ("GIGA_MAX_SCENES", _capi.MAX_SCENES),
+                        ("GIGA_CONV32_UNET", _capi.CONV32_UNET), ("GIGA_CONV16_UNET", _capi.CONV16_UNET)):
         assert defines.get(name) == value, (name, defines.get(name), value)
-    flags = _capi.FOLD_FINAL | _capi.PERSIST_UNET | _capi.LAYERWISE_UNET
-    assert flags & 3 == 0 and bin(flags).count("1") == 3          # distinct bits above the precision values 0..3
+    flags = _capi.FOLD_FINAL | _capi.PERSIST_UNET | _capi.LAYERWISE_UNET | _capi.CONV32_UNET | _capi.CONV16_UNET
+    assert flags & 3 == 0 and bin(flags).count("1") == 5          # distinct bits above the precision values 0..3
     lib = _capi.lib()
-    for f in (_capi.PERSIST_UNET, _capi.LAYERWISE_UNET, flags):
+    for f in (_capi.PERSIST_UNET, _capi.LAYERWISE_UNET, _capi.CONV32_UNET, _capi.CONV16_UNET, flags):
         assert lib.giga_encoder_workspace_bytes(4, 1 | f) == lib.giga_encoder_workspace_bytes(4, 1)
         assert lib.giga_encoder_forward(None, None, None, None, 0, f, None, 0, None) == 0          # empty batch
     # the launch form of the U-Net is a per-call choice of the module: False (default), True (forced persistent), "layers"
     net = networks.get_network("giga")
     for mode in (True, "layers", False):
         assert net.set_persistent_unet(mode) is net and net.encoder.persistent_unet == mode
+    # ... and so are the U-Net kernels of the f16-class modes: "auto" (the library's default), "conv32", "conv16"
+    for kernel in ("conv32", "conv16", "auto"):
+        assert net.set_unet_kernel(kernel) is net and net.encoder.unet_kernel == kernel
+    with pytest.raises(ValueError):
+        net.set_unet_kernel("conv64")
 
 
 def test_param_counts_and_sizes():

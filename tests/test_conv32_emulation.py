@@ -114,3 +114,52 @@ def test_conv32_emulation_matches_torch(emu, sd7, mode, G):
         else:
             tol = 3e-6 if mode == 2 else 2e-5                # bf16: exact products; f16x3: the dropped lo x lo term, 2^-22 relative
             assert float((got - ref).abs().max()) <= tol * scale, (layer, float((got - ref).abs().max()), scale)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["f16", "f16x3", "bf16"])
+@pytest.mark.parametrize("G", [1, 3, 5])
+def test_conv32_fused_pair_emulation_equals_two_layers(emu, sd7, mode, G):
+    """The fused pairs of the persistent kernel (giga_conv32_geom.h: C32Pair -- layers (0,1), (2,3), (10,11): the second layer
+    reads the first one's output from LDS, the member recomputes one row above and below its band) must give the SAME bits as
+    the two layers run one after the other, write every output of both layers exactly once, and fill every byte of the second
+    layer's LDS image exactly once.  Modes whose weights do not fit side by side report 1 (the kernel keeps the barrier there)."""
+    emu.conv32_emu_pair.restype = ctypes.c_int
+    emu.conv32_emu_pair.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 8
+    flat = torch.cat([v.reshape(-1) for v in sd7.values()])
+    blob = _capi.pack_weights(flat, 15).numpy()
+    rng = np.random.default_rng(700 + 10 * mode + G)
+    fused = 0
+    for la in (0, 2, 10):
+        kind, c0, c1, cout, H, W, poolin, _ = LAYERS[la]
+        ih, iw = (2 * H, 2 * W) if poolin else (H, W)
+        x0 = rng.standard_normal((G, ih, iw, c0)).astype(np.float32)
+        x1 = rng.standard_normal((G, ih, iw, max(c1, 1))).astype(np.float32)
+        if mode == 0:
+            x0, x1 = x0.astype(np.float16).astype(np.float32), x1.astype(np.float16).astype(np.float32)
+        cb = LAYERS[la + 1][3]
+        outA, outB = np.full((G, H, W, cout), np.nan, np.float32), np.full((G, H, W, cb), np.nan, np.float32)
+        wA, wB = np.zeros(outA.shape, np.int32), np.zeros(outB.shape, np.int32)
+        pool = np.full((G, H, W, c0), np.nan, np.float32)
+        stats = np.zeros(4, np.int32)
+        rc = emu.conv32_emu_pair(la, mode, blob.ctypes.data, G, x0.ctypes.data, x1.ctypes.data if c1 else None, outA.ctypes.data,
+                                 pool.ctypes.data if poolin else None, wA.ctypes.data, outB.ctypes.data, wB.ctypes.data, stats.ctypes.data)
+        if rc == 1:
+            continue
+        assert rc == 0, (la, rc)
+        fused += 1
+        assert wA.min() == 1 and wA.max() == 1 and wB.min() == 1 and wB.max() == 1, (la, wA.min(), wA.max(), wB.min(), wB.max())
+        assert stats[0] <= 160 * 1024 - 1024 and stats[2] >= 6
+        # the two layers separately
+        uA, uB = np.full(outA.shape, np.nan, np.float32), np.full(outB.shape, np.nan, np.float32)
+        pool2 = np.full(pool.shape, np.nan, np.float32)
+        w2 = np.zeros(outA.shape, np.int32)
+        assert emu.conv32_emu_layer(la, mode, blob.ctypes.data, G, x0.ctypes.data, x1.ctypes.data if c1 else None, uA.ctypes.data,
+                                    pool2.ctypes.data if poolin else None, w2.ctypes.data, stats.ctypes.data) == 0
+        w3 = np.zeros(outB.shape, np.int32)
+        assert emu.conv32_emu_layer(la + 1, mode, blob.ctypes.data, G, uA.ctypes.data, None, uB.ctypes.data, None, w3.ctypes.data,
+                                    stats.ctypes.data) == 0
+        assert np.array_equal(outA, uA), (la, "first layer of the pair")
+        assert np.array_equal(outB, uB), (la, "second layer of the pair")
+        if poolin:
+            assert np.array_equal(pool, pool2)
+    assert fused == (3 if mode != 1 else 0)

@@ -30,6 +30,34 @@ def _planes(net, x):
     return torch.stack([fea[k] for k in O.PLANES]).clone()
 
 
+def test_kernel_choice_flags_select_what_runs(net32):
+    """`set_unet_kernel` / GIGA_CONV32_UNET / GIGA_CONV16_UNET must reach the launcher (a flag that is masked and dropped on the way
+    leaves every comparison in this file comparing a kernel with itself): giga_encoder_last_path() says what the call ran."""
+    from giga_amd import _capi
+    L = _capi.lib()
+    dev = torch.device("cuda:0")
+    try:
+        for prec in ("fp16", "fp16x3"):
+            net32.set_precision(prec)
+            for B, fused in ((1, True), (11, True), (32, False)):
+                x = torch.from_numpy(synth.tsdf_batch(3, B)).to(dev)
+                for kernel, want in (("conv16", 0), ("conv32", _capi.PATH_CONV32), ("auto", _capi.PATH_CONV32)):
+                    net32.set_unet_kernel(kernel)
+                    for form, pbit in ((False, _capi.PATH_PERSISTENT), ("layers", 0)):
+                        net32.set_persistent_unet(form)
+                        _planes(net32, x)
+                        got = L.giga_encoder_last_path()
+                        # (f16x3 launches the fused-pairs instantiation too; none of its pairs fits two weight sets side by side)
+                        exp = want | pbit | (_capi.PATH_FUSED_PAIRS if want and pbit and fused else 0)
+                        assert got == exp, (prec, B, kernel, form, got, exp)
+        net32.set_precision("fp32")                       # fp32 has conv16 only, whatever is asked for
+        net32.set_unet_kernel("conv32").set_persistent_unet(False)
+        _planes(net32, torch.from_numpy(synth.tsdf_batch(3, 32)).to(dev))
+        assert L.giga_encoder_last_path() == _capi.PATH_PERSISTENT
+    finally:
+        net32.set_unet_kernel("conv32").set_persistent_unet(False).set_precision("fp32")
+
+
 def test_conv32_against_oracle_and_conv16(net32, sd7):
     dev = torch.device("cuda:0")
     x = torch.from_numpy(synth.tsdf_batch(70, 3))
