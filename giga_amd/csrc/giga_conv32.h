@@ -307,6 +307,59 @@ struct C32Tile {
     }
 };
 
+// the tiles of one staged sub-band (KP == 1): batches of NTB tiles dealt over the waves, all slice passes of the member per batch
+template <class G, bool RELU, int NTB>
+__device__ __forceinline__ void c32_tiles(const ConvArgs& a, const uint8_t* smem, int sgm, int NT, int sb, int R, int ioff = 0, int boff = 0) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nbatch = (NT + NTB - 1) / NTB;
+    // a task = (batch, slice pass); tasks are dealt over the waves, so that the passes of a small sub-band (the ConvTranspose
+    // layers of a single scene: one batch, four passes) run side by side instead of one after the other on one wave
+    for (int task = wave; task < nbatch * G::NSP; task += C32_NW) {
+        const int bi = task / G::NSP, sp = task - bi * G::NSP;
+        C32Tile<G, RELU, NTB> t;
+        t.init(a, sgm, sp, bi * NTB, NT, ioff, boff);
+        t.mma(smem, sp);
+        t.store(a, sgm, sp, bi * NTB, NT, sb, R);
+    }
+}
+// a sub-band whose channels are walked in KP parts: ONE register tile per wave (RBMAX keeps it to that), alive across the parts;
+// each part has its own weight fill and its own staged image
+template <class G, bool RELU, int NTB>
+__device__ __forceinline__ void c32_parts(const ConvArgs& a, uint8_t* smem, int member, bool filled, int NT, int sb, int R) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sgm = G::member_sgm(member);
+    const bool mine = wave * NTB < NT;
+    C32Tile<G, RELU, NTB> t;
+#pragma unroll 1
+    for (int part = 0; part < G::KP; ++part) {
+        if (part > 0 || !filled) {
+            __syncthreads();                               // everyone has finished with the previous weights and image
+            c32_fill<G>(a, smem, member, part);
+        }
+        c32_stage<G>(a, smem, sb, R, part);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        if (part == 0) t.init(a, sgm, 0, wave * NTB, NT);  // (the biases arrived with part 0's weights)
+        if (mine) t.mma(smem, 0);
+    }
+    if (mine) t.store(a, sgm, 0, wave * NTB, NT, sb, R);
+}
+
+// ---- one layer for one member of a group: `a` is already the group's image range (a.nimg = its G images); the member's
+// weights (part 0) are on their way into LDS (c32_fill, issued by the caller before its barrier).
+template <class G, bool RELU>
+__device__ __forceinline__ void c32_tiles_any(const ConvArgs& a, const uint8_t* smem, int sgm, int NT, int sb, int R, int ioff, int boff = 0) {
+    const int ntb = G::batch_tiles(NT);
+    if constexpr (G::SPW > 1 && G::KP == 1) {              // few tasks: one-slice register tiles, twice as many tasks (bit-identical)
+        if ((NT + ntb - 1) / ntb * G::NSP <= C32_NW / 2) {
+            c32_tiles_any<typename G::Thin, RELU>(a, smem, sgm, NT, sb, R, ioff, boff);
+            return;
+        }
+    }
+    if (ntb == 1) c32_tiles<G, RELU, 1>(a, smem, sgm, NT, sb, R, ioff, boff);
+    else if (ntb == 2) c32_tiles<G, RELU, 2>(a, smem, sgm, NT, sb, R, ioff, boff);
+    else if constexpr (G::NTBM >= 3) c32_tiles<G, RELU, 3>(a, smem, sgm, NT, sb, R, ioff, boff);
+}
 // ---- fused pair A -> B (giga_conv32_geom.h: C32Pair): A's epilogue writes B's input image in LDS ------------------------------------
 // the register tile of A (sgm = 0): values -> B's image (every row of A's sub-band) and, for the rows the member owns, memory
 template <class GA, class GB, bool RELU, int NTB>
@@ -365,15 +418,26 @@ template <class GA, class GB, bool RELU, int NTB>
 __device__ __forceinline__ void c32_tiles_mid(const ConvArgs& a, uint8_t* smem, int ioff, uint8_t* mid, int NT, int sbA, int RA, int R) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nbatch = (NT + NTB - 1) / NTB;
-    for (int bi = wave; bi < nbatch; bi += C32_NW) {
-#pragma unroll 1
-        for (int sp = 0; sp < GA::NSP; ++sp) {
-            C32Tile<GA, RELU, NTB> t;
-            t.init(a, 0, sp, bi * NTB, NT, ioff);
-            t.mma(smem, sp);
-            c32_store_mid<GA, GB, RELU, NTB>(t, a, mid, sp, bi * NTB, NT, sbA, RA, R);
+    for (int task = wave; task < nbatch * GA::NSP; task += C32_NW) {       // (batch, slice pass) tasks over the waves, as c32_tiles
+        const int bi = task / GA::NSP, sp = task - bi * GA::NSP;
+        C32Tile<GA, RELU, NTB> t;
+        t.init(a, 0, sp, bi * NTB, NT, ioff);
+        t.mma(smem, sp);
+        c32_store_mid<GA, GB, RELU, NTB>(t, a, mid, sp, bi * NTB, NT, sbA, RA, R);
+    }
+}
+template <class GA, class GB, bool RELU>
+__device__ __forceinline__ void c32_tiles_mid_any(const ConvArgs& a, uint8_t* smem, int ioff, uint8_t* mid, int NT, int sbA, int RA, int R) {
+    const int ntb = GA::batch_tiles(NT);
+    if constexpr (GA::SPW > 1) {                           // few tasks: one-slice register tiles (see c32_tiles_any)
+        if ((NT + ntb - 1) / ntb * GA::NSP <= C32_NW / 2) {
+            c32_tiles_mid_any<typename GA::Thin, GB, RELU>(a, smem, ioff, mid, NT, sbA, RA, R);
+            return;
         }
     }
+    if (ntb == 1) c32_tiles_mid<GA, GB, RELU, 1>(a, smem, ioff, mid, NT, sbA, RA, R);
+    else if (ntb == 2) c32_tiles_mid<GA, GB, RELU, 2>(a, smem, ioff, mid, NT, sbA, RA, R);
+    else if constexpr (GA::NTBM >= 3) c32_tiles_mid<GA, GB, RELU, 3>(a, smem, ioff, mid, NT, sbA, RA, R);
 }
 // can A -> B run as a fused pair?  (same-resolution 3x3 layers, whole weights of both in LDS, room for sub-bands of 6 rows and more)
 template <class GA, class GB>
@@ -413,72 +477,15 @@ __device__ __forceinline__ void c32_run_pair(const ConvArgs& a, const ConvArgs& 
         __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's share of both weight fills has landed
         __syncthreads();
         C32_T(a, 2);
-        {
-            const int NT = GA::n_tiles(R + 2), ntb = GA::batch_tiles(NT);
-            if (ntb == 1) c32_tiles_mid<GA, GB, RELU_A, 1>(a, smem, PR::WB, mid, NT, sb - 1, R + 2, R);
-            else if (ntb == 2) c32_tiles_mid<GA, GB, RELU_A, 2>(a, smem, PR::WB, mid, NT, sb - 1, R + 2, R);
-            else if constexpr (GA::NTBM >= 3) c32_tiles_mid<GA, GB, RELU_A, 3>(a, smem, PR::WB, mid, NT, sb - 1, R + 2, R);
-        }
+        c32_tiles_mid_any<GA, GB, RELU_A>(a, smem, PR::WB, mid, GA::n_tiles(R + 2), sb - 1, R + 2, R);
         C32_T(a, 3);
         __syncthreads();                                   // B's image is complete
         C32_T(b, 2);
-        {
-            const int NT = GB::n_tiles(R), ntb = GB::batch_tiles(NT);
-            if (ntb == 1) c32_tiles<GB, RELU_B, 1>(b, smem + PR::WA, 0, NT, sb, R, PR::imgA_bytes(R), 64);
-            else if (ntb == 2) c32_tiles<GB, RELU_B, 2>(b, smem + PR::WA, 0, NT, sb, R, PR::imgA_bytes(R), 64);
-            else if constexpr (GB::NTBM >= 3) c32_tiles<GB, RELU_B, 3>(b, smem + PR::WA, 0, NT, sb, R, PR::imgA_bytes(R), 64);
-        }
+        c32_tiles_any<GB, RELU_B>(b, smem + PR::WA, 0, GB::n_tiles(R), sb, R, PR::imgA_bytes(R), 64);
         C32_T(b, 3);
     }
 }
 
-// the tiles of one staged sub-band (KP == 1): batches of NTB tiles dealt over the waves, all slice passes of the member per batch
-template <class G, bool RELU, int NTB>
-__device__ __forceinline__ void c32_tiles(const ConvArgs& a, const uint8_t* smem, int sgm, int NT, int sb, int R, int ioff = 0, int boff = 0) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nbatch = (NT + NTB - 1) / NTB;
-    for (int bi = wave; bi < nbatch; bi += C32_NW) {
-#pragma unroll 1
-        for (int sp = 0; sp < G::NSP; ++sp) {
-            C32Tile<G, RELU, NTB> t;
-            t.init(a, sgm, sp, bi * NTB, NT, ioff, boff);
-            t.mma(smem, sp);
-            t.store(a, sgm, sp, bi * NTB, NT, sb, R);
-        }
-    }
-}
-// a sub-band whose channels are walked in KP parts: ONE register tile per wave (RBMAX keeps it to that), alive across the parts;
-// each part has its own weight fill and its own staged image
-template <class G, bool RELU, int NTB>
-__device__ __forceinline__ void c32_parts(const ConvArgs& a, uint8_t* smem, int member, bool filled, int NT, int sb, int R) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int sgm = G::member_sgm(member);
-    const bool mine = wave * NTB < NT;
-    C32Tile<G, RELU, NTB> t;
-#pragma unroll 1
-    for (int part = 0; part < G::KP; ++part) {
-        if (part > 0 || !filled) {
-            __syncthreads();                               // everyone has finished with the previous weights and image
-            c32_fill<G>(a, smem, member, part);
-        }
-        c32_stage<G>(a, smem, sb, R, part);
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-        if (part == 0) t.init(a, sgm, 0, wave * NTB, NT);  // (the biases arrived with part 0's weights)
-        if (mine) t.mma(smem, 0);
-    }
-    if (mine) t.store(a, sgm, 0, wave * NTB, NT, sb, R);
-}
-
-// ---- one layer for one member of a group: `a` is already the group's image range (a.nimg = its G images); the member's
-// weights (part 0) are on their way into LDS (c32_fill, issued by the caller before its barrier).
-template <class G, bool RELU>
-__device__ __forceinline__ void c32_tiles_any(const ConvArgs& a, const uint8_t* smem, int sgm, int NT, int sb, int R, int ioff) {
-    const int ntb = G::batch_tiles(NT);
-    if (ntb == 1) c32_tiles<G, RELU, 1>(a, smem, sgm, NT, sb, R, ioff);
-    else if (ntb == 2) c32_tiles<G, RELU, 2>(a, smem, sgm, NT, sb, R, ioff);
-    else if constexpr (G::NTBM >= 3) c32_tiles<G, RELU, 3>(a, smem, sgm, NT, sb, R, ioff);
-}
 template <class G, bool RELU>
 __device__ __forceinline__ void c32_run(const ConvArgs& a, uint8_t* smem, int member) {
     const int sgm = G::member_sgm(member);

@@ -84,6 +84,9 @@ struct C32 {
     static constexpr int NS = NSUB * CS;           // weight slices of the layer
     static constexpr int SPM = NS / SGM;           // slices per member
     static constexpr int SPW = SPW_ < SPM ? SPW_ : SPM;       // slices of a wave's register tile (A fragments read per step)
+    // the same layer with one-slice register tiles: same LDS contents (weights, image), twice the tile tasks -- for sub-bands so
+    // small that the SPW-slice tasks would leave most waves idle (the 20 x 20 and 10 x 10 layers of one or two scenes)
+    using Thin = C32<MODE, KIND, C0, C1, COUT, H, W, POOLIN, 1, SGM_, KP_>;
     static constexpr int NSP = SPM / SPW;          // slice passes of a tile batch
     static constexpr int NBANDS = C32_GROUP / SGM; // row bands of a group
     static constexpr int NOP = MODE == C32_SPLIT ? 2 : 1;     // operand registers per fragment ([hi, lo])

@@ -134,12 +134,14 @@ static int emu_layer(const uint8_t* wimg, const float* bias, int Gimg, const flo
                     for (int e = 0; e < G::IPP * G::ILB; ++e)
                         if (wrote[IMG + (size_t)q * G::PS + e] != 1) return -6;
                 // ---- tiles: batches of ntb tiles dealt over the eight waves; per batch all slices of the member ----
+                // (KP == 1: (batch, slice pass) tasks dealt over the waves; KP > 1: one batch per wave, NSP == 1)
                 for (int wave = 0; wave < C32_NW; ++wave)
-                    for (int bi = wave; bi < nbatch; bi += C32_NW)
+                    for (int task = wave; task < nbatch * G::NSP; task += C32_NW)
                         for (int j = 0; j < ntb; ++j) {
+                            const int bi = task / G::NSP, sp = task - bi * G::NSP;
                             const int tt = bi * ntb + j;
                             if (tt >= NT) continue;
-                            for (int sl = 0; sl < G::SPM; ++sl) {      // (pass sp = sl / SPW, slice s = sl % SPW of the register tile)
+                            for (int sl = sp * G::SPW; sl < (sp + 1) * G::SPW; ++sl) {      // the slices of the pass's register tile
                                 double* acc = &accs[(((size_t)tt * G::SPM + sl) * 64) * 16];
                                 visits[(size_t)tt * G::SPM + sl] += 1;
                                 for (int it = 0; it < G::NIT; ++it) {
