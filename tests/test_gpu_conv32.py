@@ -1,5 +1,6 @@
-"""GPU: the opt-in conv32 U-Net kernels (csrc/giga_conv32.h, `net.set_unet_kernel("conv32")`, C ABI flag GIGA_CONV32_UNET) held to
-the same contracts as the default conv16 kernels (encoder/unet.py:225-239):
+"""GPU: the conv32 U-Net kernels (csrc/giga_conv32.h; the default of 'fp16' / 'fp16x3' since round 4; `net.set_unet_kernel`, C ABI flags
+GIGA_CONV32_UNET / GIGA_CONV16_UNET) held to the same contracts as the conv16 kernels (encoder/unet.py:225-239):
+  * the kernel-choice flags reach the launcher (giga_encoder_last_path), in both launch forms, with and without fused pairs;
   * fp16x3 planes and head outputs against the oracle at the fp32 tolerance (1e-4); plain fp16 planes inside the f16 envelope
     (the per-layer one-ulp test is tests/test_gpu_f16_exact.py::test_f16_unet_and_conv_in_layer_by_layer[conv32]);
   * the persistent launch == per-layer launches, BIT FOR BIT (the summation order of an output is fixed: bias, taps x k-chunks),

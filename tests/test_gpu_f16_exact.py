@@ -59,7 +59,8 @@ def assert_within_one_ulp(got, want, what):
 
 @pytest.mark.parametrize("kernel", ["conv16", "conv32"])
 def test_f16_unet_and_conv_in_layer_by_layer(sd7, kernel):
-    """kernel: the default conv16 U-Net kernels, or the opt-in conv32 kernels (GIGA_CONV32_UNET) -- the same per-layer contract."""
+    """kernel: the conv16 U-Net kernels (GIGA_CONV16_UNET) or the conv32 kernels (the default of the f16-class modes) -- the same
+    per-layer contract."""
     dev = torch.device("cuda:0")
     net = networks.get_network("giga"); net.load_state_dict(sd7); net = net.to(dev).eval().set_precision("fp16").set_unet_kernel(kernel)
     for Bs, first in ((2, 40), (32, 500)):        # the five-x-part conv_in kernels and the one-x-part ones (32 scenes up)
