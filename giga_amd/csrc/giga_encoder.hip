@@ -39,8 +39,8 @@ constexpr int CV_RS = 44;                         // floats per (ix, iy) row of 
 constexpr int CV_OFF = 3;                         // iz = -1 sits at float CV_OFF of its row, iz = 40 at float 44 = float 0 of the next row
 constexpr int CV_ROWS = 12;                       // the group's 10 iy rows + halo
 constexpr int ci_red_units(int nw) { return nw == 4 ? 25 : 13; }   // yz reduction: units per round (8 waves: 13 + 12, 104 KiB; 4 waves: all 25)
-constexpr size_t ci_lds_bytes(int xw, int nw) {
-    const size_t stage = ((size_t)(xw + 3) * CV_ROWS * CV_RS + 4) * sizeof(float);   // + one slab: the A-operand prefetch runs one slice ahead
+constexpr size_t ci_lds_bytes(int xw, int nw, bool f16class = false) {
+    const size_t stage = ((size_t)(xw + 3) * (f16class ? CI16_SLAB : CV_ROWS * CV_RS) + 4) * sizeof(float);   // + one slab: the A-operand prefetch runs one slice ahead
     const size_t red = (size_t)nw * ci_red_units(nw) * 64 * 16;                // NW waves x UR units x 64 lanes x 16 B
     return stage > red ? stage : red;
 }
@@ -67,6 +67,9 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
     float* __restrict__ yz_partial,        // [NXP][B][40(iz)][40(iy)][32] sums over the part's ix
     int B) {
     constexpr int XW = NW * SXW, NT = NW * 64;
+    // row / slab strides of the staged sub-volume in words: the f16-class instantiations use the layout that makes their 8-tap
+    // gather conflict-free (giga_layout.h: ci16_tap), fp32 the compact one (its 4-tap k-steps are conflict-free there)
+    constexpr int RS = SPLIT ? CI16_RS : CV_RS, SLAB = SPLIT ? CI16_SLAB : CV_ROWS * CV_RS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,15 +125,14 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
     for (int s = 0; s < 7; ++s) {
         int t = 4 * s + g;
         t = t > 26 ? 26 : t;
-        abase[s] = ((t / 9) * CV_ROWS + (j >> 3) + (t / 3) % 3) * CV_RS + CV_OFF + 4 * ((j >> 2) & 1) + (j & 3) + t % 3;
+        abase[s] = (t / 9) * SLAB + ((j >> 3) + (t / 3) % 3) * RS + CV_OFF + 4 * ((j >> 2) & 1) + (j & 3) + t % 3;
     }
-    // SPLIT: k-slot g of the single K = 32 step supplies taps 8g .. 8g+7 (taps > 26 have zero weight and read tap 26's voxel)
+    // SPLIT: k-slot g of the single K = 32 step reads the voxels of taps ci16_read(g, 0..7) (giga_layout.h)
     int sbase[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        int t = 8 * g + e;
-        t = t > 26 ? 26 : t;
-        sbase[e] = ((t / 9) * CV_ROWS + (j >> 3) + (t / 3) % 3) * CV_RS + CV_OFF + 4 * ((j >> 2) & 1) + (j & 3) + t % 3;
+        const int t = g == 0 ? ci16_read(0, e) : g == 1 ? ci16_read(1, e) : g == 2 ? ci16_read(2, e) : ci16_read(3, e);
+        sbase[e] = (t / 9) * SLAB + ((j >> 3) + (t / 3) % 3) * RS + CV_OFF + 4 * ((j >> 2) & 1) + (j & 3) + t % 3;
     }
     f32x4v acc_yz[5][5];
 #pragma unroll
@@ -172,11 +174,11 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
     // ---- the staged values go to LDS: row = 44 floats, iz = -1 at float 3 (so the 40 values start 16-byte aligned: one
     // ds_write_b128 per item), iz = 40 at float 44 = the unused float 0 of the next row ----
     if (st_slab < SPP) {
-        float* st_dst = lds + (st_slab * CV_ROWS + st_yl) * CV_RS + CV_OFF + 1 + 4 * st_q;
+        float* st_dst = lds + st_slab * SLAB + st_yl * RS + CV_OFF + 1 + 4 * st_q;
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
             if (st_slab + SPP * p >= XW + 2) break;
-            float* dst = st_dst + SPP * p * CV_ROWS * CV_RS;
+            float* dst = st_dst + SPP * p * SLAB;
             float4 val = vals[p];
             if constexpr (SPLIT) {                     // word = hi | lo << 16
                 float* v4 = reinterpret_cast<float*>(&val);
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
                     if (ip < 5) {
                         unsigned w8[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) w8[e] = ldw[sbase[e] + ixl * CV_ROWS * CV_RS + 2 * ip * CV_RS + 8 * zg];
+                        for (int e = 0; e < 8; ++e) w8[e] = ldw[sbase[e] + ixl * SLAB + 2 * ip * RS + 8 * zg];
                         unsigned hw[4], lw[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {   // bytes [w0.b0 w0.b1 w1.b0 w1.b1] = two hi halfs, [w0.b2 w0.b3 w1.b2 w1.b3] = two lo halfs
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
     // uninterrupted burst of 35 MFMAs (7 k-steps x 5 iy-pairs) carrying only the LDS reads of the A operands three k-steps
     // ahead (rolling window, runs on into the next stage / slice: nothing is ever waited for), followed by ONE dense run of
     // VALU work: ReLU, the three axis sums, the lane swaps and the plane stores.
-    constexpr int SLICE = CV_ROWS * CV_RS;
+    constexpr int SLICE = SLAB;
     // two LDS base addresses per k-step (iy-pairs 0..2 / 3..4), kept in registers for the whole kernel and bumped once per
     // slice: every read of the burst is base + immediate (the asm pins stop the compiler from re-deriving them inside it)
     typedef __attribute__((address_space(3))) const float lds_cfloat;
@@ -269,14 +271,14 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
         a_lo[s] = (int)lds_base + 4 * (abase[s] + wave * SXW * SLICE);   // absolute LDS byte addresses
-        a_hi[s] = a_lo[s] + 4 * 6 * CV_RS;
+        a_hi[s] = a_lo[s] + 4 * 6 * RS;
         asm volatile("" : "+v"(a_lo[s]), "+v"(a_hi[s]));
     }
     float A[7][5];
     auto load_a = [&](int s, int off) {
 #pragma unroll
         for (int ip = 0; ip < 5; ++ip)
-            A[s][ip] = *(lds_cfloat*)((size_t)(unsigned)((ip < 3 ? a_lo[s] : a_hi[s]) + 4 * (2 * (ip < 3 ? ip : ip - 3) * CV_RS + off)));
+            A[s][ip] = *(lds_cfloat*)((size_t)(unsigned)((ip < 3 ? a_lo[s] : a_hi[s]) + 4 * (2 * (ip < 3 ? ip : ip - 3) * RS + off)));
     };
     load_a(0, 0); load_a(1, 0); load_a(2, 0);
     for (int sx = 0; sx < SXW; ++sx) {
@@ -797,12 +799,12 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     constexpr int NW = 8;
     if (nxp == 1) {
         auto kern = convin_project_kernel<T, RES / NW, CI_F16, NW, CI_LO>;
-        constexpr size_t lds = ci_lds_bytes(RES, NW);
+        constexpr size_t lds = ci_lds_bytes(RES, NW, CI_F16);
         giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
         GIGA_LAUNCH(kern, dim3(8 * B), dim3(NW * 64), lds, s, tsdf, cw, cb, P0, XZP, YZP, B);
     } else {
         auto kern = convin_project_kernel<T, 8 / NW, CI_F16, NW, CI_LO>;
-        constexpr size_t lds = ci_lds_bytes(8, NW);
+        constexpr size_t lds = ci_lds_bytes(8, NW, CI_F16);
         giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
         GIGA_LAUNCH(kern, dim3(5, 8, B), dim3(NW * 64), lds, s, tsdf, cw, cb, P0, XZP, YZP, B);
     }

@@ -119,6 +119,37 @@ constexpr size_t DEC32_BYTES = (DEC32_FRAGS + 1) * FRAG;                  // 111
 
 // w16s: f16x3 split [hi, lo] fragment pairs (2 * nfrag16); wbf: bf16 fragments (f16 fragment layout), derived from w32;
 // c32h / c32s / c32b: conv32 images (giga_conv32_geom.h) in f16, f16x3 [hi, lo] pairs (2 * nfragc32) and bf16
+// ---- f16-class conv_in (giga_encoder.hip: convin_project_kernel<.., SPLIT = true>): which tap sits in K slot (g, e) of the single
+// K = 32 step (lane k-group g = lane >> 4, half e of its 8).  The staged sub-volume of those instantiations has rows of
+// CI16_RS = 56 words and slabs of CI16_SLAB = 688 words, and a half-wave holds k-groups (0, 1) or (2, 3): its 32 lanes read, for
+// one e, 8 consecutive words in two rows per k-group -- banks b + {0..7, 24..31} (56 = 24 mod 32) -- and the partner k-group must
+// sit 16 banks further for the four runs to be disjoint.  An address is dx * SLAB + dy * RS + dz (+ the voxel), SLAB = 16 and
+// 2 * RS = 16 mod 32: partners differ by one step in dx (same dy, dz) or are (dy = 0, dy = 2) of one (dx, dz).  Per dz the 3 x 3
+// grid of (dx, dy) gives four such pairs and one single tap, whose partner slot has weight ZERO and reads a valid neighbour:
+// 12 real pairs + 3 (real, zero) + 1 (zero, zero) = the 16 pairs of the two half-waves.  Every ds_read_b32 of the gather is
+// conflict-free (tests/test_abi_and_host.py checks the table: every tap once, the partner rule, 16 cycles per unit in a bank model).
+// Tap index = dx * 9 + dy * 3 + dz (the reference's Conv3d weight order, voxels.py:89-97: kernel index [kx][ky][kz] over the
+// grid's (x, y, z)).  ci16_tap: the tap whose WEIGHT the slot carries (-1: zero); ci16_read: the tap whose VOXEL the slot reads.
+constexpr int CI16_RS = 56, CI16_SLAB = 12 * CI16_RS + 16;
+constexpr int ci16_pair_tap(int p, int side) {           // pair p = 5 * dz + q, side 0 / 1
+    const int dz = p / 5, q = p % 5;
+    if (p >= 15) return -1;
+    // (dx, dy) of the two sides
+    const int dxa[5] = {0, 2, 0, 0, 2}, dya[5] = {0, 0, 2, 1, 1};
+    const int dxb[5] = {1, 2, 1, 1, 1}, dyb[5] = {0, 2, 2, 1, 1};
+    if (q == 4 && side == 1) return -1;                  // the single tap's partner: zero weight
+    return side == 0 ? dxa[q] * 9 + dya[q] * 3 + dz : dxb[q] * 9 + dyb[q] * 3 + dz;
+}
+constexpr int ci16_pair_read(int p, int side) {
+    const int pp = p >= 15 ? 0 : p;                      // the (zero, zero) pair reads what pair 0 reads
+    const int dz = pp / 5, q = pp % 5;
+    const int dxa[5] = {0, 2, 0, 0, 2}, dya[5] = {0, 0, 2, 1, 1};
+    const int dxb[5] = {1, 2, 1, 1, 1}, dyb[5] = {0, 2, 2, 1, 1};
+    return side == 0 ? dxa[q] * 9 + dya[q] * 3 + dz : dxb[q] * 9 + dyb[q] * 3 + dz;
+}
+constexpr int ci16_tap(int g, int e) { return ci16_pair_tap(8 * (g >> 1) + e, g & 1); }
+constexpr int ci16_read(int g, int e) { return ci16_pair_read(8 * (g >> 1) + e, g & 1); }
+
 struct ConvPackOff { size_t w16, w32, bias, w16s, wbf; int nfrag16, nfrag32; size_t c32h, c32s, c32b; int nfragc32; };
 struct PackOff {
     size_t convin_w;        // fp32 [2][7][64]  B operands (channel half, K-step of 4 taps; tap 27 = 0)

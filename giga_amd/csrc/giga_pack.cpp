@@ -278,14 +278,15 @@ int pack_weights_host(const float* P, size_t n_params, int head_present, uint8_t
                 cw[(h * 7 + s) * 64 + lane] = tap < 27 ? P[po.conv_in_w + n * 27 + tap] : 0.f;
             }
     // f16x3 split conv_in: B operand of ONE v_mfma_f32_16x16x32_f16 per channel half (K = 27 taps padded to 32):
-    //   [h][hi|lo][lane]: lane (j = lane&15 -> channel 16h + j, g = lane>>4), half e -> tap 8g + e (taps >= 27 are zero)
+    //   [h][hi|lo][lane]: lane (j = lane&15 -> channel 16h + j, g = lane>>4), half e -> tap ci16_tap(g, e) (giga_layout.h: the
+    //   slot order that makes the kernel's gather conflict-free; slots without a tap are zero)
     {
         half_t* cs = reinterpret_cast<half_t*>(blob + ko.convin_ws);
         for (int h = 0; h < 2; ++h)
             for (int lane = 0; lane < 64; ++lane)
                 for (int e = 0; e < 8; ++e) {
-                    const int n = 16 * h + (lane & 15), tap = 8 * (lane >> 4) + e;
-                    const float w = tap < 27 ? P[po.conv_in_w + n * 27 + tap] : 0.f;
+                    const int n = 16 * h + (lane & 15), tap = ci16_tap(lane >> 4, e);
+                    const float w = tap >= 0 ? P[po.conv_in_w + n * 27 + tap] : 0.f;
                     const half_t hi = f2h(w);
                     cs[((2 * h) * 64 + lane) * 8 + e] = hi;
                     cs[((2 * h + 1) * 64 + lane) * 8 + e] = f2h(w - (float)hi);

@@ -473,4 +473,11 @@ int conv32_emu_pair(int layer_a, int mode, const uint8_t* blob, int Gimg, const 
     return -11;
 }
 
+// the K-slot table of the f16-class conv_in (giga_layout.h: ci16_tap / ci16_read) and its LDS strides
+void ci16_table(int* tap, int* read, int* strides) {
+    for (int g = 0; g < 4; ++g)
+        for (int e = 0; e < 8; ++e) { tap[8 * g + e] = ci16_tap(g, e); read[8 * g + e] = ci16_read(g, e); }
+    strides[0] = CI16_RS; strides[1] = CI16_SLAB;
+}
+
 }  // extern "C"

@@ -163,3 +163,27 @@ def test_conv32_fused_pair_emulation_equals_two_layers(emu, sd7, mode, G):
         if poolin:
             assert np.array_equal(pool, pool2)
     assert fused == (3 if mode != 1 else 0)
+
+
+def test_conv_in_f16_slot_table(emu):
+    """The K-slot order of the f16-class conv_in (giga_layout.h: ci16_tap / ci16_read, shared by the packer and
+    convin_project_kernel<.., SPLIT>): every one of the 27 taps carries its weight in exactly one slot, a slot without a weight
+    still reads a voxel inside the staged sub-volume, and in a 32-bank model of the LDS every ds_read_b32 of the gather -- 32 lanes
+    of a half-wave = 16 voxels (2 iy x 8 iz) x the two k-groups (0, 1) or (2, 3) -- touches 32 different banks."""
+    tap, read, strides = np.zeros(32, np.int32), np.zeros(32, np.int32), np.zeros(2, np.int32)
+    emu.ci16_table.restype = None
+    emu.ci16_table.argtypes = [ctypes.c_void_p] * 3
+    emu.ci16_table(tap.ctypes.data, read.ctypes.data, strides.ctypes.data)
+    RS, SLAB = int(strides[0]), int(strides[1])
+    assert sorted(t for t in tap if t >= 0) == list(range(27))
+    assert ((read >= 0) & (read < 27)).all() and all(read[i] == tap[i] for i in range(32) if tap[i] >= 0)
+    assert RS >= 45 and SLAB >= 12 * RS                      # 42 values + the alignment offset per row, 12 rows per slab
+    for e in range(8):
+        for half in range(2):
+            banks = {}
+            for lane in range(32 * half, 32 * half + 32):
+                j, g = lane & 15, lane >> 4
+                t = int(read[8 * g + e])
+                a = (t // 9) * SLAB + ((j >> 3) + (t // 3) % 3) * RS + 3 + 4 * ((j >> 2) & 1) + (j & 3) + t % 3
+                banks.setdefault(a % 32, set()).add(a)
+            assert max(len(v) for v in banks.values()) == 1, (e, half)
