@@ -1346,14 +1346,23 @@ __global__ void lattice_resample_kernel(const TP* __restrict__ planes, const flo
     const Bilin bl = bilin_setup(norm_coord(lin[iu]), norm_coord(lin[iv]));
     const TP* src = planes + (size_t)img * RES * RES * CD + 8 * cg;
     TP* dst = out + (size_t)pix * CD + 8 * cg;
+    // the thread's 8 channels of a tap are 16 (f16) or 32 (fp32) contiguous bytes: one or two 16-byte loads per tap, one or two
+    // 16-byte stores (element-wise 2-byte accesses made this kernel 14 us at 32 scenes for 17 MB)
+    typedef TP vec8 __attribute__((ext_vector_type(8)));
+    const vec8 v00 = *reinterpret_cast<const vec8*>(src + (size_t)bl.o00 * CD);
+    const vec8 v01 = *reinterpret_cast<const vec8*>(src + (size_t)bl.o01 * CD);
+    const vec8 v10 = *reinterpret_cast<const vec8*>(src + (size_t)bl.o10 * CD);
+    const vec8 v11 = *reinterpret_cast<const vec8*>(src + (size_t)bl.o11 * CD);
+    vec8 r;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        float acc = (float)src[(size_t)bl.o00 * CD + c] * bl.w00;
-        acc = fmaf((float)src[(size_t)bl.o01 * CD + c], bl.w01, acc);
-        acc = fmaf((float)src[(size_t)bl.o10 * CD + c], bl.w10, acc);
-        acc = fmaf((float)src[(size_t)bl.o11 * CD + c], bl.w11, acc);
-        dst[c] = (TP)acc;
+        float acc = (float)v00[c] * bl.w00;
+        acc = fmaf((float)v01[c], bl.w01, acc);
+        acc = fmaf((float)v10[c], bl.w10, acc);
+        acc = fmaf((float)v11[c], bl.w11, acc);
+        r[c] = (TP)acc;
     }
+    *reinterpret_cast<vec8*>(dst) = r;
 }
 
 

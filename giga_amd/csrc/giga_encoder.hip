@@ -369,16 +369,19 @@ __global__ void plane_finalize_kernel(const float* __restrict__ xz_partial, cons
     if (t >= per4) return;
     const f32x4v* xs = reinterpret_cast<const f32x4v*>(xz_partial) + t;
     const f32x4v* ys = reinterpret_cast<const f32x4v*>(yz_partial) + t;
+    typedef TOut out4 __attribute__((ext_vector_type(4)));      // one 8- or 16-byte store per thread and plane
     f32x4v sx = (xs[0] + xs[per4]) + (xs[2 * per4] + xs[3 * per4]);
-    TOut* dx = planes + 4 * t;
+    out4 ox;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dx[r] = (TOut)(sx[r] * (1.0f / RES));
+    for (int r = 0; r < 4; ++r) ox[r] = (TOut)(sx[r] * (1.0f / RES));
+    *reinterpret_cast<out4*>(planes + 4 * t) = ox;
     if (nxp > 1) {                                          // (one x-part: conv_in wrote the yz plane itself)
         f32x4v sy = ys[0];
         for (int k = 1; k < nxp; ++k) sy += ys[(size_t)k * per4];
-        TOut* dy = planes + 2 * 4 * per4 + 4 * t;
+        out4 oy;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dy[r] = (TOut)(sy[r] * (1.0f / RES));
+        for (int r = 0; r < 4; ++r) oy[r] = (TOut)(sy[r] * (1.0f / RES));
+        *reinterpret_cast<out4*>(planes + 2 * 4 * per4 + 4 * t) = oy;
     }
 }
 
