@@ -525,8 +525,10 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
 
     def set_unet_kernel(self, kernel="auto"):
         """Which convolution kernels run the f16-class U-Net ('fp16', 'fp16x3'; include/giga_hip.h, GIGA_CONV32_UNET / GIGA_CONV16_UNET):
-        "auto" (the library's default: conv32 -- 32x32x16 MFMA register tiles over LDS-resident row bands -- unless the environment
-        says GIGA_CONV32=0), "conv32" or "conv16" (16x16x32, wave-private patches; the only kernels of 'fp32' / 'bf16')."""
+        "auto" (the library's default: conv32 -- 32x32x16 MFMA register tiles over LDS-resident row bands, same-resolution layer pairs
+        fused -- up to 16 scenes, conv16 beyond; the environment variable GIGA_CONV32=0 / 1 overrides), "conv32" or "conv16" (16x16x32,
+        wave-private patches; the only kernels of 'fp32' / 'bf16').  A forced kernel makes a scene's result independent of the batch
+        size it runs in (bit for bit); "auto" does not across the 16-scene threshold."""
         if kernel not in ("auto", "conv16", "conv32"):
             raise ValueError(kernel)
         self.encoder.unet_kernel = kernel

@@ -404,13 +404,44 @@ __global__ __launch_bounds__(PS_NW * 64) void plane_gather_kernel(const float* _
     __syncthreads();
     for (int i = tid; i < N; i += PS_NW * 64) sorted[start[cell_of[i]] + rank_of[i]] = (unsigned short)i;
     __syncthreads();
-    for (int c = tid; c < PS_CELLS; c += PS_NW * 64) {                // order every cell's (short) list by point index
+    // order every cell's list by point index.  A short list (the normal case: 2.6 points per cell at 2048 queries) is sorted by
+    // insertion by the thread that owns the cell; LONG lists -- queries clustered in one cell: points clamped onto a face of the
+    // cube, duplicates -- would be O(n^2) serial LDS work on one lane (8 M steps at 4096 points), so they are ranked by the whole
+    // workgroup instead: element x goes to slot #{y : list[y] < list[x]} (point indices are distinct), n^2 / 1024 steps per thread.
+    constexpr int PS_LONG = 32;
+    int* nlong = start + PS_CELLS + 1;                                // (the 63 spare words behind start[]): [0] count, [1..] long cells
+    if (tid == 0) nlong[0] = 0;
+    __syncthreads();
+    for (int c = tid; c < PS_CELLS; c += PS_NW * 64) {
         const int s0 = start[c], s1 = start[c + 1];
+        if (s1 - s0 > PS_LONG) {                                      // (at most 4096 / 33 = 124 such cells; the first 62 are listed,
+            const int k = atomicAdd(nlong, 1);                        //  the others fall back to the serial sort below)
+            if (k < 62) { nlong[1 + k] = c; continue; }
+        }
         for (int x = s0 + 1; x < s1; ++x) {
             const unsigned short v = sorted[x];
             int y = x - 1;
             while (y >= s0 && sorted[y] > v) { sorted[y + 1] = sorted[y]; --y; }
             sorted[y + 1] = v;
+        }
+    }
+    __syncthreads();
+    {
+        const int nl = nlong[0] < 62 ? nlong[0] : 62;
+        unsigned short* tmp = rank_of;                                // (the ranks were consumed by the scatter above)
+        for (int k = 0; k < nl; ++k) {
+            const int c = nlong[1 + k], s0 = start[c], s1 = start[c + 1];
+            for (int x = s0 + tid; x < s1; x += PS_NW * 64) {
+                const unsigned short v = sorted[x];
+                int r = 0;
+                for (int y = s0; y < s1; ++y) r += sorted[y] < v;     // (all lanes read the same word: a broadcast)
+                tmp[s0 + r] = v;
+            }
+        }
+        __syncthreads();
+        for (int k = 0; k < nl; ++k) {
+            const int c = nlong[1 + k], s0 = start[c], s1 = start[c + 1];
+            for (int x = s0 + tid; x < s1; x += PS_NW * 64) sorted[x] = tmp[x];
         }
     }
     __syncthreads();

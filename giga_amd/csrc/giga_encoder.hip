@@ -869,12 +869,17 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
                 (persist > 0 || (persist == 0 && (env_persist > 0 || (env_persist < 0 && by_default))));
     int mega_slot = -2;
     if (mega) { mega_slot = persistent_slot(s); mega = mega_slot != -1; }        // at most MEGA_MAX_IN_FLIGHT persistent launches in flight
-    // conv32 (giga_conv32.h) runs the f16-class modes unless the call (GIGA_CONV16_UNET) or the process (GIGA_CONV32=0) asks for
-    // conv16; never chosen by batch size (a scene's result must not depend on the batch it is in).
+    // conv32 (giga_conv32.h) or conv16 for the f16-class modes.  A call (GIGA_CONV32_UNET / GIGA_CONV16_UNET) or the process
+    // (GIGA_CONV32=1 / 0) can force one; left alone, conv32 runs up to 16 scenes (48 images) and conv16 beyond: conv32's encoder is
+    // 3-9 % faster up to 32 scenes, but from ~24 scenes on -- every CU busy -- the chip holds a 3-5 % lower shader clock while and after
+    // the conv32 launch runs (at LOWER socket power: a current limit), which costs a sustained 32-scene step up to 4 % and a
+    // 128-scene step up to 6 % (tools/gpu_sustained_power.py, profiles/r04/final/sustained_power.txt).
     constexpr int C32MODE = sizeof(T) == 2 ? C32_NATIVE : MATH == MATH_SPLIT ? C32_SPLIT : -1;
+    constexpr int C32_AUTO_MAX_IMAGES = 48;
     static const int env_c32 = [] { const char* e = getenv("GIGA_CONV32"); return e ? (atoi(e) ? 1 : -1) : 0; }();
     if constexpr (C32MODE >= 0) {
-        if (conv32 > 0 || (conv32 == 0 && env_c32 >= 0)) {
+        const int want = conv32 != 0 ? conv32 : env_c32 != 0 ? env_c32 : (nimg <= C32_AUTO_MAX_IMAGES ? 1 : -1);
+        if (want > 0) {
             auto W32 = [&](int l) { return blob + (C32MODE == C32_SPLIT ? ko.conv[l].c32s : C32MODE == C32_BF16 ? ko.conv[l].c32b : ko.conv[l].c32h); };
             ConvArgs M[NCONV];
             for (int l = 0; l < NCONV; ++l) { M[l] = L[l]; M[l].w = W32(l); M[l].xcd_local = 0; M[l].out_pool = nullptr; }

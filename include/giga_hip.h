@@ -138,15 +138,17 @@ int giga_decoder_forward(const void* planes_nhwc, const float* p, const void* pa
 #define GIGA_PERSIST_UNET 32
 #define GIGA_LAYERWISE_UNET 64
 /* Which convolution kernels run the U-Net of the f16-class precisions (1 and 2):
- *   conv32 (csrc/giga_conv32.h; the DEFAULT since round 4): v_mfma_f32_32x32x16, a member of a group owns a band of ROWS of the
+ *   conv32 (csrc/giga_conv32.h; round 4; the default up to 16 scenes): v_mfma_f32_32x32x16, a member of a group owns a band of ROWS of the
  *     group's images -- staged once per layer into LDS -- and one LDS-DMA copy of its weights; register tiles fed by conflict-free
  *     ds_read_b128 at `base + immediate`, no VALU in the MFMA loop; at up to two images per group the same-resolution layer
  *     pairs (0,1), (2,3), (10,11) of plain f16 run without the group barrier between them (the second layer reads the first one's
  *     output from LDS; one halo row recomputed per side; bit-identical to the unfused form).
  *   conv16 (csrc/giga_conv16.h): 16x16x32, wave-private haloed patches; the only kernels of precisions 0 and 3.
  * Same arithmetic per layer (f16 / f16x3 operands, fp32 accumulation, outputs within one rounding of each other), same launch
- * forms, same workspace.  Measured (tools/gpu_unet_small.py): conv32 is 2-5 % faster up to 32 scenes and
- * 4 % slower at 128; the choice does NOT depend on the batch size, so that a scene's result does not either.
+ * forms, same workspace.  Default: conv32 up to 16 scenes (48 images), conv16 beyond.  Measured: conv32's
+ * encoder is 3-9 % faster up to 32 scenes, but with every CU busy (from ~24 scenes) the chip holds a 3-5 % lower shader clock while
+ * and after the conv32 launch runs, which costs sustained large-batch steps more than the kernel gains.  A scene's low-order bits
+ * therefore depend on whether its batch has more than 16 scenes -- force one kernel where that matters:
  *   GIGA_CONV32_UNET / GIGA_CONV16_UNET, OR-ed into `precision` (1 or 2) of giga_encoder_forward*: force the one or the other for
  *   this call; the environment variable GIGA_CONV32=1 / 0 does the same for a whole process (the flag of a call wins). */
 #define GIGA_CONV32_UNET 128

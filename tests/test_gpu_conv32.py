@@ -42,7 +42,7 @@ def test_kernel_choice_flags_select_what_runs(net32):
             net32.set_precision(prec)
             for B, fused in ((1, True), (11, True), (32, False)):
                 x = torch.from_numpy(synth.tsdf_batch(3, B)).to(dev)
-                for kernel, want in (("conv16", 0), ("conv32", _capi.PATH_CONV32), ("auto", _capi.PATH_CONV32)):
+                for kernel, want in (("conv16", 0), ("conv32", _capi.PATH_CONV32), ("auto", _capi.PATH_CONV32 if B <= 16 else 0)):
                     net32.set_unet_kernel(kernel)
                     for form, pbit in ((False, _capi.PATH_PERSISTENT), ("layers", 0)):
                         net32.set_persistent_unet(form)

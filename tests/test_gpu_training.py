@@ -88,6 +88,38 @@ def test_gradients_at_batch_32(sd7, M, loss_kind):
         assert (got - ref).abs().max().item() <= 2e-3 * scale + 1e-6, name
 
 
+def test_plane_gradient_gather_with_all_queries_in_one_cell(sd7):
+    """The worst case of the binned gather: every occupancy query of a scene in ONE pixel cell (scene 0: 4096 points inside a
+    1e-3 cube; scene 1: all points clamped onto one corner of the volume) -- cell lists of 4096 points, which the workgroup ranks
+    cooperatively instead of one lane sorting them by insertion (8 M serial LDS steps: the step took milliseconds).  Gradients
+    against the oracle; the step must also stay in the time of a normal one."""
+    import time
+    dev = torch.device("cuda:0")
+    B, M = 2, 4096
+    x, pos, pos_occ, y = _batch(710, B, M)
+    g = torch.Generator().manual_seed(5)
+    pos_occ = pos_occ.clone()
+    pos_occ[0] = torch.tensor([0.1013, -0.2031, 0.3047]) + 1e-3 * torch.rand(M, 3, generator=g)
+    pos_occ[1] = torch.tensor([0.7, 0.9, -0.8]) + 0.05 * torch.rand(M, 3, generator=g)         # outside: clamped to the corner cell
+    ref_loss, ref_grads, _ = _oracle_grads(sd7, x, pos, pos_occ, y)
+    net = networks.get_network("giga")
+    net.load_state_dict(sd7)
+    net = net.to(dev).train()
+    times = []
+    for _ in range(3):
+        net.zero_grad(set_to_none=True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        loss, _ = giga_loss(net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev)), tuple(t.to(dev) for t in y))
+        loss.backward()
+        torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+    assert abs(loss.item() - ref_loss) < 1e-5
+    for name, ref in ref_grads.items():
+        got = net.get_parameter(name).grad.cpu()
+        scale = ref.abs().max().item()
+        assert (got - ref).abs().max().item() <= 2e-3 * scale + 1e-6, name
+    assert min(times) < 0.02, times                          # (a serial sort of 4096 points per cell costs far more than 20 ms)
+
+
 @pytest.mark.parametrize("B,M", [(3, 301), (2, 4096), (5, 256)])
 def test_plane_gradient_gather_path(sd7, B, M):
     """From 256 occupancy queries per scene up (to 4096) the plane gradient of the occupancy head is built by a binned gather
