@@ -9,6 +9,8 @@ GIGA_CONV32_UNET / GIGA_CONV16_UNET) held to the same contracts as the conv16 ke
   * conv32 against conv16 on the same input: fp16x3 to 2e-5 of the planes' range (both are fp32-grade evaluations).
 The data movement itself (staging, zero padding, tiles, fragment order, slice groups, channel parts) is checked without a GPU by
 tests/test_conv32_emulation.py."""
+import os
+
 import pytest
 import torch
 
@@ -42,7 +44,9 @@ def test_kernel_choice_flags_select_what_runs(net32):
             net32.set_precision(prec)
             for B, fused in ((1, True), (11, True), (32, False)):
                 x = torch.from_numpy(synth.tsdf_batch(3, B)).to(dev)
-                for kernel, want in (("conv16", 0), ("conv32", _capi.PATH_CONV32), ("auto", _capi.PATH_CONV32 if B <= 16 else 0)):
+                env = os.environ.get("GIGA_CONV32")              # a process-wide override of "auto" (the flag of a call still wins)
+                auto32 = (B <= 16) if env is None else (int(env) != 0)
+                for kernel, want in (("conv16", 0), ("conv32", _capi.PATH_CONV32), ("auto", _capi.PATH_CONV32 if auto32 else 0)):
                     net32.set_unet_kernel(kernel)
                     for form, pbit in ((False, _capi.PATH_PERSISTENT), ("layers", 0)):
                         net32.set_persistent_unet(form)
