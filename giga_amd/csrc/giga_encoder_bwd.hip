@@ -18,19 +18,29 @@ namespace giga {
 // dS[img][y][x][c] = dCat[img][y][x][coff + c] (skip half of the concat gradient, channel stride cs)
 //                  + (S[y][x][c] == Q[y/2][x/2][c] ? dQ[y/2][x/2][c] : 0)      (MaxPool2d(2,2) backward)
 // and, S being the ReLU output of the layer below, its backward in the same pass: dS = S > 0 ? dS : 0
+// (one thread per FOUR channels: 16-byte loads and stores; C, cs and coff are multiples of 4)
 __global__ void pool_bwd_add_kernel(float* __restrict__ dS, const float* __restrict__ dcat, int cs, int coff,
                                     const float* __restrict__ dQ, const float* __restrict__ S,
                                     const float* __restrict__ Q, int nimg, int H, int W, int C) {
-    const size_t total = (size_t)nimg * H * W * C;
+    const int C4 = C >> 2;
+    const size_t total = (size_t)nimg * H * W * C4;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int c = (int)(i % C);
-    const size_t pix = i / C;
+    const int c = 4 * (int)(i % C4);
+    const size_t pix = i / C4;
     const int x = (int)(pix % W), y = (int)((pix / W) % H);
     const size_t img = pix / ((size_t)W * H);
     const size_t qi = ((img * (H / 2) + y / 2) * (W / 2) + x / 2) * C + c;
-    const float s = S[i];
-    dS[i] = s > 0.f ? dcat[pix * cs + coff + c] + (s == Q[qi] ? dQ[qi] : 0.f) : 0.f;
+    const float4 s = *reinterpret_cast<const float4*>(S + pix * C + c);
+    const float4 d = *reinterpret_cast<const float4*>(dcat + pix * cs + coff + c);
+    const float4 q = *reinterpret_cast<const float4*>(Q + qi);
+    const float4 g = *reinterpret_cast<const float4*>(dQ + qi);
+    float4 o;
+    o.x = s.x > 0.f ? d.x + (s.x == q.x ? g.x : 0.f) : 0.f;
+    o.y = s.y > 0.f ? d.y + (s.y == q.y ? g.y : 0.f) : 0.f;
+    o.z = s.z > 0.f ? d.z + (s.z == q.z ? g.z : 0.f) : 0.f;
+    o.w = s.w > 0.f ? d.w + (s.w == q.w ? g.w : 0.f) : 0.f;
+    *reinterpret_cast<float4*>(dS + pix * C + c) = o;
 }
 
 // ------------------------------- weight gradient (MFMA reduction over pixels) ----------------------------
@@ -1153,7 +1163,7 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
     rc |= launch_conv<float, CONV3, 128, 0, 64, 10, 10, 1, false, false, MATH>(dgrad_args(4, G(g.gA2), 0, G(g.gQ1)), s);
     // pool1 + skip: dS1 = gC0[..., 64:128] + unpool(dQ1)
     {
-        const size_t tot = n20 * 64;
+        const size_t tot = n20 * 64 / 4;
         GIGA_LAUNCH(pool_bwd_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, G(g.gS1),
                            G(g.gC0), 128, 64, G(g.gQ1), F(f.S1), F(f.Q1), nimg, 20, 20, 64);
     }
@@ -1165,7 +1175,7 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
     rc |= launch_conv<float, CONV3, 64, 0, 32, 20, 20, 2, false, false, MATH>(dgrad_args(2, G(g.gA1), 0, G(g.gQ0)), s);
     // pool0 + skip: dS0 = gC1[..., 32:64] + unpool(dQ0)
     {
-        const size_t tot = n40 * 32;
+        const size_t tot = n40 * 32 / 4;
         GIGA_LAUNCH(pool_bwd_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, G(g.gS0),
                            G(g.gC1), 64, 32, G(g.gQ0), F(f.S0), F(f.Q0), nimg, 40, 40, 32);
     }
