@@ -496,7 +496,7 @@ struct LinProblem {
     float* db;           // mvalid entries (may be null)
     int ncol, sM, mvalid, nvalid;
 };
-constexpr int LIN_MAX = 20;
+constexpr int LIN_MAX = 52;                          // 17 problems per head: up to three heads in one launch (the struct stays under the 4-KiB kernarg limit)
 struct LinArgs { LinProblem pr[LIN_MAX]; int nprob; long long P; int pts_per_block; int ksplit; int nb_total; int nb_start[LIN_MAX + 1]; };
 
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(LinArgs a) {
@@ -588,13 +588,28 @@ int launch_decoder_backward(const float* planes, const float* p, const uint8_t* 
         giga::dyn_lds_once(reinterpret_cast<const void*>(plane_gather_kernel), (int)PS_LDS);
         GIGA_LAUNCH(plane_gather_kernel, dim3(2, 3, B), dim3(PS_NW * 64), PS_LDS, s, a.dcbuf, p, gplanes, B, N);
     }
-    // weight / bias gradients: one launch per head
+    // weight / bias gradients: one launch per head, or ONE for all heads when their problems fit one argument struct (the three
+    // grasp heads of a one-query call: three 6-us launches of a handful of workgroups each)
+    const bool merged = a.nheads > 1 && 17 * a.nheads <= LIN_MAX;
+    LinArgs L{};
+    auto flush = [&]() {
+        L.nb_start[L.nprob] = L.nb_total;
+        L.P = P;
+        int ksplit = 2048 / L.nb_total;
+        if (ksplit < 1) ksplit = 1;
+        long long ppb = (P + ksplit - 1) / ksplit;
+        ppb = (ppb + 31) / 32 * 32;
+        L.pts_per_block = (int)ppb;
+        ksplit = (int)((P + ppb - 1) / ppb);
+        L.ksplit = ksplit;
+        GIGA_LAUNCH(linear_wgrad_kernel, dim3(L.nb_total * ksplit), dim3(256), 0, s, L);
+        L = LinArgs{};
+    };
     for (int hh = 0; hh < a.nheads; ++hh) {
         const int h = a.head_id[hh];
         const HeadParamOff& o = po.head[h];
         const size_t AS = (size_t)P * 32;
         float* S = a.scratch[hh];
-        LinArgs L{};
         auto add = [&](const float* R, const float* C, int ncol, float* dW, float* db, int sM, int mvalid, int nvalid) {
             LinProblem& q = L.pr[L.nprob];
             q.R = R; q.C = C; q.ncol = ncol; q.dW = dW; q.db = db; q.sM = sM; q.mvalid = mvalid; q.nvalid = nvalid;
@@ -609,17 +624,9 @@ int launch_decoder_backward(const float* planes, const float* p, const uint8_t* 
             add(S + i * AS, a.Cbuf, 96, grads + o.fc_c_w[i], grads + o.fc_c_b[i], 96, 32, 96);                   // fc_c: DN[i], C
         }
         add(S + 0 * AS, a.Pbuf, 32, grads + o.fc_p_w, grads + o.fc_p_b, 3, 32, 3);                             // fc_p: DN[0], p
-        L.nb_start[L.nprob] = L.nb_total;
-        L.P = P;
-        int ksplit = 2048 / L.nb_total;
-        if (ksplit < 1) ksplit = 1;
-        long long ppb = (P + ksplit - 1) / ksplit;
-        ppb = (ppb + 31) / 32 * 32;
-        L.pts_per_block = (int)ppb;
-        ksplit = (int)((P + ppb - 1) / ppb);
-        L.ksplit = ksplit;
-        GIGA_LAUNCH(linear_wgrad_kernel, dim3(L.nb_total * ksplit), dim3(256), 0, s, L);
+        if (!merged) flush();
     }
+    if (merged) flush();
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
