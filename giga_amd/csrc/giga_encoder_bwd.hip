@@ -521,6 +521,11 @@ static int launch_wgrad3(const Wgrad3Args& a, hipStream_t s) {
 //     into place with v_alignbyte_b32: per k-chunk 1 + 3 x 3 LDS reads and 24 VALU feed nine MFMAs (288 matrix cycles).
 //   X columns: data at col 8 + x; cols < 8 and >= 8 + 8G stay zero (the convolution's zero padding), zeroed once.
 typedef __bf16 wbf8 __attribute__((ext_vector_type(8)));
+// channel stride (bf16 elements) of the transposed strips: the smallest value >= n that is 8 mod 128, i.e. 16 bytes mod 256: the 32
+// lanes of an operand read (one channel each, 16 bytes) then fall into 16 different 16-byte bank groups per pass -- with the natural
+// stride (rows x pitch: 0 or 64 bytes mod 256 for every layer) they shared one to four (a third of the launch's cycles carried LDS
+// bank conflicts: 2-8.6 M per launch) -- and the staging stores of 16 channel quads hit four bank groups instead of one.
+constexpr int wg_cs(int n) { return (n - 8 + 127) / 128 * 128 + 8; }
 
 template <int C0, int C1, int COUT, int H, int RS>
 __global__ __launch_bounds__(512) void conv3_wgrad_bf16_kernel(Wgrad3Args a) {
@@ -533,7 +538,8 @@ __global__ __launch_bounds__(512) void conv3_wgrad_bf16_kernel(Wgrad3Args a) {
     constexpr int XR = RS + 2;
     constexpr int NVX = (CIN / 4) * XR * G, NVY = (COUT / 4) * RS * G, NV = NVX + NVY;
     static_assert(NV <= 512, "one staging item per thread");
-    constexpr int XELEMS = CIN * XR * PX, YELEMS = COUT * RS * PY;
+    constexpr int XCS = wg_cs(XR * PX), YCS = wg_cs(RS * PY);        // channel strides
+    constexpr int XELEMS = CIN * XCS, YELEMS = COUT * YCS;
     constexpr int NCH = RS * G / 2;                   // k-chunks (two groups each) per strip
     static_assert((RS * G) % 2 == 0 && H % RS == 0, "strip geometry");
     extern __shared__ __attribute__((aligned(16))) float wg_lds[];
@@ -586,8 +592,8 @@ __global__ __launch_bounds__(512) void conv3_wgrad_bf16_kernel(Wgrad3Args a) {
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const __bf16* ya = Yt + (size_t)(mb * 32 + n) * RS * PY;          // this lane's dY channel row block
-    const __bf16* xb = Xt + (size_t)(nb * 32 + n) * XR * PX + 8;      // this lane's X channel, col of x = 0
+    const __bf16* ya = Yt + (size_t)(mb * 32 + n) * YCS;              // this lane's dY channel row block
+    const __bf16* xb = Xt + (size_t)(nb * 32 + n) * XCS + 8;          // this lane's X channel, col of x = 0
 
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
     int st = blockIdx.x;
@@ -596,8 +602,8 @@ __global__ __launch_bounds__(512) void conv3_wgrad_bf16_kernel(Wgrad3Args a) {
         __syncthreads();                              // everyone is done reading the previous strip (and the zero fill)
         const unsigned okc = ok;
         if (isx || isy) {
-            __bf16* dst = isx ? Xt + ((size_t)(4 * cq) * XR + sr) * PX + 8 + 8 * sg : Yt + ((size_t)(4 * cq) * RS + sr) * PY + 8 * sg;
-            const int cstride = isx ? XR * PX : RS * PY;
+            __bf16* dst = isx ? Xt + (size_t)(4 * cq) * XCS + sr * PX + 8 + 8 * sg : Yt + (size_t)(4 * cq) * YCS + sr * PY + 8 * sg;
+            const int cstride = isx ? XCS : YCS;
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {
                 float v8[8] = {ch == 0 ? stg[0].x : ch == 1 ? stg[0].y : ch == 2 ? stg[0].z : stg[0].w,
@@ -705,7 +711,8 @@ __global__ __launch_bounds__(576) void conv3_wgrad_bf16_taps_kernel(Wgrad3Args a
     constexpr int XR = RS + 2;
     constexpr int NVX = (CIN / 4) * XR * G, NVY = (COUT / 4) * RS * G, NV = NVX + NVY;
     static_assert(NV <= 512, "one staging item per thread");
-    constexpr int XELEMS = CIN * XR * PX;
+    constexpr int XCS = wg_cs(XR * PX), YCS = wg_cs(RS * PY);        // channel strides (see wg_cs)
+    constexpr int XELEMS = CIN * XCS;
     constexpr int NCH = RS * G / 2;
     static_assert((RS * G) % 2 == 0 && H % RS == 0, "strip geometry");
     extern __shared__ __attribute__((aligned(16))) float wg_lds[];
@@ -763,8 +770,8 @@ __global__ __launch_bounds__(576) void conv3_wgrad_bf16_taps_kernel(Wgrad3Args a
         lds_barrier();                                // everyone is done reading the previous strip
         const unsigned okc = ok;
         if (isx || isy) {
-            __bf16* dst = isx ? Xt + ((size_t)(4 * cq) * XR + sr) * PX + 8 + 8 * sg : Yt + ((size_t)(4 * cq) * RS + sr) * PY + 8 * sg;
-            const int cstride = isx ? XR * PX : RS * PY;
+            __bf16* dst = isx ? Xt + (size_t)(4 * cq) * XCS + sr * PX + 8 + 8 * sg : Yt + (size_t)(4 * cq) * YCS + sr * PY + 8 * sg;
+            const int cstride = isx ? XCS : YCS;
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {
                 float v8[8] = {ch == 0 ? stg[0].x : ch == 1 ? stg[0].y : ch == 2 ? stg[0].z : stg[0].w,
@@ -792,10 +799,10 @@ __global__ __launch_bounds__(576) void conv3_wgrad_bf16_taps_kernel(Wgrad3Args a
             const int gi = 2 * j + hi, r = gi / G, xg = gi % G;
             wbf8 A[NMB], B[NBK];
 #pragma unroll
-            for (int m = 0; m < NMB; ++m) A[m] = *reinterpret_cast<const wbf8*>(Yt + (size_t)(m * 32 + n) * RS * PY + r * PY + 8 * xg);
+            for (int m = 0; m < NMB; ++m) A[m] = *reinterpret_cast<const wbf8*>(Yt + (size_t)(m * 32 + n) * YCS + r * PY + 8 * xg);
 #pragma unroll
             for (int k = 0; k < NBK; ++k) {
-                const __bf16* row = Xt + (size_t)(k * 32 + n) * XR * PX + 8 + (r + ty) * PX + 8 * xg;   // X row y + ty - 1, col of the group's x0
+                const __bf16* row = Xt + (size_t)(k * 32 + n) * XCS + 8 + (r + ty) * PX + 8 * xg;   // X row y + ty - 1, col of the group's x0
                 const uint4 mid = *reinterpret_cast<const uint4*>(row);
                 uint4 sel = mid;
                 if (tx == 0) {
@@ -852,7 +859,7 @@ static int launch_wgrad3_bf16(const Wgrad3Args& a, hipStream_t s) {
     constexpr int CIN = C0 + C1, W = H;
     constexpr int NBLK = (COUT / 32) * (CIN / 32), BPG = NBLK < 8 ? NBLK : 8, NY = NBLK / BPG;
     constexpr int G = (W + 7) / 8;
-    constexpr size_t strip = ((size_t)CIN * (RS + 2) * (8 * G + 16) + (size_t)COUT * RS * 8 * G) * 2;
+    constexpr size_t strip = ((size_t)CIN * wg_cs((RS + 2) * (8 * G + 16)) + (size_t)COUT * wg_cs(RS * 8 * G)) * 2;
     constexpr size_t lds = strip > 8 * 3 * 4 * 64 * 16 ? strip : 8 * 3 * 4 * 64 * 16;      // strip or the epilogue slots (96 KiB)
     static_assert(lds <= 160 * 1024, "LDS budget");
     const int nstrips = a.nimg * (H / RS);
