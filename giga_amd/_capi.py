@@ -78,6 +78,7 @@ _SIGNATURES = {
                                       ctypes.c_void_p]),
     "giga_launch_count": (ctypes.c_ulonglong, []),
     "giga_encoder_last_path": (ctypes.c_int, []),
+    "giga_forget_device_state": (None, []),
     "giga_event_create": (ctypes.c_void_p, []),
     "giga_event_destroy": (None, [ctypes.c_void_p]),
     "giga_event_record": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

@@ -17,6 +17,7 @@ int pack_bwd_map_host(int head_present, int32_t* map, size_t nwords);
 // giga_encoder_bwd.hip / giga_decoder_bwd.hip
 struct BwdWs { size_t gA6, gA5, gC1, gA4, gA3, gC0, gS2, gA2, gQ1, gS1, gA1, gQ0, gS0, gA0, gP0, WG, total; };
 BwdWs enc_bwd_workspace(int B);
+void persistent_forget();
 int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws,
                             float* gplanes, uint8_t* gws, float* grads, int head_present, int B, hipStream_t s, bool bf16_convs);
 size_t dec_bwd_scratch_floats(long long P, int nheads);
@@ -190,6 +191,11 @@ int giga_encoder_forward(const float* tsdf, const void* packed, void* planes_nhw
 }
 
 unsigned long long giga_launch_count(void) { return g_launch_count.load(std::memory_order_relaxed); }
+
+void giga_forget_device_state(void) {
+    giga::dyn_lds_forget();
+    giga::persistent_forget();
+}
 
 void* giga_event_create(void) {
     hipEvent_t e = nullptr;

@@ -770,6 +770,15 @@ static void persistent_launched(int slot, hipStream_t s) {
     m.busy.clear(std::memory_order_release);
 }
 
+// after hipDeviceReset: the recorded events belong to a context that is gone -- drop them (not destroyed: their device is) and start over
+void persistent_forget() {
+    for (MegaSlots& m : g_mega_slots) {
+        while (m.busy.test_and_set(std::memory_order_acquire)) {}
+        for (int i = 0; i < MegaSlots::MEGA_TRACKED; ++i) { m.used[i] = false; m.ev[i] = nullptr; m.stream[i] = nullptr; }
+        m.busy.clear(std::memory_order_release);
+    }
+}
+
 // probe: if probe_stage == k, ev0/ev1 (hipEvent_t) are recorded right before / after launch k
 // (k = 0 conv_in+project, 1 plane_finalize, 2..14 = U-Net layers 0..12).
 struct Probe { int stage; hipEvent_t ev0, ev1; };

@@ -14,10 +14,13 @@ namespace giga {
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) ONCE per (kernel, device) instead of before every launch: the call takes a
 // runtime lock and a code-object lookup, host time that a launch-bound caller (a single-scene plan: ~17 launches of a few
 // microseconds each) pays on every kernel.  Lock-free table keyed by the kernel's host address and the current device.
+constexpr unsigned DYN_LDS_SLOTS = 1024;                   // >> number of kernel instantiations x devices
+inline std::atomic<uintptr_t> g_dyn_lds_keys[DYN_LDS_SLOTS];
+inline std::atomic<int> g_dyn_lds_vals[DYN_LDS_SLOTS];
 inline void dyn_lds_once(const void* kern, int bytes) {
-    constexpr unsigned N = 1024;                             // >> number of kernel instantiations x devices
-    static std::atomic<uintptr_t> keys[N];
-    static std::atomic<int> vals[N];
+    constexpr unsigned N = DYN_LDS_SLOTS;
+    std::atomic<uintptr_t>* keys = g_dyn_lds_keys;
+    std::atomic<int>* vals = g_dyn_lds_vals;
     int dev = 0;
     (void)hipGetDevice(&dev);
     const uintptr_t key = reinterpret_cast<uintptr_t>(kern) * 64u + (uintptr_t)(dev & 63) + 1u;
@@ -35,10 +38,14 @@ inline void dyn_lds_once(const void* kern, int bytes) {
     }
     // (recorded only when the runtime accepted it: a failed set is retried by the next launch instead of being remembered as done.
     //  The record lives as long as the process: after hipDeviceReset the attribute is gone while the record stays -- a caller that
-    //  resets devices must reload the library.)
+    //  resets devices calls giga_forget_device_state(), which runs dyn_lds_forget().)
     if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
         keys[h].load(std::memory_order_relaxed) == key)
         vals[h].store(bytes, std::memory_order_relaxed);
+}
+// forget every recorded limit (the keys stay: a slot is found again, its value 0 makes the next launch set the attribute anew)
+inline void dyn_lds_forget() {
+    for (unsigned i = 0; i < DYN_LDS_SLOTS; ++i) g_dyn_lds_vals[i].store(0, std::memory_order_relaxed);
 }
 }  // namespace giga
 #define GIGA_LAUNCH(...) \

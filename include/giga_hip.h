@@ -288,6 +288,10 @@ int giga_grasp_select(const float* tsdf, const float* qual, const float* rot, co
 /* Number of kernel launches the library has enqueued in this process so far (all streams): the difference around a call is
  * that call's launch count.  Diagnostic only. */
 unsigned long long giga_launch_count(void);
+/* The library's per-device bookkeeping -- which kernels have had their dynamic-LDS limit raised, which streams have a persistent
+ * U-Net launch in flight -- outlives a hipDeviceReset(), the state it describes does not.  A host that resets a device calls this
+ * before its next call into the library (no GPU work is enqueued; safe to call at any time when no call is in progress). */
+void giga_forget_device_state(void);
 /* How the LAST encoder call of this process ran its U-Net (diagnostic: tests pin the launch-form and kernel flags to it):
  * an OR of GIGA_PATH_PERSISTENT (one persistent launch; else one launch per layer), GIGA_PATH_CONV32 (conv32 kernels; else
  * conv16) and GIGA_PATH_FUSED_PAIRS (the persistent conv32 launch ran its same-resolution layer pairs fused). */

@@ -52,6 +52,14 @@ def test_python_constants_equal_the_header_defines():
         net.set_unet_kernel("conv64")
 
 
+def test_forget_device_state_is_callable_without_a_gpu():
+    """giga_forget_device_state (for hosts that call hipDeviceReset) only clears host-side tables: callable anywhere, any number of times."""
+    lib = _capi.lib()
+    lib.giga_forget_device_state()
+    lib.giga_forget_device_state()
+    assert lib.giga_encoder_last_path() in range(8)
+
+
 def test_param_counts_and_sizes():
     lib = _capi.lib()
     assert lib.giga_param_count(15) == 581863          # SURVEY 8a

@@ -532,3 +532,23 @@ def test_persistent_unet_kernel_is_bit_identical_to_per_layer_launches(net, dev,
     finally:
         net.set_persistent_unet(False)
         net.set_precision("fp32")
+
+
+def test_forget_device_state_between_calls(net, dev):
+    """giga_forget_device_state() drops the library's per-device bookkeeping (raised dynamic-LDS limits, persistent launches in
+    flight: what a host calls after hipDeviceReset); the next calls must set everything up again and give the same bits."""
+    from giga_amd import _capi
+    x = torch.from_numpy(synth.tsdf_batch(40, 3)).to(dev)
+    p = torch.from_numpy(synth.query_points(40, 3, 256, stream=2)).to(dev)
+    try:
+        for prec in ("fp32", "fp16x3", "fp16"):
+            net.set_precision(prec)
+            with torch.no_grad():
+                a = [t.clone() for t in net(x, p, p_tsdf=p)]
+                torch.cuda.synchronize()
+                _capi.lib().giga_forget_device_state()
+                b = net(x, p, p_tsdf=p)
+            for u, v in zip(a, b):
+                assert torch.equal(u, v), prec
+    finally:
+        net.set_precision("fp32")
