@@ -31,7 +31,7 @@ template <int POL> __device__ __forceinline__ u32x4 ld16(const u32x4* p) {
 
 template <int SP, int LP>
 __global__ __launch_bounds__(NT) void k(unsigned* cnt, unsigned* tickets, u32x4* rec /* [ROUNDS][8][32][REG] */, const u32x4* cold,
-                                        long long* clocks /* [2][NWG] */, unsigned* bad_out, int readers, int use_cold, int second) {
+                                        long long* clocks /* [2][NWG] */, unsigned* bad_out, int readers, int use_cold, int second, int warm, int self) {
     __shared__ int s_rank;
     const int xcd = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7;
     if (threadIdx.x == 0) s_rank = (int)__hip_atomic_fetch_add(tickets + xcd * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -42,10 +42,14 @@ __global__ __launch_bounds__(NT) void k(unsigned* cnt, unsigned* tickets, u32x4*
     unsigned bad = 0;
     constexpr int RV = REG_BYTES / 16;
     for (int r = 0; r < ROUNDS; ++r) {
-        u32x4* mine = rec + (((size_t)r * 8 + xcd) * 32 + rank) * RV;
-        const u32x4* theirs = use_cold ? cold + (((size_t)r * 8 + xcd) * 32 + rank) * RV
-                                       : rec + (((size_t)r * 8 + xcd) * 32 + (rank + 1) % 32) * RV;
-        const unsigned stamp = (unsigned)r * 1000u + (unsigned)((rank + 1) % 32);
+        // warm: the SAME two 16-MiB buffers every round (ping-pong), as a recycled activation workspace gives the real kernels:
+        // TLB entries and L2 tags of the regions are warm after the first two rounds; self: the reader is the writer (L2-hit control)
+        const size_t rr = warm ? (size_t)(r & 1) : (size_t)r;
+        const int src_rank = self ? rank : (rank + 1) % 32;
+        u32x4* mine = rec + ((rr * 8 + xcd) * 32 + rank) * RV;
+        const u32x4* theirs = use_cold ? cold + ((rr * 8 + xcd) * 32 + rank) * RV
+                                       : rec + ((rr * 8 + xcd) * 32 + src_rank) * RV;
+        const unsigned stamp = (unsigned)r * 1000u + (unsigned)src_rank;
 #pragma unroll
         for (int i = 0; i < IT; ++i) st16<SP>(mine + i * NT + threadIdx.x, u32x4{(unsigned)r * 1000u + rank, threadIdx.x, (unsigned)i, 7u});
         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(NT) void k(unsigned* cnt, unsigned* tickets, u32x4*
             const long long t2 = __builtin_amdgcn_s_memtime();
             if (threadIdx.x == 0) total += t2 - t0;
             if (second) {                                  // a region that ANOTHER workgroup of this XCD has just read: an L2 hit if reads allocate
-                const u32x4* again = rec + (((size_t)r * 8 + xcd) * 32 + (rank + 2) % 32) * RV;
+                const u32x4* again = rec + ((rr * 8 + xcd) * 32 + (rank + 2) % 32) * RV;
                 __syncthreads();
                 const long long t3 = __builtin_amdgcn_s_memtime();
                 u32x4 w[IT];
@@ -92,9 +96,9 @@ __global__ __launch_bounds__(NT) void k(unsigned* cnt, unsigned* tickets, u32x4*
 }
 
 template <int SP, int LP>
-static void run(const char* what, unsigned* cnt, unsigned* tickets, u32x4* rec, u32x4* cold, long long* clocks, unsigned* bad, int readers, int use_cold, int second = 0) {
+static void run(const char* what, unsigned* cnt, unsigned* tickets, u32x4* rec, u32x4* cold, long long* clocks, unsigned* bad, int readers, int use_cold, int second = 0, int warm = 0, int self = 0) {
     (void)hipMemset(cnt, 0, 8 * 32 * 4); (void)hipMemset(tickets, 0, 8 * 32 * 4); (void)hipMemset(bad, 0, 4);
-    hipLaunchKernelGGL((k<SP, LP>), dim3(NWG), dim3(NT), 0, 0, cnt, tickets, rec, cold, clocks, bad, readers, use_cold, second);
+    hipLaunchKernelGGL((k<SP, LP>), dim3(NWG), dim3(NT), 0, 0, cnt, tickets, rec, cold, clocks, bad, readers, use_cold, second, warm, self);
     (void)hipDeviceSynchronize();
     long long h[2 * NWG]; unsigned b;
     (void)hipMemcpy(h, clocks, sizeof h, hipMemcpyDeviceToHost); (void)hipMemcpy(&b, bad, 4, hipMemcpyDeviceToHost);
@@ -103,18 +107,34 @@ static void run(const char* what, unsigned* cnt, unsigned* tickets, u32x4* rec, 
     const double per = sum / n / ROUNDS;
     printf("%-44s readers/XCD %2d: %7.0f clocks per 64-KiB read (slowest workgroup %7.0f) = %5.1f B/clk/CU, wrong values %u\n", what, readers, per,
            (double)mx / ROUNDS, REG_BYTES / per, b);
+    fflush(stdout);
     if (second) {
         double s2 = 0; for (int i = 0; i < NWG; ++i) if (h[i] >= 0) s2 += (double)h[NWG + i];
+        fflush(stdout);
         printf("%-44s                 second read (region another workgroup just read): %7.0f clocks = %5.1f B/clk/CU\n", "", s2 / n / ROUNDS, REG_BYTES / (s2 / n / ROUNDS));
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool warm_only = argc > 1 && argv[1][0] == 'w';
     unsigned *cnt, *tickets, *bad; u32x4 *rec, *cold; long long* clocks;
     const size_t RB = (size_t)ROUNDS * 8 * 32 * REG_BYTES;      // 384 MiB
     (void)hipMalloc(&cnt, 8 * 32 * 4); (void)hipMalloc(&tickets, 8 * 32 * 4); (void)hipMalloc(&bad, 4);
     (void)hipMalloc(&rec, RB); (void)hipMalloc(&cold, RB); (void)hipMalloc(&clocks, 2 * NWG * 8);
     (void)hipMemset(rec, 0, RB); (void)hipMemset(cold, 1, RB);
+    if (warm_only) {
+        // round 5: (i) warm regions, (ii) the second-read variant recorded, (iii) reader = writer as the L2-hit control
+        for (int readers : {32, 4}) {
+            run<0, 0>("WARM ping-pong: store plain / load plain", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 1, 0);
+            run<2, 0>("WARM ping-pong: store sc1 / load plain", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 1, 0);
+            run<0, 4>("WARM ping-pong: store plain / load nt", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 1, 0);
+            run<0, 0>("WARM, reader = writer (L2-hit control)", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 1, 1);
+            run<2, 0>("WARM, reader = writer, store sc1", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 1, 1);
+            run<0, 0>("fresh regions, reader = writer", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 0, 1);
+            run<0, 0>("fresh regions: store plain / load plain", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 0, 0);
+        }
+        return 0;
+    }
     for (int readers : {32, 4}) {
         run<0, 0>("store plain / load plain", cnt, tickets, rec, cold, clocks, bad, readers, 0);
         run<0, 0>("store plain / load plain + second read", cnt, tickets, rec, cold, clocks, bad, readers, 0, 1);
