@@ -32,6 +32,7 @@ __global__ void probe_kernel(const int* lane_addr /* [64] byte offsets */, short
 template <int LAYOUT> __host__ __device__ inline int piece_addr(int p, int q) {
     if (LAYOUT == 0) return 64 * p + 8 * (q ^ ((p >> 1) & 7));      // swizzled, 64-byte rows
     if (LAYOUT == 1) return 64 * p + 8 * q;                           // natural
+    if (LAYOUT == 3) return 64 * p + 8 * (q ^ ((p >> 2) & 7));      // swizzled by the row QUAD: rows p and p + 16 land 16 banks apart
     return 72 * p + 8 * q;                                            // padded rows
 }
 // write side: lane (n = point, hi) holds, for chunk c, features 16c + 4hi + {0..3} (piece 0) and 16c + 8 + 4hi + {0..3} (piece 1)
@@ -49,18 +50,26 @@ __global__ void tile_kernel(short* out /* [64][16]: chunk, t, j */, long long* c
     unsigned char* tile = lds + w * 2560;
     const int n = l & 31, hi = l >> 5;
     // value of (point p, feature f) = p * 32 + f
-    long long t0 = clock64();
     unsigned acc = 0;
+    int wa[4];
+    v4s wv[4];
+    for (int k = 0; k < 4; ++k) {
+        const int f0 = 16 * (k >> 1) + 8 * (k & 1) + 4 * hi;
+        wa[k] = piece_addr<LAYOUT>(n, f0 >> 2);
+        wv[k] = v4s{(short)(n * 32 + f0), (short)(n * 32 + f0 + 1), (short)(n * 32 + f0 + 2), (short)(n * 32 + f0 + 3)};
+    }
+    long long t0 = clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int u = 0; u < 4; ++u)                      // 16 stores per iteration, nothing else
 #pragma unroll
-            for (int pc = 0; pc < 2; ++pc) {
-                const int f0 = 16 * c + 8 * pc + 4 * hi;
-                v4s v = {(short)(n * 32 + f0 + it), (short)(n * 32 + f0 + 1 + it), (short)(n * 32 + f0 + 2 + it), (short)(n * 32 + f0 + 3 + it)};
-                *reinterpret_cast<v4s*>(tile + piece_addr<LAYOUT>(n, f0 >> 2)) = v;
-            }
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<v4s*>(tile + wa[k]) = wv[k];
         asm volatile("" ::: "memory");
+    }
+    for (int k = 0; k < 4; ++k) {
+        v4s v = wv[k];
+        for (int j = 0; j < 4; ++j) v[j] += (short)(iters - 1);
+        *reinterpret_cast<v4s*>(tile + wa[k]) = v;
     }
     __syncthreads();
     long long t1 = clock64();
@@ -68,9 +77,12 @@ __global__ void tile_kernel(short* out /* [64][16]: chunk, t, j */, long long* c
     const int a10 = read_addr<LAYOUT>(l, 1, 0), a11 = read_addr<LAYOUT>(l, 1, 1);
     v4s r00, r01, r10, r11;
     for (int it = 0; it < iters; ++it) {
-        r00 = tr_read(tile, a00); r01 = tr_read(tile, a01); r10 = tr_read(tile, a10); r11 = tr_read(tile, a11);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                    // 16 reads per iteration; results consumed once per iteration
+            r00 = tr_read(tile, a00); r01 = tr_read(tile, a01); r10 = tr_read(tile, a10); r11 = tr_read(tile, a11);
+            asm volatile("" : "+v"(r00), "+v"(r01), "+v"(r10), "+v"(r11));
+        }
         acc ^= (unsigned)r00[0] + (unsigned)r01[1] + (unsigned)r10[2] + (unsigned)r11[3];
-        asm volatile("" ::: "memory");
     }
     long long t2 = clock64();
     if (w == 0) {
@@ -99,8 +111,8 @@ template <int LAYOUT> static int run_tile(const char* name, short* d_out, long l
                         const short want = (short)(p * 32 + f + iters - 1);
                         bad += h[l * 16 + 8 * chunk + 4 * t + j] != want;
                     }
-        printf("%-28s waves %d: operand image wrong elements %d / 1024; %6.1f clk per 4 ds_write_b64 (one tile), %6.1f clk per 4 tr reads (one operand)\n",
-               name, nw, bad, (double)c[0] / iters, (double)c[1] / iters);
+        printf("%-28s waves %d: operand image wrong elements %d / 1024; %6.1f clk per 4 ds_write_b64 (one tile), %6.1f clk per 4 tr reads (one operand) [16 in flight per loop trip]\n",
+               name, nw, bad, (double)c[0] / iters / 4, (double)c[1] / iters / 4);
     }
     return bad;
 }
@@ -142,6 +154,7 @@ int main() {
     rc |= run_tile<0>("swizzled 64-B rows", d_out, d_clk) != 0;
     rc |= run_tile<1>("natural 64-B rows", d_out, d_clk) != 0;
     rc |= run_tile<2>("padded 72-B rows", d_out, d_clk) != 0;
+    rc |= run_tile<3>("quad-swizzled 64-B rows", d_out, d_clk) != 0;
     printf(rc ? "FAILED\n" : "OK\n");
     return rc;
 }
