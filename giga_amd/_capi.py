@@ -16,7 +16,9 @@ LIB_PATH = os.path.join(_HERE, "lib", "libgiga_hip.so")
 HEAD_QUAL, HEAD_ROT, HEAD_WIDTH, HEAD_TSDF = 1, 2, 4, 8
 DETACH_OCC = 16          # GIGA_DETACH_OCC: flag for giga_backward's head_present
 BF16_CONVS = 32          # GIGA_BF16_CONVS: dgrad convolutions on bf16 MFMA (giga_backward's head_present)
+BF16_DECODER = 64        # GIGA_BF16_DECODER: the decoder backward as one fused bf16 kernel per call (giga_backward's head_present)
 ENC_BF16 = 3             # encoder `precision` 3: bf16 U-Net convolutions, fp32 activations in memory
+DEC_BF16 = 3             # decoder `precision` 3: bf16 linear layers on fp32 planes (the forward of the bf16 training decoder)
 FOLD_FINAL = 16          # GIGA_FOLD_FINAL: OR-ed into `precision` of an encoder call and of the decoder calls on its planes
 PERSIST_UNET = 32        # GIGA_PERSIST_UNET: OR-ed into `precision` of an encoder call (one persistent U-Net launch)
 LAYERWISE_UNET = 64      # GIGA_LAYERWISE_UNET: one launch per U-Net layer even for small batches
@@ -134,7 +136,7 @@ def lib():
             fn = getattr(handle, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.giga_abi_version() != 1:
+        if handle.giga_abi_version() != 2:
             raise GigaHipError("libgiga_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -600,14 +600,18 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
         return [fp]
 
     def set_train_precision(self, precision):
-        """Arithmetic of the differentiable forward/backward (giga_amd/training.py): "fp32" (default) or "bf16" (bf16 MFMA
-        operands in the U-Net's forward and data-gradient convolutions, fp32 everywhere else; BASELINE config c5)."""
-        if precision not in ("fp32", "bf16"):
+        """Arithmetic of the differentiable forward/backward (giga_amd/training.py): "fp32" (default), "bf16" (BASELINE config
+        c5: bf16 MFMA operands / fp32 accumulation in the U-Net's forward, data-gradient and 3x3 weight-gradient convolutions AND in
+        the decoder heads -- forward, gradient chain and weight gradients in one fused kernel per call; fp32 activations in
+        memory, fp32 conv_in, master weights and optimizer) or "bf16_convs" (the convolutions only; fp32 decoders)."""
+        if precision not in ("fp32", "bf16", "bf16_convs"):
             raise ValueError(precision)
-        self._train_bf16 = precision == "bf16"
+        self._train_bf16 = precision != "fp32"
+        self._train_bf16_dec = precision == "bf16"
         st = getattr(self, "_train_state", None)
         if st is not None:
             st.bf16 = self._train_bf16
+            st.bf16_dec = self._train_bf16_dec
             st._wkey = None
         return self
 
@@ -629,6 +633,7 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
             st = self._train_state = _TrainState(self._head_present(), inputs.device, detach_occ=self.detach_tsdf)
             st.data_parallel, st.group = getattr(self, "_dp", (False, None))
             st.bf16 = getattr(self, "_train_bf16", False)
+            st.bf16_dec = getattr(self, "_train_bf16_dec", False)
         self.__dict__["_stale_after_training"] = True
         fp = self.__dict__.get("_flat_param")
         if fp is not None:

@@ -25,6 +25,17 @@ bool dec_bwd_writes_planes(int nheads, int B, int N);
 int launch_decoder_backward(const float* planes, const float* p, const uint8_t* blob, const uint8_t* bwd_blob,
                             int head_mask, const float* const* outs, const float* const* douts, float* gplanes,
                             float* grads, int head_present, float* scratch, int B, int N, hipStream_t s, bool writes_planes);
+int launch_plane_gather(const float* dcbuf, const float* p, float* gplanes, int B, int N, hipStream_t s);
+// giga_decoder_train16.hip (bf16 decoder of the bf16 training step)
+struct DectPending { const float* partial[NHEADS]; int nwg[NHEADS]; int head_id[NHEADS]; int n; };
+int launch_dect_derive(uint8_t* fwd_blob, uint8_t* bwd_blob, hipStream_t s);
+int launch_dect_forward(const float* planes, const float* p, const uint8_t* blob, int head_mask, float* const* outs, int B, int N,
+                        int post, hipStream_t s);
+size_t dect_partial_floats(long long P, int nheads);
+int launch_dect_backward(const float* planes, const float* p, const uint8_t* blob, const uint8_t* bwd_blob, int head_mask,
+                         const float* const* outs, const float* const* douts, float* gplanes, float* dcbuf, float* scratch, int B,
+                         int N, hipStream_t s, DectPending* pend);
+int launch_dect_reduce(const DectPending& pend, float* grads, int head_present, hipStream_t s);
 // giga_loss.hip
 int launch_train_loss(const float* qual, const float* rot, const float* width, const float* occ, const float* label,
                       const float* rot_t, const float* width_t, const float* occ_t, int B, int M, float* losses,
@@ -105,7 +116,9 @@ int giga_derive_bf16_fragments(void* packed_dev, void* bwd_packed_dev, void* str
     r.n = 2 * NCONV;
     GIGA_LAUNCH(derive_bf16_kernel, dim3(at), dim3(64), 0, static_cast<hipStream_t>(stream),
                        static_cast<uint8_t*>(packed_dev), static_cast<uint8_t*>(bwd_packed_dev), r);
-    return hipGetLastError() == hipSuccess ? 0 : -10;
+    if (hipGetLastError() != hipSuccess) return -10;
+    // the bf16 images of the decoder heads (bf16 training decoder, giga_dect.h), from the fp32 head images of the same blobs
+    return launch_dect_derive(static_cast<uint8_t*>(packed_dev), static_cast<uint8_t*>(bwd_packed_dev), static_cast<hipStream_t>(stream));
 }
 
 int giga_abi_version(void) { return GIGA_ABI_VERSION; }
@@ -243,9 +256,20 @@ int giga_decoder_forward_probe(const void* planes_nhwc, const float* p, const vo
     if (B < 0 || N < 0) return -1;
     const bool fold = (precision & GIGA_FOLD_FINAL) != 0;     // planes are the encoder output BEFORE conv_final
     precision &= ~GIGA_FOLD_FINAL;
-    if (precision < 0 || precision > 2) return -5;
+    if (precision < 0 || precision > 3 || (precision == 3 && fold)) return -5;
     if ((long long)B * N == 0 || (head_mask & 15) == 0) return 0;
     if (!planes_nhwc || !p || !packed) return -1;
+    if (precision == 3) {                                     // bf16 operands / fp32 accumulate on fp32 planes: the bf16 training forward
+        float* outs3[NHEADS] = {qual, rot, width, occ};
+        for (int h = 0; h < NHEADS; ++h)
+            if ((head_mask >> h & 1) && !outs3[h]) return -6;
+        hipStream_t s3 = static_cast<hipStream_t>(stream);
+        if (ev_start && hipEventRecord(static_cast<hipEvent_t>(ev_start), s3) != hipSuccess) return -10;
+        const int rc3 = launch_dect_forward(static_cast<const float*>(planes_nhwc), p, static_cast<const uint8_t*>(packed), head_mask & 15,
+                                            outs3, B, N, post, s3);
+        if (ev_stop && hipEventRecord(static_cast<hipEvent_t>(ev_stop), s3) != hipSuccess) return -10;
+        return rc3;
+    }
     const PackOff ko = pack_offsets();
     DecArgs a{};
     a.planes = planes_nhwc; a.p = p; a.blob = static_cast<const uint8_t*>(packed);
@@ -318,7 +342,12 @@ static size_t train_dec_scratch_bytes(int B, int N, int M, int head_present) {
     const int ng = __builtin_popcount(head_present & 7), nt = (head_present >> 3) & 1;
     const size_t a = ng ? dec_bwd_scratch_floats((long long)B * N, ng) : 0;
     const size_t b = nt && M > 0 ? dec_bwd_scratch_floats((long long)B * M, 1) : 0;
-    return align_up((a > b ? a : b) * sizeof(float), 256);
+    // bf16 decoder (GIGA_BF16_DECODER): the dc rows of the occupancy head + the partial gradient tiles of both calls (they are
+    // reduced together at the end); far below the fp32 path's row arrays except for a handful of points
+    const size_t c = (nt && M > 0 ? (size_t)B * M * 96 + dect_partial_floats((long long)B * M, 1) : 0) +
+                     (ng ? dect_partial_floats((long long)B * N, ng) : 0);
+    const size_t m = a > b ? a : b;
+    return align_up((m > c ? m : c) * sizeof(float), 256);
 }
 
 size_t giga_backward_workspace_bytes(int B, int N, int M, int head_present) {
@@ -348,6 +377,7 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
     if (B > GIGA_MAX_SCENES) return -7;
     const bool detach_occ = (head_present & GIGA_DETACH_OCC) != 0;     // detach_tsdf, models/__init__.py:61-63
     const bool bf16_convs = (head_present & GIGA_BF16_CONVS) != 0;     // data-gradient convolutions on bf16 MFMA
+    const bool bf16_dec = (head_present & GIGA_BF16_DECODER) != 0;     // decoder backward on the fused bf16 kernel
     head_present &= 15;
     if (N < 0 || M < 0) return -1;
     if (n_params != param_offsets(head_present).total) return -2;
@@ -372,6 +402,23 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
     if (!occ_writes && hipMemsetAsync(gplanes, 0, gp_bytes, s) != hipSuccess) return -10;
     if (hipMemsetAsync(grads, 0, n_params * sizeof(float), s) != hipSuccess) return -10;
     int rc = 0;
+    if (bf16_dec) {
+        // one fused launch per call (recompute, gradient chain, weight gradients), ONE reduce for every head of the step
+        DectPending pend{};
+        float* sc = scratch;
+        if (occ_runs) {
+            float* dcbuf = occ_writes ? sc : nullptr;
+            if (dcbuf) sc += (size_t)B * M * 96;
+            rc |= launch_dect_backward(static_cast<const float*>(planes_nhwc), p_tsdf, blob, bblob, 8, outs, douts,
+                                       detach_occ ? nullptr : gplanes, dcbuf, sc, B, M, s, &pend);
+            sc += dect_partial_floats((long long)B * M, 1);
+            if (dcbuf) rc |= launch_plane_gather(dcbuf, p_tsdf, gplanes, B, M, s);
+        }
+        if ((head_present & 7) && N > 0)
+            rc |= launch_dect_backward(static_cast<const float*>(planes_nhwc), p, blob, bblob, head_present & 7, outs, douts,
+                                       gplanes, nullptr, sc, B, N, s, &pend);
+        rc |= launch_dect_reduce(pend, grads, head_present, s);
+    } else {
     if (occ_runs) {
         rc |= launch_decoder_backward(static_cast<const float*>(planes_nhwc), p_tsdf, blob, bblob, 8, outs, douts,
                                       detach_occ ? nullptr : gplanes, grads, head_present, scratch, B, M, s, occ_writes);
@@ -379,6 +426,7 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
     if ((head_present & 7) && N > 0) {
         rc |= launch_decoder_backward(static_cast<const float*>(planes_nhwc), p, blob, bblob, head_present & 7, outs,
                                       douts, gplanes, grads, head_present, scratch, B, N, s, false);
+    }
     }
     rc |= launch_encoder_backward(tsdf, blob, bblob, static_cast<const uint8_t*>(enc_workspace_fwd), gplanes, gws,
                                   grads, head_present, B, s, bf16_convs);

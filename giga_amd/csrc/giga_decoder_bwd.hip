@@ -548,6 +548,13 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(LinArgs a) {
 }
 
 // ------------------------------- launcher ------------------------------------------------------------------------
+// plane gradients of a many-point head from its dc rows [B * N][96] (WRITTEN; the caller has checked dec_bwd_writes_planes(1, B, N))
+int launch_plane_gather(const float* dcbuf, const float* p, float* gplanes, int B, int N, hipStream_t s) {
+    giga::dyn_lds_once(reinterpret_cast<const void*>(plane_gather_kernel), (int)PS_LDS);
+    GIGA_LAUNCH(plane_gather_kernel, dim3(2, 3, B), dim3(PS_NW * 64), PS_LDS, s, dcbuf, p, gplanes, B, N);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
 size_t dec_bwd_scratch_floats(long long P, int nheads) { return (size_t)P * 32 * DB_NARR * nheads + (size_t)P * (96 + 32 + 96); }
 
 // the plane gradients of this call are gathered and WRITTEN (plane_gather_kernel) instead of added with atomics

@@ -159,6 +159,7 @@ struct PackOff {
     size_t dec16f[NHEADS], dec32f[NHEADS];   // the same heads with the encoder's final 1x1 conv folded into fc_c (see giga_pack.cpp)
     size_t dec16s[NHEADS], dec16sf[NHEADS];  // f16x3 split images (plain, folded)
     size_t convin_ws;       // f16x3 split conv_in B operands: [2 channel halves][hi, lo] fragments of v_mfma_f32_16x16x32_f16
+    size_t dect[NHEADS];    // bf16 forward images of the bf16 training decoder (giga_dect.h), derived from dec32
     size_t total;
 };
 
@@ -202,6 +203,7 @@ inline PackOff pack_offsets() {
         o.conv[l].c32s = at; at += (size_t)2 * o.conv[l].nfragc32 * FRAG;
         o.conv[l].c32b = at; at += (size_t)o.conv[l].nfragc32 * FRAG;
     }
+    for (int h = 0; h < NHEADS; ++h) { o.dect[h] = at; at += align_up(DEC16_BYTES, 256); }     // round 5 (ABI 2)
     o.total = at;
     return o;
 }
@@ -217,6 +219,7 @@ struct BwdPackOff {
     int nfrag[NCONV];
     size_t dec[NHEADS];          // transposed decoder matrices of head h
     size_t convbf[NCONV];        // bf16 images of the dgrad fragments (f16 fragment layout, nfrag[l] / 2 fragments)
+    size_t dect[NHEADS];         // bf16 transposed decoder matrices of the bf16 training decoder (giga_dect.h), derived from dec
     size_t total;
 };
 // decoder backward image per head: 5 blocks x (Wc^T: 3 row blocks x 4 frags, W0^T 4 frags, W1^T 4 frags)
@@ -236,6 +239,7 @@ inline BwdPackOff bwd_pack_offsets() {
     }
     for (int h = 0; h < NHEADS; ++h) { o.dec[h] = at; at += DECB_BYTES; }
     for (int l = 0; l < NCONV; ++l) { o.convbf[l] = at; at += (size_t)(o.nfrag[l] / 2) * FRAG; }
+    for (int h = 0; h < NHEADS; ++h) { o.dect[h] = at; at += (size_t)(NBLK * 10 + 1) * FRAG; }  // DECT_BWD_BYTES (giga_dect.h)
     o.total = at;
     return o;
 }

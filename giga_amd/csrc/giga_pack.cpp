@@ -8,6 +8,7 @@
 //    without any cross-lane movement.
 #include "giga_layout.h"
 #include "giga_conv32_geom.h"
+#include "giga_dect.h"
 
 #include <cmath>
 #include <cstring>
@@ -300,6 +301,7 @@ int pack_weights_host(const float* P, size_t n_params, int head_present, uint8_t
         pack_head16(P, po.head[h], HEAD_OUT[h], blob + ko.dec16[h]);
         pack_head32(P, po.head[h], HEAD_OUT[h], blob + ko.dec32[h]);
         pack_head16s(P, po.head[h], HEAD_OUT[h], blob + ko.dec16s[h]);
+        dect_pack_fwd_host(blob + ko.dec32[h], blob + ko.dect[h]);        // bf16 training image, from the fp32 image just packed
     }
     // Folded variants.  The encoder ends with conv_final, a 1x1 convolution WITHOUT activation (unet.py:238), and the
     // decoder's first use of the planes is linear too: bilinear sampling (decoder.py:117-122) followed by fc_c (:169).
@@ -394,7 +396,10 @@ int pack_bwd_host(const float* P, size_t n_params, int head_present, uint8_t* bl
     std::memset(blob, 0, bo.total);
     for (int l = 0; l < NCONV; ++l) pack_conv_dgrad(P, po, bo, l, blob);
     for (int h = 0; h < NHEADS; ++h)
-        if (head_present >> h & 1) pack_head_bwd(P, po.head[h], HEAD_OUT[h], blob + bo.dec[h]);
+        if (head_present >> h & 1) {
+            pack_head_bwd(P, po.head[h], HEAD_OUT[h], blob + bo.dec[h]);
+            dect_pack_bwd_host(blob + bo.dec[h], blob + bo.dect[h]);
+        }
     // bf16 images of the dgrad fragments: f16-layout fragment i16 (k-group of 32) = fp32 fragments 2*i16 and 2*i16 + 1
     for (int l = 0; l < NCONV; ++l) {
         const float* f32 = reinterpret_cast<const float*>(blob + bo.conv[l]);

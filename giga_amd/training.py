@@ -61,7 +61,8 @@ class _TrainState:
         self.flat = torch.empty(self.n_params, device=device, dtype=torch.float32)
         self.repacks = 0                # how often the images were rebuilt: identifies the weights they currently hold
         self._wkey = None               # (storage, version) of every parameter the images were built from
-        self.bf16 = False               # set by ConvolutionalOccupancyNetwork.set_train_precision("bf16")
+        self.bf16 = False               # set by ConvolutionalOccupancyNetwork.set_train_precision("bf16" / "bf16_convs")
+        self.bf16_dec = False           # ... ("bf16"): the decoder heads on the fused bf16 kernels (csrc/giga_decoder_train16.hip)
         self.data_parallel = False      # set by ConvolutionalOccupancyNetwork.enable_data_parallel()
         self.group = None
         self._pool = []
@@ -170,15 +171,17 @@ class GigaFunction(torch.autograd.Function):
                  torch.empty((B, N, 4), device=dev) if hp & 2 and N > 0 else None,
                  torch.empty((B, N), device=dev) if hp & 4 and N > 0 else None,
                  torch.empty((B, M), device=dev) if hp & 8 and M > 0 else None]
+            dprec = _capi.DEC_BF16 if state.bf16 and state.bf16_dec else 0
             if state.head_present & 7 and N > 0:
                 _capi.check(L.giga_decoder_forward(_capi.ptr(sb.nhwc), _capi.ptr(p), _capi.ptr(state.blob),
                                                    state.head_present & 7, _capi.ptr(o[0]), _capi.ptr(o[1]), _capi.ptr(o[2]),
-                                                   None, B, N, 0, 1, s), "giga_decoder_forward")
+                                                   None, B, N, dprec, 1, s), "giga_decoder_forward")
             if state.head_present & 8 and M > 0:
                 _capi.check(L.giga_decoder_forward(_capi.ptr(sb.nhwc), _capi.ptr(p_tsdf), _capi.ptr(state.blob), 8, None,
-                                                   None, None, _capi.ptr(o[3]), B, M, 0, 0, s), "giga_decoder_forward")
+                                                   None, None, _capi.ptr(o[3]), B, M, dprec, 0, s), "giga_decoder_forward")
         ctx.state, ctx.dims, ctx.lease, ctx.repacks = state, (B, N, M), _Lease(sb), state.repacks
         ctx.bf16 = state.bf16
+        ctx.bf16_dec = state.bf16 and state.bf16_dec
         # save_for_backward, not a plain attribute: a node that holds its own outputs in a Python attribute is a reference
         # cycle (output -> grad_fn -> ctx -> output) that only the cyclic GC would free
         ctx.save_for_backward(x, p, p_tsdf, *o)
@@ -209,7 +212,8 @@ class GigaFunction(torch.autograd.Function):
             _capi.check(L.giga_backward(
                 _capi.ptr(x), _capi.ptr(state.blob), _capi.ptr(state.bwd_blob), _capi.ptr(sb.ws), _capi.ptr(sb.nhwc),
                 _capi.ptr(p), _capi.ptr(p_tsdf), _ptr_array(outs), _ptr_array(douts), _capi.ptr(grads),
-                grads.numel(), state.head_present | state.bwd_flags | (_capi.BF16_CONVS if ctx.bf16 else 0), B, N, M,
+                grads.numel(), state.head_present | state.bwd_flags | (_capi.BF16_CONVS if ctx.bf16 else 0) |
+                (_capi.BF16_DECODER if ctx.bf16_dec else 0), B, N, M,
                 _capi.ptr(sb.wsb), sb.wsb.numel(),
                 _capi.stream_ptr(dev)), "giga_backward")
         if state.data_parallel:

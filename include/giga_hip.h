@@ -23,8 +23,9 @@
  *                      within 1e-5 of the fp32 path).  Decoder entry points only change arithmetic; planes are fp32
  *                      (as for precision 0); the encoder runs its convolutions (conv_in and the U-Net) in the same split
  *                      arithmetic;
- *                  3 = (encoder entry points only) bf16 operands / fp32 accumulate in the U-Net convolutions, fp32 activations
- *                      in memory, fp32 conv_in: the forward of the bf16 training step (see GIGA_BF16_CONVS);
+ *                  3 = bf16 operands / fp32 accumulate, fp32 activations and planes in memory: the forward of the bf16 training
+ *                      step.  Encoder entry points: the U-Net convolutions (fp32 conv_in; see GIGA_BF16_CONVS); giga_decoder_forward:
+ *                      every linear layer of the heads (see GIGA_BF16_DECODER; not with GIGA_FOLD_FINAL, not the lattice entry point);
  *   - "NHWC planes": one buffer [3 (xz,xy,yz)][B][40 (H)][40 (W)][32 (C)] of float (precision 0 and 2) or
  *     _Float16 (precision 1).  H/W follow the reference's plane indexing (ConvONets/common.py:246-251,
  *     303-318): xz -> (H=z, W=x), xy -> (H=y, W=x), yz -> (H=z, W=y).
@@ -41,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GIGA_ABI_VERSION 1
+#define GIGA_ABI_VERSION 2   /* 2: the packed blobs grew (bf16 decoder images; conv_in f16 slot order of round 4): repack */
 
 #define GIGA_HEAD_QUAL 1   /* decoder_qual  (out_dim 1, sigmoid epilogue)     */
 #define GIGA_HEAD_ROT 2    /* decoder_rot   (out_dim 4, L2-normalise epilogue) */
@@ -190,6 +191,14 @@ int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, cons
  * fp32 accumulate, fp32 gradients in memory); pairs with an encoder forward at precision 3.  ConvTranspose / 1x1 weight
  * gradients, the decoder and conv_in stay fp32.  BASELINE config c5 ("bf16"). */
 #define GIGA_BF16_CONVS 32
+/* GIGA_BF16_DECODER, OR-ed into giga_backward's head_present: the decoder heads' backward runs as ONE fused bf16 kernel per call
+ * (csrc/giga_decoder_train16.hip): the forward chain recomputed on bf16 MFMA, the gradient chain with the transposed bf16 matrices,
+ * and the weight gradients dW = dY^T X in the same kernel (tiles handed over through LDS and read back transposed with
+ * ds_read_b64_tr_b16; gradient tiles resident in registers across the workgroup's points) -- no [P][32] row arrays, no separate
+ * weight-gradient launch; one reduce launch for every head of the step.  Pairs with giga_decoder_forward at precision 3 (the same
+ * bf16 arithmetic; the backward recomputes it bit for bit).  Operands (features, activations, gradients, weights) are rounded to
+ * bf16 once, accumulation and the residual stream are fp32, fc_p / the biases are carried as hi + lo bf16 pairs. */
+#define GIGA_BF16_DECODER 64
 /* bf16 images of the convolution fragments, derived ON THE DEVICE from the fp32 fragments of the same blob(s) after
  * giga_repack_device (either pointer may be NULL).  giga_pack_weights / giga_pack_bwd_weights fill them on the host too. */
 int giga_derive_bf16_fragments(void* packed_dev, void* bwd_packed_dev, void* stream);

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"libgiga_hip.so does not export {name}"
     assert declared == set(_capi.EXPORTS), declared ^ set(_capi.EXPORTS)
-    assert lib.giga_abi_version() == 1
+    assert lib.giga_abi_version() == 2
     assert lib.giga_strerror(0) == b"ok" and lib.giga_strerror(-4) == b"workspace too small"
 
 
@@ -76,7 +76,8 @@ def test_argument_validation_without_gpu():
     assert lib.giga_encoder_forward(None, None, None, None, 1, 0, None, 0, None) == -1
     assert lib.giga_encoder_forward(None, None, None, None, 0, 0, None, 0, None) == 0     # empty batch
     assert lib.giga_decoder_forward(None, None, None, 7, None, None, None, None, 0, 5, 0, 1, None) == 0
-    assert lib.giga_decoder_forward(None, None, None, 7, None, None, None, None, 1, 5, 3, 1, None) == -5
+    assert lib.giga_decoder_forward(None, None, None, 7, None, None, None, None, 1, 5, 4, 1, None) == -5
+    assert lib.giga_decoder_forward(None, None, None, 7, None, None, None, None, 1, 5, 3, 1, None) == -1      # bf16 decoder: null pointers
     assert lib.giga_pack_weights(None, 0, 15, None, 0) == -1
     # more than GIGA_MAX_SCENES scenes per call: refused before anything is enqueued (fake host addresses, never dereferenced)
     fake = torch.zeros(4)
