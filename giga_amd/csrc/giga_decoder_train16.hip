@@ -62,8 +62,10 @@ constexpr int TILE_B = 2048;
 constexpr int ZONE_WAVE = 9 * TILE_B;                           // 18432
 constexpr int ZONE_B = 4 * ZONE_WAVE;                           // 73728 >= DECT_FWD_BYTES
 constexpr int CW_B = 3 * TILE_B + 512 + 256;                    // 6912
-constexpr int LDS_FWD = ZONE_B + 4 * CW_B;                      // 101376
+constexpr int LDS_FWD = ZONE_B + 4 * CW_B;                      // 101376: end of the backward's per-wave regions
 constexpr int LDS_BWD = LDS_FWD + (int)DECT_BWD_BYTES;          // 153600
+constexpr int FWD_NW = 8;
+constexpr int LDS_FWD8 = ZONE_B + FWD_NW * CW_B;                // 129024: forward kernel (image in the zone + 8 waves' C tiles)
 static_assert(ZONE_B >= (int)DECT_FWD_BYTES && LDS_BWD <= 160 * 1024, "LDS budget of the bf16 training decoder");
 
 // byte address of the 8-byte piece (point p, features 4q .. 4q+3) of a [32][32] bf16 tile: rows of 64 bytes, the pieces of a row
@@ -87,10 +89,10 @@ struct DectArgs {
     float invN;
 };
 
-// 64 lanes x 16 B chunks of an image by LDS-DMA, the chunks dealt over the four waves
-template <int CHUNKS>
+// 64 lanes x 16 B chunks of an image by LDS-DMA, the chunks dealt over the workgroup's waves
+template <int CHUNKS, int NW>
 __device__ __forceinline__ void dect_dma(const uint8_t* src, uint8_t* lds_dst, int wave, int lane) {
-    for (int c = wave; c < CHUNKS; c += 4)
+    for (int c = wave; c < CHUNKS; c += NW)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)c * FRAG + lane * 16),
                                          (__attribute__((address_space(3))) void*)(lds_dst + c * FRAG), 16, 0, 0);
 }
@@ -160,8 +162,18 @@ __device__ __forceinline__ bf8 onehot_col(int lane, int col) {          // B ope
 
 template <int I> struct IntC { static constexpr int v = I; };
 
-template <bool BWD>
-__global__ __launch_bounds__(256, 1) void dect_kernel(DectArgs a) {
+#ifdef GIGA_TRACE   // diagnostic build: s_memtime timeline of workgroup 0 (tools/gpu_dect_trace.py)
+static __device__ long long g_dect_trace[2 * 4 * 40];     // [occupancy head ? 1 : 0][wave][point]
+#define DT(idx) do { if (BWD && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && round == 0) g_dect_trace[(id == 3) * 160 + wave * 40 + (idx)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DT(idx) do {} while (0)
+#endif
+
+// NW waves of one 32-point tile each per round.  Backward: 4 (one per SIMD, 472 VGPRs).  Forward: 8 -- two per SIMD, so that one
+// wave's gather runs under the other's chain -- whose C tiles sit behind the zone at a stride of CW_B bytes like the backward's.
+template <bool BWD, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void dect_kernel(DectArgs a) {
+    static_assert(!BWD || NW == 4, "the backward's tile ownership is written for four waves");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -177,10 +189,10 @@ __global__ __launch_bounds__(256, 1) void dect_kernel(DectArgs a) {
     const long long tiles_total = (a.P + 31) / 32;
     const int bid = xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
     const long long tile_lo = tiles_total * bid / gridDim.x, tile_hi = tiles_total * (bid + 1) / gridDim.x;
-    const int rounds = (int)((tile_hi - tile_lo + 3) / 4);
+    const int rounds = (int)((tile_hi - tile_lo + NW - 1) / NW);
 
-    dect_dma<(int)(DECT_FWD_BYTES / FRAG)>(a.img_fwd[h], zone, wave, lane);
-    if constexpr (BWD) dect_dma<(int)(DECT_BWD_BYTES / FRAG)>(a.img_bwd[h], imgb, wave, lane);
+    dect_dma<(int)(DECT_FWD_BYTES / FRAG), NW>(a.img_fwd[h], zone, wave, lane);
+    if constexpr (BWD) dect_dma<(int)(DECT_BWD_BYTES / FRAG), NW>(a.img_bwd[h], imgb, wave, lane);
 
     // per-lane LDS offsets, the same for every tile
     int wa[4];                                                           // chain layout -> tile pieces (tile_write)
@@ -201,38 +213,77 @@ __global__ __launch_bounds__(256, 1) void dect_kernel(DectArgs a) {
     }
 
     for (int round = 0; round < rounds; ++round) {
-        const long long tile = tile_lo + (long long)round * 4 + wave;
+        const long long tile = tile_lo + (long long)round * NW + wave;
         const bool active = tile < tile_hi;
         long long g = tile * 32 + n;
         const bool valid = active && g < a.P;
         if (!valid) g = a.P - 1;
+        DT(0);
         // ---------------- gather: four adjacent lanes fetch the four 16-byte quads of one (point, channel half) = one 64-byte line,
         // interpolate (the fma order of aten's grid_sampler: nw, ne, sw, se), round to bf16 and write the 8-byte piece of the C
         // tile; the chain then reads its B operands (lane = point) from the tile.  The tile is also the X operand of fc_c's
         // weight gradient.
         const long long tile0 = tile * 32;
+        {
+            // phase 1: the coordinates of this lane's four (point, piece) items; phase 2: 2 x 24 tap loads (two round trips instead of
+            // one per item: left to itself the compiler waits for every item's coordinates before it asks for the item's taps);
+            // phase 3: interpolate, round, store.  The sched_barriers pin the phases.
+            float cx[4], cy[4], cz[4];
+            int bp[4];
+            const int q = lane & 7;                                      // piece = channels 4q .. 4q+3
 #pragma unroll
-        for (int part = 0; part < 4; ++part) {
-            const int pt = part * 8 + (lane >> 3), q = lane & 7;          // point of the tile, piece = channels 4q .. 4q+3
-            long long gp = active ? tile0 + pt : a.P - 1;
-            if (gp >= a.P) gp = a.P - 1;
-            int bp, rdummy;
-            split_scene(gp, a.N, a.invN, bp, rdummy);
-            const float nx = norm_coord(a.p[3 * gp + 0]), ny = norm_coord(a.p[3 * gp + 1]), nz = norm_coord(a.p[3 * gp + 2]);
+            for (int part = 0; part < 4; ++part) {
+                const int pt = part * 8 + (lane >> 3);
+                long long gp = active ? tile0 + pt : a.P - 1;
+                if (gp >= a.P) gp = a.P - 1;
+                int rdummy;
+                split_scene(gp, a.N, a.invN, bp[part], rdummy);
+                cx[part] = a.p[3 * gp + 0]; cy[part] = a.p[3 * gp + 1]; cz[part] = a.p[3 * gp + 2];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                const Bilin bl = bilin_setup(pl == 2 ? ny : nx, pl == 1 ? ny : nz);       // xz: (x, z)  xy: (x, y)  yz: (y, z)
-                const float* base = a.planes + pl * plane_stride + (size_t)bp * RES * RES * CD + 4 * q;
-                const float4 v00 = *reinterpret_cast<const float4*>(base + (size_t)bl.o00 * CD);
-                const float4 v01 = *reinterpret_cast<const float4*>(base + (size_t)bl.o01 * CD);
-                const float4 v10 = *reinterpret_cast<const float4*>(base + (size_t)bl.o10 * CD);
-                const float4 v11 = *reinterpret_cast<const float4*>(base + (size_t)bl.o11 * CD);
-                bf4 o;
-                o[0] = (__bf16)fmaf(v11.x, bl.w11, fmaf(v10.x, bl.w10, fmaf(v01.x, bl.w01, v00.x * bl.w00)));
-                o[1] = (__bf16)fmaf(v11.y, bl.w11, fmaf(v10.y, bl.w10, fmaf(v01.y, bl.w01, v00.y * bl.w00)));
-                o[2] = (__bf16)fmaf(v11.z, bl.w11, fmaf(v10.z, bl.w10, fmaf(v01.z, bl.w01, v00.z * bl.w00)));
-                o[3] = (__bf16)fmaf(v11.w, bl.w11, fmaf(v10.w, bl.w10, fmaf(v01.w, bl.w01, v00.w * bl.w00)));
-                *reinterpret_cast<bf4*>(cw + pl * TILE_B + piece_addr(pt, q)) = o;
+            for (int half = 0; half < 2; ++half) {                       // 24 loads (96 VGPRs) in flight per half
+                float4 v[2][3][4];
+                float wq[2][3][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int part = 2 * half + u;
+                    const float nx = norm_coord(cx[part]), ny = norm_coord(cy[part]), nz = norm_coord(cz[part]);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const Bilin bl = bilin_setup(pl == 2 ? ny : nx, pl == 1 ? ny : nz);   // xz: (x, z)  xy: (x, y)  yz: (y, z)
+                        const float* base = a.planes + pl * plane_stride + (size_t)bp[part] * RES * RES * CD + 4 * q;
+                        v[u][pl][0] = *reinterpret_cast<const float4*>(base + (size_t)bl.o00 * CD);
+                        v[u][pl][1] = *reinterpret_cast<const float4*>(base + (size_t)bl.o01 * CD);
+                        v[u][pl][2] = *reinterpret_cast<const float4*>(base + (size_t)bl.o10 * CD);
+                        v[u][pl][3] = *reinterpret_cast<const float4*>(base + (size_t)bl.o11 * CD);
+                        wq[u][pl][0] = bl.w00; wq[u][pl][1] = bl.w01; wq[u][pl][2] = bl.w10; wq[u][pl][3] = bl.w11;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // (the interpolation below is pure arithmetic, which the optimiser would hoist back in front of the barrier and interleave
+                //  with the loads, a handful in flight at a time: its weights pass through an opaque asm that stays behind the barrier)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        asm volatile("" : "+v"(wq[u][pl][0]), "+v"(wq[u][pl][1]), "+v"(wq[u][pl][2]), "+v"(wq[u][pl][3]));
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int pt = (2 * half + u) * 8 + (lane >> 3);
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const float4 v00 = v[u][pl][0], v01 = v[u][pl][1], v10 = v[u][pl][2], v11 = v[u][pl][3];
+                        const float w00 = wq[u][pl][0], w01 = wq[u][pl][1], w10 = wq[u][pl][2], w11 = wq[u][pl][3];
+                        bf4 o4;
+                        o4[0] = (__bf16)fmaf(v11.x, w11, fmaf(v10.x, w10, fmaf(v01.x, w01, v00.x * w00)));
+                        o4[1] = (__bf16)fmaf(v11.y, w11, fmaf(v10.y, w10, fmaf(v01.y, w01, v00.y * w00)));
+                        o4[2] = (__bf16)fmaf(v11.z, w11, fmaf(v10.z, w10, fmaf(v01.z, w01, v00.z * w00)));
+                        o4[3] = (__bf16)fmaf(v11.w, w11, fmaf(v10.w, w10, fmaf(v01.w, w01, v00.w * w00)));
+                        *reinterpret_cast<bf4*>(cw + pl * TILE_B + piece_addr(pt, q)) = o4;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // aux operand of the chain: [p_hi (3), 1, p_lo (3), 1] on hi = 0 lanes, [p_hi (3), 0 ...] on hi = 1 lanes (giga_dect.h)
@@ -250,9 +301,11 @@ __global__ __launch_bounds__(256, 1) void dect_kernel(DectArgs a) {
                 at[4 * 32 + n] = xl; at[5 * 32 + n] = yl; at[6 * 32 + n] = zl; at[7 * 32 + n] = zero;
             }
         }
+        DT(1);
         // the forward image (first round: requested at kernel start; later rounds: after the previous round's last barrier) has landed
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
+        DT(2);
         bf8 cfb[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -301,6 +354,7 @@ __global__ __launch_bounds__(256, 1) void dect_kernel(DectArgs a) {
             o = mfma_bf(W[56 * 64 + lane], XO[0], o);
             o = mfma_bf(W[57 * 64 + lane], XO[1], o);
         }
+        DT(3);
         if constexpr (!BWD) {
             if (hi == 0 && valid) {
                 float d0 = o[0], d1 = o[1], d2 = o[2], d3 = o[3];
@@ -338,6 +392,7 @@ __global__ __launch_bounds__(256, 1) void dect_kernel(DectArgs a) {
             }
             if (!valid) { dO[0] = 0.f; dO[1] = 0.f; dO[2] = 0.f; dO[3] = 0.f; }
             __syncthreads();             // every wave is through its forward chain: the zone becomes the waves' step buffers
+            DT(4);
             uint8_t* zw = zone + wave * ZONE_WAVE;
             // ---------------- step "5": XO, dO, DN[5] = (Wout^T dO) * (net5 > 0) ------------------------------------------------
             const float* wout = reinterpret_cast<const float*>(imgb + (size_t)DECT_BWD_FRAGS * FRAG);     // [4][32], bf16 values
@@ -356,7 +411,9 @@ __global__ __launch_bounds__(256, 1) void dect_kernel(DectArgs a) {
             mask_by(G, 0, XO[0]); mask_by(G, 1, XO[1]);
             bf8 Gb[2] = {cvt_bf8(G, 0), cvt_bf8(G, 1)};
             tile_write(zw + 6 * TILE_B + (5 % 3) * TILE_B, wa, Gb[0], Gb[1]);
+            DT(5);
             __syncthreads();
+            DT(6);
             if (wave == 2) {             // fc_out: dW[o][k] = sum_p dO[p][o] XO[p][k]
 #pragma unroll
                 for (int w2 = 0; w2 < 4; ++w2) {
@@ -406,7 +463,9 @@ __global__ __launch_bounds__(256, 1) void dect_kernel(DectArgs a) {
                             *reinterpret_cast<float4*>(a.dcbuf + g * 96 + pl * 32 + 8 * q + 4 * hi) =
                                 make_float4(dc[pl][4 * q], dc[pl][4 * q + 1], dc[pl][4 * q + 2], dc[pl][4 * q + 3]);
                 }
+                DT(7 + 3 * (4 - blk));
                 __syncthreads();
+                DT(8 + 3 * (4 - blk));
                 // ---- weight-gradient tiles of this block: wave w plays role (w + blk) & 3 -------------------------------------
                 auto role = [&](auto wc) __attribute__((always_inline)) {
                     constexpr int WV = decltype(wc)::v;
@@ -452,9 +511,11 @@ __global__ __launch_bounds__(256, 1) void dect_kernel(DectArgs a) {
                 else if (wave == 1) role(IntC<1>{});
                 else if (wave == 2) role(IntC<2>{});
                 else role(IntC<3>{});
+                DT(9 + 3 * (4 - blk));
             };
             step(IntC<4>{}); step(IntC<3>{}); step(IntC<2>{}); step(IntC<1>{}); step(IntC<0>{});
             __syncthreads();             // every wave has read what it needs of this round's tiles
+            DT(22);
             if (a.gplanes && !a.dcbuf) {
                 // ---------------- scatter dc into the plane gradients (sample_plane_feature backward) with fp32 atomics, transposed
                 // through a wave-private stage in the zone so that one atomic instruction covers two (point, tap) pairs x 32
@@ -483,23 +544,29 @@ __global__ __launch_bounds__(256, 1) void dect_kernel(DectArgs a) {
                         }
                     }
                 }
-                // wave-private staging: DS operations of one wave execute in order, no barrier needed
+                // every wave's (point pair, plane) items are dealt over the FOUR waves: float atomics retire slowly (~180 clocks per wave
+                // instruction), and with one query per scene a single wave of the workgroup has points at all
+                __syncthreads();
                 const int c = lane & 31;
+                for (int item = wave; item < 4 * 48; item += 4) {
+                    const int w2 = item / 48, rest = item - 48 * w2, pl = rest >> 4, pr = rest & 15;
+                    if ((tile_lo + (long long)round * NW + w2) >= tile_hi) continue;      // that wave had no tile (uniform)
+                    const float* T2 = reinterpret_cast<const float*>(zone + w2 * ZONE_WAVE);
+                    const int* Q2 = reinterpret_cast<const int*>(T2 + 32 * 96);
+                    const float* W2 = reinterpret_cast<const float*>(Q2 + 32 * 12);
+                    const int pt = 2 * pr + hi;
+                    const float v = T2[pt * 96 + pl * 32 + c];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    for (int pr = 0; pr < 16; ++pr) {
-                        const int pt = 2 * pr + hi;
-                        const float v = T[pt * 96 + pl * 32 + c];
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const int off = Q[(pt * 3 + pl) * 4 + t];
-                            const float w = Wt[(pt * 3 + pl) * 4 + t];
-                            if (off >= 0) atomicAdd(a.gplanes + off + c, v * w);
-                        }
+                    for (int t = 0; t < 4; ++t) {
+                        const int off = Q2[(pt * 3 + pl) * 4 + t];
+                        const float w = W2[(pt * 3 + pl) * 4 + t];
+                        if (off >= 0) atomicAdd(a.gplanes + off + c, v * w);
                     }
+                }
                 __syncthreads();         // the stage is free before the next round's forward image lands on it
             }
-            if (round + 1 < rounds) dect_dma<(int)(DECT_FWD_BYTES / FRAG)>(a.img_fwd[h], zone, wave, lane);
+            DT(23);
+            if (round + 1 < rounds) dect_dma<(int)(DECT_FWD_BYTES / FRAG), NW>(a.img_fwd[h], zone, wave, lane);
         }
     }
     if constexpr (BWD) {
@@ -636,6 +703,14 @@ __global__ __launch_bounds__(64) void dect_derive_kernel(uint8_t* fwd_blob, uint
     }
 }
 
+#ifdef GIGA_TRACE
+}  // namespace giga
+extern "C" int giga_debug_dect_trace(long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(giga::g_dect_trace), sizeof(long long) * 2 * 4 * 40) == hipSuccess ? 0 : -10;
+}
+namespace giga {
+#endif
+
 int launch_dect_derive(uint8_t* fwd_blob, uint8_t* bwd_blob, hipStream_t s) {
     const PackOff ko = pack_offsets();
     const BwdPackOff bo = bwd_pack_offsets();
@@ -664,8 +739,9 @@ int launch_dect_forward(const float* planes, const float* p, const uint8_t* blob
         a.head_id[a.nheads] = h; a.img_fwd[a.nheads] = blob + ko.dect[h]; a.out[a.nheads] = outs[h];
         ++a.nheads;
     }
-    giga::dyn_lds_once(reinterpret_cast<const void*>(dect_kernel<false>), LDS_FWD);
-    GIGA_LAUNCH(dect_kernel<false>, dim3(dect_grid(P), a.nheads), dim3(256), LDS_FWD, s, a);
+    const long long tiles = (P + 31) / 32, wgs = (tiles + FWD_NW - 1) / FWD_NW;
+    giga::dyn_lds_once(reinterpret_cast<const void*>(dect_kernel<false, FWD_NW>), LDS_FWD8);
+    GIGA_LAUNCH((dect_kernel<false, FWD_NW>), dim3((unsigned)(wgs < 256 ? wgs : 256), a.nheads), dim3(FWD_NW * 64), LDS_FWD8, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
@@ -694,8 +770,8 @@ int launch_dect_backward(const float* planes, const float* p, const uint8_t* blo
         pend->partial[pend->n] = a.partial[a.nheads]; pend->nwg[pend->n] = grid; pend->head_id[pend->n] = h; ++pend->n;
         ++a.nheads;
     }
-    giga::dyn_lds_once(reinterpret_cast<const void*>(dect_kernel<true>), LDS_BWD);
-    GIGA_LAUNCH(dect_kernel<true>, dim3(grid, a.nheads), dim3(256), LDS_BWD, s, a);
+    giga::dyn_lds_once(reinterpret_cast<const void*>(dect_kernel<true, 4>), LDS_BWD);
+    GIGA_LAUNCH((dect_kernel<true, 4>), dim3(grid, a.nheads), dim3(256), LDS_BWD, s, a);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 

@@ -219,15 +219,17 @@ def test_bf16_training_step(sd7, monkeypatch):
          torch.randn(32, 256, generator=g5) / 16]
     sdg = {k: v.clone().requires_grad_(True) for k, v in sd7.items()}
     sum((o * r).sum() for o, r in zip(O.model_forward(sdg, x, pos, p_tsdf=pos_occ), R)).backward()
-    net = networks.get_network("giga"); net.load_state_dict(sd7); net = net.to(dev).train().set_train_precision("bf16")
-    monkeypatch.setattr(_capi, "ENC_BF16", 0)                # forward stays fp32 for this part
+    net = networks.get_network("giga"); net.load_state_dict(sd7); net = net.to(dev).train().set_train_precision("bf16_convs")
+    monkeypatch.setattr(_capi, "ENC_BF16", 0)                # forward stays fp32 for this part (and the decoders: "bf16_convs")
     out = net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev))
     sum((o * r.to(dev)).sum() for o, r in zip(out, R)).backward()
     worst = max((((p.grad.cpu() - sdg[n].grad).norm() / (sdg[n].grad.norm() + 1e-12)).item(), n) for n, p in net.named_parameters())
     print("bf16 dgrad convolutions, fp32 forward: worst relative L2 gradient error", worst)
     assert worst[0] <= 2e-2, worst
     monkeypatch.undo()
-    # (c) the whole bf16 step on the joint loss
+    # (c) the whole bf16 step on the joint loss: bf16 convolutions AND bf16 decoder heads (tests/test_gpu_train16.py holds the
+    #     decoder kernels to their operand-rounded reference)
+    net.set_train_precision("bf16")
     net.zero_grad(set_to_none=True)
     ref_loss, ref_grads, _ = _oracle_grads(sd7, x, pos, pos_occ, y)
     loss, _ = giga_loss(net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev)), tuple(t.to(dev) for t in y))
