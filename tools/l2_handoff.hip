@@ -31,7 +31,7 @@ template <int POL> __device__ __forceinline__ u32x4 ld16(const u32x4* p) {
 
 template <int SP, int LP>
 __global__ __launch_bounds__(NT) void k(unsigned* cnt, unsigned* tickets, u32x4* rec /* [ROUNDS][8][32][REG] */, const u32x4* cold,
-                                        long long* clocks /* [2][NWG] */, unsigned* bad_out, int readers, int use_cold, int second, int warm, int self) {
+                                        long long* clocks /* [2][NWG] */, unsigned* bad_out, int readers, int use_cold, int second, int warm, int self, int pre_stride = 0) {
     __shared__ int s_rank;
     const int xcd = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7;
     if (threadIdx.x == 0) s_rank = (int)__hip_atomic_fetch_add(tickets + xcd * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -50,6 +50,28 @@ __global__ __launch_bounds__(NT) void k(unsigned* cnt, unsigned* tickets, u32x4*
         const u32x4* theirs = use_cold ? cold + ((rr * 8 + xcd) * 32 + rank) * RV
                                        : rec + ((rr * 8 + xcd) * 32 + src_rank) * RV;
         const unsigned stamp = (unsigned)r * 1000u + (unsigned)src_rank;
+        if (pre_stride > 0) {
+            // translation prefetch: BEFORE the producer has written it, touch one word per `pre_stride` bytes of the region this workgroup
+            // will read after the barrier (the values are stale and discarded; the page-table walk is what is wanted)
+            const int nt = REG_BYTES / pre_stride;
+            if ((int)threadIdx.x < nt) {
+                unsigned junk;
+                asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(junk) : "v"(reinterpret_cast<const char*>(theirs) + (size_t)threadIdx.x * pre_stride) : "memory");
+                bad += junk == 0xFFFFFFFEu;
+            }
+        }
+        if (pre_stride < 0) {
+            // write-allocate by hand: the PRODUCER reads the whole region it is about to write (stale values, discarded), so that its
+            // stores hit lines that are already in the L2
+            u32x4 junk[IT];
+#pragma unroll
+            for (int i = 0; i < IT; ++i) junk[i] = ld16<0>(mine + i * NT + threadIdx.x);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < IT; ++i) asm volatile("" : "+v"(junk[i]));    // ALL four registers of every load stay allocated until here:
+#pragma unroll                                                                 // the compiler believes an asm load completes at once and
+            for (int i = 0; i < IT; ++i) bad += junk[i].w == 0xFFFFFFFEu;      // re-uses the registers of unused components while it is in flight
+        }
 #pragma unroll
         for (int i = 0; i < IT; ++i) st16<SP>(mine + i * NT + threadIdx.x, u32x4{(unsigned)r * 1000u + rank, threadIdx.x, (unsigned)i, 7u});
         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -65,6 +87,8 @@ __global__ __launch_bounds__(NT) void k(unsigned* cnt, unsigned* tickets, u32x4*
 #pragma unroll
             for (int i = 0; i < IT; ++i) v[i] = ld16<LP>(theirs + i * NT + threadIdx.x);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < IT; ++i) asm volatile("" : "+v"(v[i]));
             const long long t1 = __builtin_amdgcn_s_memtime();
             __syncthreads();
             const long long t2 = __builtin_amdgcn_s_memtime();
@@ -77,6 +101,8 @@ __global__ __launch_bounds__(NT) void k(unsigned* cnt, unsigned* tickets, u32x4*
 #pragma unroll
                 for (int i = 0; i < IT; ++i) w[i] = ld16<LP>(again + i * NT + threadIdx.x);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < IT; ++i) asm volatile("" : "+v"(w[i]));
                 __syncthreads();
                 const long long t4 = __builtin_amdgcn_s_memtime();
                 if (threadIdx.x == 0) total2 += t4 - t3;
@@ -96,9 +122,9 @@ __global__ __launch_bounds__(NT) void k(unsigned* cnt, unsigned* tickets, u32x4*
 }
 
 template <int SP, int LP>
-static void run(const char* what, unsigned* cnt, unsigned* tickets, u32x4* rec, u32x4* cold, long long* clocks, unsigned* bad, int readers, int use_cold, int second = 0, int warm = 0, int self = 0) {
+static void run(const char* what, unsigned* cnt, unsigned* tickets, u32x4* rec, u32x4* cold, long long* clocks, unsigned* bad, int readers, int use_cold, int second = 0, int warm = 0, int self = 0, int pre_stride = 0) {
     (void)hipMemset(cnt, 0, 8 * 32 * 4); (void)hipMemset(tickets, 0, 8 * 32 * 4); (void)hipMemset(bad, 0, 4);
-    hipLaunchKernelGGL((k<SP, LP>), dim3(NWG), dim3(NT), 0, 0, cnt, tickets, rec, cold, clocks, bad, readers, use_cold, second, warm, self);
+    hipLaunchKernelGGL((k<SP, LP>), dim3(NWG), dim3(NT), 0, 0, cnt, tickets, rec, cold, clocks, bad, readers, use_cold, second, warm, self, pre_stride);
     (void)hipDeviceSynchronize();
     long long h[2 * NWG]; unsigned b;
     (void)hipMemcpy(h, clocks, sizeof h, hipMemcpyDeviceToHost); (void)hipMemcpy(&b, bad, 4, hipMemcpyDeviceToHost);
@@ -131,7 +157,11 @@ int main(int argc, char** argv) {
             run<0, 0>("WARM, reader = writer (L2-hit control)", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 1, 1);
             run<2, 0>("WARM, reader = writer, store sc1", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 1, 1);
             run<0, 0>("fresh regions, reader = writer", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 0, 1);
-            run<0, 0>("fresh regions: store plain / load plain", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 0, 0);
+            run<0, 0>("fresh regions: store plain / load plain + 2nd", cnt, tickets, rec, cold, clocks, bad, readers, 0, 1, 0, 0);
+            run<0, 0>("WARM ping-pong: store plain / load plain + 2nd", cnt, tickets, rec, cold, clocks, bad, readers, 0, 1, 1, 0);
+            run<0, 0>("fresh + translation prefetch every 4 KiB", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 0, 0, 4096);
+            run<0, 0>("fresh, producer READS its region before writing", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 0, 0, -1);
+            run<0, 4>("fresh, producer reads first / consumer load nt", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 0, 0, -1);
         }
         return 0;
     }
