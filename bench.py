@@ -363,8 +363,45 @@ def main():
     # -------- CPU baseline: the oracle (port of the reference path) on the host cores -------------------
     if single and not args.no_cpu_baseline:               # rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(sd, synth, M)
+    out["summary"] = summary_of(out)                      # LAST key: every named-config number inside the tail of the line
     print(json.dumps(out), flush=True)
     finish()
+
+
+def summary_of(out):
+    """Compact digest of the line (its last key): ms per step / pass of every BASELINE config the run measured and the roofline
+    fractions, so that a reader of the line's tail sees all of them."""
+    ex = out.get("extra", {})
+    g = lambda d, *ks: (lambda v: round(v, 4) if isinstance(v, float) else v)(_dig(d, ks))  # noqa: E731
+    s = {"c2_fp32_ms": round(out["ms_per_step"], 4), "c2_scenes_per_s": round(out["value"], 1),
+         "c2_unet_launch_frac_fp32_peak": g(out, "roofline", "frac"), "c2_launches": out.get("launches_per_step"),
+         "c2_fp16x3_ms": g(ex, "c2_fp16x3", "ms_per_step"), "c2_ii_fp32_ms": g(ex, "c2_ii", "fp32", "ms_per_step"),
+         "c2_ii_fp16x3_ms": g(ex, "c2_ii", "fp16x3", "ms_per_step")}
+    for k, v in ex.items():
+        if k.startswith("c4") and isinstance(v, dict):
+            s[k + "_ms"] = g(v, "ms_per_step") if "ms_per_step" in v else g(v, "ms_per_call")
+            fr = _dig(v, ("roofline", "frac"))
+            if fr is not None:
+                s[k + "_decoder_frac"] = round(fr, 4)
+        if k.startswith("c5_train_step") and isinstance(v, dict):
+            s[k + "_ms"] = g(v, "ms_per_step")
+            s[k + "_launches"] = v.get("launches_per_step")
+            fr = _dig(v, ("roofline", "frac"))
+            if fr is not None:
+                s[k + "_frac"] = round(fr, 4)
+    cb = out.get("cpu_baseline")
+    if cb:
+        s["cpu_scenes_per_s"] = round(cb["value"], 2)
+        s["cpu_cores"] = cb["cores"]
+    return s
+
+
+def _dig(d, ks):
+    for k in ks:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
 
 
 def core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, dec_occ_ms, dom, dom_ms, step_ms, named_ms, bracket_ms,
@@ -857,9 +894,56 @@ def bench_train(net, dev, synth, B, M, steps=50, rank=0, world=1, sync=None, pre
     el, per = _time_steps(step, steps, 0)
     if sync is not None:
         sync()
+    # ---- what the step is made of (untimed): the library's launches per step and, one launch per extra step, HIP events around
+    # EVERY launch of the step on the stream it runs on (giga_launch_probe); the five longest kernels and the step's roofline
+    from giga_amd import _capi
+    L = _capi.lib()
+    torch.cuda.synchronize()
+    n0 = L.giga_launch_count()
+    step()
+    torch.cuda.synchronize()
+    n_launch = int(L.giga_launch_count() - n0)
+    kernels = []
+    if rank == 0 and world == 1:
+        ev0, ev1 = L.giga_event_create(), L.giga_event_create()
+        ms = ctypes.c_float()
+        for i in range(1, n_launch + 1):
+            reps, name = [], ""
+            for _ in range(3):
+                torch.cuda.synchronize()
+                L.giga_launch_probe(L.giga_launch_count() + i, ev0, ev1)
+                step()
+                if L.giga_event_elapsed_ms(ev0, ev1, ctypes.byref(ms)) == 0:
+                    reps.append(ms.value)
+                name = (L.giga_launch_probe_name() or b"").decode()
+            L.giga_launch_probe(0, None, None)
+            if reps:
+                kernels.append((float(np.median(reps)), i, name))
+        L.giga_event_destroy(ev0); L.giga_event_destroy(ev1)
     net.eval().set_train_precision("fp32")
-    arith = ("bf16 MFMA operands / fp32 accumulate in the U-Net's forward and data-gradient convolutions, fp32 elsewhere (weight "
-             "gradients, decoders, conv_in, master weights)") if precision == "bf16" else "fp32"
+    arith = {"bf16": "bf16 MFMA operands / fp32 accumulate in the U-Net's forward, data-gradient and 3x3 weight-gradient convolutions and in "
+                     "the decoder heads (forward, gradient chain and weight gradients in one fused kernel per call); fp32 conv_in, "
+                     "ConvTranspose / 1x1 weight gradients, activations in memory, master weights and optimizer",
+             "bf16_convs": "bf16 MFMA operands / fp32 accumulate in the U-Net's convolutions only; fp32 decoders",
+             "fp32": "fp32"}[precision]
+    # algorithmic FLOPs of the step: 3 x the forward of the literal train_giga call (training ~ 3x forward FLOPs)
+    step_flop = 3.0 * B * (FLOP_ENCODER + FLOP_GRASP3 + FLOP_HEAD["tsdf"] * M)
+    ach = step_flop / el / 1e12
+    by_kernel = {}
+    for t, i, name in kernels:
+        e = by_kernel.setdefault(name, [0.0, 0])
+        e[0] += t; e[1] += 1
+    top = sorted(by_kernel.items(), key=lambda kv: -kv[1][0])[:5]
+    peak = PEAK_F16_MFMA_TFLOPS if precision.startswith("bf16") else PEAK_F32_MATRIX_TFLOPS
+    roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "frac_of_fp32_matrix_peak": ach / PEAK_F32_MATRIX_TFLOPS, "frac_of_bf16_mfma_peak": ach / PEAK_F16_MFMA_TFLOPS,
+            "flops_per_step": step_flop, "traffic": None,
+            "note": "whole step: 3 x the algorithmic forward FLOPs of the literal train_giga call / the wall time of a step; the "
+                    "per-kernel times below are HIP events around each launch of the step (giga_launch_probe), medians of three",
+            "sum_of_launch_ms": round(sum(t for t, _, _ in kernels), 4) if kernels else None,
+            "five_longest_kernels": [{"kernel": k, "ms_per_step": round(v[0], 4), "launches_per_step": v[1]} for k, v in top]}
+    if world > 1:
+        roof = None
     return {"workload": f"joint GIGA training step (train_giga.py:198-211): B={B} scenes/GPU, 1 grasp query + {M} "
                         f"occupancy queries, forward + fused loss + HIP backward + fused Adam"
                         f"{' (giga_amd.optim.FlatAdam: one launch)' if giga_adam else ''}"
@@ -867,6 +951,7 @@ def bench_train(net, dev, synth, B, M, steps=50, rank=0, world=1, sync=None, pre
                         + (", one RCCL all-reduce of the flat gradient bucket per step" if world > 1 else ""),
             "steps": steps, "ms_per_step": el * 1e3, "step_ms_median": float(np.median(per)), "step_ms_max": float(np.max(per)),
             "step_ms_p90": float(np.percentile(per, 90)), "scenes_per_sec": world * B / el,
+            "launches_per_step": n_launch, "roofline": roof,
             "final_loss": float(last["loss"].detach())}
 
 

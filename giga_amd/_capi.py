@@ -79,6 +79,8 @@ _SIGNATURES = {
                                       ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int,
                                       ctypes.c_void_p]),
     "giga_launch_count": (ctypes.c_ulonglong, []),
+    "giga_launch_probe": (ctypes.c_int, [ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_void_p]),
+    "giga_launch_probe_name": (ctypes.c_char_p, []),
     "giga_encoder_last_path": (ctypes.c_int, []),
     "giga_forget_device_state": (None, []),
     "giga_event_create": (ctypes.c_void_p, []),

@@ -63,6 +63,9 @@ int launch_planes_unpack(const void* src, float* dst, int B, int precision, hipS
 using namespace giga;
 
 std::atomic<unsigned long long> giga::g_launch_count{0};
+std::atomic<unsigned long long> giga::g_probe_target{0};
+void* giga::g_probe_ev[2] = {nullptr, nullptr};
+const char* volatile giga::g_probe_name = "";
 
 // byte offset of head h's weight image for a precision (0 fp32, 1 f16, 2 f16x3 split), plain or with conv_final folded in
 static size_t head_image_offset(const PackOff& ko, int h, int precision, bool fold) {
@@ -204,6 +207,15 @@ int giga_encoder_forward(const float* tsdf, const void* packed, void* planes_nhw
 }
 
 unsigned long long giga_launch_count(void) { return g_launch_count.load(std::memory_order_relaxed); }
+
+int giga_launch_probe(unsigned long long ordinal, void* ev_start, void* ev_stop) {
+    if (ordinal != 0 && (!ev_start || !ev_stop)) return -1;
+    g_probe_target.store(0, std::memory_order_relaxed);
+    g_probe_ev[0] = ev_start; g_probe_ev[1] = ev_stop;
+    g_probe_target.store(ordinal, std::memory_order_release);
+    return 0;
+}
+const char* giga_launch_probe_name(void) { return g_probe_name; }
 
 void giga_forget_device_state(void) {
     giga::dyn_lds_forget();

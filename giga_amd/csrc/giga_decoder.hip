@@ -1231,12 +1231,9 @@ __global__ __launch_bounds__(256) void decoder_f32_tile_kernel(DecArgs a) {
     __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0): this wave's share of the chain fragments has landed
     __syncthreads();                                            // FC_1 .. FC_3 and the chain's fragments are in LDS
     if (blk_b >= 0) put_fc(blk_b, fc_block(fa));
-    if (wave == 0) {
-        const float4* CW = reinterpret_cast<const float4*>(CHW);
-        const float* ctab_l = reinterpret_cast<const float*>(CHW + 45 * FRAG);
-#pragma unroll
-        for (int blk = 0; blk < NBLK; ++blk) {
-            if (blk == NBLK - 1) __syncthreads();               // FC_4 (wave 1's second block) is in LDS
+    const float4* CW = reinterpret_cast<const float4*>(CHW);
+    const float* ctab_l = reinterpret_cast<const float*>(CHW + 45 * FRAG);
+    auto chain_block = [&](int blk) __attribute__((always_inline)) {
             if (blk > 0) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -1266,7 +1263,16 @@ __global__ __launch_bounds__(256) void decoder_f32_tile_kernel(DecArgs a) {
                 net = mfma32(A.z, relu(hh[4 * q + 2]), net);
                 net = mfma32(A.w, relu(hh[4 * q + 3]), net);
             }
-        }
+    };
+    // Wave 0 runs the chain; its block 4 needs FC_4, which wave 1 computes after the first barrier.  The second barrier sits in
+    // UNIFORM control flow (every wave reaches the same __syncthreads): blocks 0..3, barrier, block 4 and the tail.
+    if (wave == 0) {
+#pragma unroll
+        for (int blk = 0; blk < NBLK - 1; ++blk) chain_block(blk);
+    }
+    __syncthreads();                                            // FC_4 (wave 1's second block) is in LDS
+    if (wave == 0) {
+        chain_block(NBLK - 1);
         net = mfma32(CW[40 * 64 + lane].y, ax1, net);           // + b1 of block 4 (slot "1.0")
         f32x16 o;
 #pragma unroll
@@ -1283,8 +1289,6 @@ __global__ __launch_bounds__(256) void decoder_f32_tile_kernel(DecArgs a) {
             o = mfma32(A.w, relu(net[4 * q + 3]), o);
         }
         if (hi == 0 && valid) store_head(a, h, g, o[0], o[1], o[2], o[3]);
-    } else {
-        __syncthreads();                                        // (the barrier wave 0 takes before block 4)
     }
 }
 constexpr size_t DEC32_TILE_LDS = 4 * 32 * 96 * sizeof(float) + NBLK * 4 * 64 * sizeof(float4) + 46 * FRAG;   // 4 gather stages, FC exchange, chain fragments

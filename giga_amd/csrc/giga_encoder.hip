@@ -734,7 +734,8 @@ struct MegaSlots {                                 // per device: the last persi
     std::atomic_flag busy = ATOMIC_FLAG_INIT;
     hipStream_t stream[MEGA_TRACKED] = {};
     hipEvent_t ev[MEGA_TRACKED] = {};
-    bool used[MEGA_TRACKED] = {};
+    bool used[MEGA_TRACKED] = {};                  // ev[i] records stream[i]'s last persistent launch
+    bool pending[MEGA_TRACKED] = {};               // slot i is RESERVED for a launch on stream[i] that has not been recorded yet
 };
 static MegaSlots g_mega_slots[16];
 // Launches on ONE stream run one after the other, so what counts is the number of STREAMS whose last persistent launch has not
@@ -747,19 +748,25 @@ static int persistent_slot(hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -1;
     MegaSlots& m = g_mega_slots[dev];
     while (m.busy.test_and_set(std::memory_order_acquire)) {}
+    // The slot is RESERVED here, under the lock (pending = true, stream = s), and reservations count like launches in flight: two
+    // host threads on different streams cannot both see "three others" and both take the same spare slot (the event of the second
+    // would then overwrite the first's and leave a launch untracked -- exactly in the multi-stream case the bound exists for).
     int mine = -1, spare = -1, others = 0;
     for (int i = 0; i < MegaSlots::MEGA_TRACKED; ++i) {
-        if (m.used[i] && m.stream[i] == s) { mine = i; continue; }
-        if (m.used[i] && hipEventQuery(m.ev[i]) == hipSuccess) m.used[i] = false;     // that stream's last launch has finished
-        if (m.used[i]) ++others;
+        if ((m.used[i] || m.pending[i]) && m.stream[i] == s) { mine = i; continue; }
+        if (m.used[i] && !m.pending[i] && hipEventQuery(m.ev[i]) == hipSuccess) m.used[i] = false;   // that stream's last launch has finished
+        if (m.used[i] || m.pending[i]) ++others;
         else if (spare < 0) spare = i;
     }
     int slot = mine >= 0 ? mine : spare;
     if (others >= MEGA_MAX_IN_FLIGHT || slot < 0) slot = -1;
     else if (!m.ev[slot] && hipEventCreateWithFlags(&m.ev[slot], hipEventDisableTiming) != hipSuccess) slot = -1;
+    if (slot >= 0) { m.pending[slot] = true; m.stream[slot] = s; }
     m.busy.clear(std::memory_order_release);
     return slot;
 }
+// after the launch: record its completion event and turn the reservation into a tracked launch (a failed record drops the
+// reservation; a slot that tracked an earlier launch of the stream keeps tracking that one)
 static void persistent_launched(int slot, hipStream_t s) {
     if (slot < 0) return;
     int dev = 0;
@@ -767,6 +774,7 @@ static void persistent_launched(int slot, hipStream_t s) {
     MegaSlots& m = g_mega_slots[dev];
     while (m.busy.test_and_set(std::memory_order_acquire)) {}
     if (hipEventRecord(m.ev[slot], s) == hipSuccess) { m.used[slot] = true; m.stream[slot] = s; }
+    m.pending[slot] = false;
     m.busy.clear(std::memory_order_release);
 }
 
@@ -774,7 +782,7 @@ static void persistent_launched(int slot, hipStream_t s) {
 void persistent_forget() {
     for (MegaSlots& m : g_mega_slots) {
         while (m.busy.test_and_set(std::memory_order_acquire)) {}
-        for (int i = 0; i < MegaSlots::MEGA_TRACKED; ++i) { m.used[i] = false; m.ev[i] = nullptr; m.stream[i] = nullptr; }
+        for (int i = 0; i < MegaSlots::MEGA_TRACKED; ++i) { m.used[i] = false; m.pending[i] = false; m.ev[i] = nullptr; m.stream[i] = nullptr; }
         m.busy.clear(std::memory_order_release);
     }
 }

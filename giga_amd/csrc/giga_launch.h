@@ -9,6 +9,11 @@
 
 namespace giga {
 extern std::atomic<unsigned long long> g_launch_count;      // defined in giga_capi.hip
+// measurement hook (giga_launch_probe): bracket the launch whose ordinal (value of g_launch_count after it is counted) equals
+// g_probe_target with two HIP events on the launch's own stream, and remember the kernel expression as written at the launch site
+extern std::atomic<unsigned long long> g_probe_target;      // 0 = no probe armed
+extern void* g_probe_ev[2];
+extern const char* volatile g_probe_name;
 }
 namespace giga {
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) ONCE per (kernel, device) instead of before every launch: the call takes a
@@ -48,5 +53,18 @@ inline void dyn_lds_forget() {
     for (unsigned i = 0; i < DYN_LDS_SLOTS; ++i) g_dyn_lds_vals[i].store(0, std::memory_order_relaxed);
 }
 }  // namespace giga
-#define GIGA_LAUNCH(...) \
-    do { ::giga::g_launch_count.fetch_add(1, std::memory_order_relaxed); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+#define GIGA_LAUNCH_ARG1(a, ...) a
+#define GIGA_LAUNCH_ARG5(a, b, c, d, e, ...) e
+#define GIGA_LAUNCH(...)                                                                                                       \
+    do {                                                                                                                       \
+        const unsigned long long giga_n_ = ::giga::g_launch_count.fetch_add(1, std::memory_order_relaxed) + 1;                  \
+        const bool giga_pr_ = giga_n_ == ::giga::g_probe_target.load(std::memory_order_relaxed);                               \
+        if (giga_pr_) {                                                                                                        \
+            ::giga::g_probe_name = GIGA_LAUNCH_STR(GIGA_LAUNCH_ARG1(__VA_ARGS__));                                              \
+            (void)hipEventRecord(static_cast<hipEvent_t>(::giga::g_probe_ev[0]), GIGA_LAUNCH_ARG5(__VA_ARGS__));               \
+        }                                                                                                                      \
+        hipLaunchKernelGGL(__VA_ARGS__);                                                                                       \
+        if (giga_pr_) (void)hipEventRecord(static_cast<hipEvent_t>(::giga::g_probe_ev[1]), GIGA_LAUNCH_ARG5(__VA_ARGS__));     \
+    } while (0)
+#define GIGA_LAUNCH_STR2(x) #x
+#define GIGA_LAUNCH_STR(x) GIGA_LAUNCH_STR2(x)

@@ -297,6 +297,12 @@ int giga_grasp_select(const float* tsdf, const float* qual, const float* rot, co
 /* Number of kernel launches the library has enqueued in this process so far (all streams): the difference around a call is
  * that call's launch count.  Diagnostic only. */
 unsigned long long giga_launch_count(void);
+/* Measurement hook for ANY launch of the library (bench.py: the kernels of the training step): the launch whose ordinal -- the value
+ * giga_launch_count() returns right after it was enqueued -- equals `ordinal` is bracketed by ev_start / ev_stop (giga_event_create)
+ * on the stream it is launched on; giga_launch_probe_name() then returns the kernel expression of that launch site.  ordinal 0
+ * disarms.  One probe per process; not for concurrent use from several host threads. */
+int giga_launch_probe(unsigned long long ordinal, void* ev_start, void* ev_stop);
+const char* giga_launch_probe_name(void);
 /* The library's per-device bookkeeping -- which kernels have had their dynamic-LDS limit raised, which streams have a persistent
  * U-Net launch in flight -- outlives a hipDeviceReset(), the state it describes does not.  A host that resets a device calls this
  * before its next call into the library (no GPU work is enqueued; safe to call at any time when no call is in progress). */
