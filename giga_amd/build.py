@@ -45,7 +45,7 @@ def build(force=False, verbose=False):
     # of the f16 chains' VALU instructions, the read rate of a layer-to-layer hand-off through one XCD's L2
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     tools = os.path.join(os.path.dirname(HERE), "tools")
-    for name in ("mfma_peak", "mfma_valu_overlap", "mfma_issue_cost", "xcd_barrier", "mfma_denorm", "valu_f16_cost", "l2_handoff", "l2_atomic_rate"):
+    for name in ("mfma_peak", "mfma_valu_overlap", "mfma_issue_cost", "xcd_barrier", "mfma_denorm", "valu_f16_cost", "l2_handoff", "l2_atomic_rate", "tr16_probe"):
         src, out = os.path.join(tools, name + ".hip"), os.path.join(HERE, "lib", name)
         if os.path.exists(src) and (force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src)):
             r = subprocess.run([hipcc, "-O2", "--offload-arch=gfx950", src, "-o", out], capture_output=not verbose, text=True)

@@ -60,7 +60,9 @@ inline void dyn_lds_forget() {
         const unsigned long long giga_n_ = ::giga::g_launch_count.fetch_add(1, std::memory_order_relaxed) + 1;                  \
         const bool giga_pr_ = giga_n_ == ::giga::g_probe_target.load(std::memory_order_relaxed);                               \
         if (giga_pr_) {                                                                                                        \
-            ::giga::g_probe_name = GIGA_LAUNCH_STR(GIGA_LAUNCH_ARG1(__VA_ARGS__));                                              \
+            const char* giga_nm_ = hipKernelNameRefByPtr(reinterpret_cast<const void*>(GIGA_LAUNCH_ARG1(__VA_ARGS__)),           \
+                                                         GIGA_LAUNCH_ARG5(__VA_ARGS__));                                      \
+            ::giga::g_probe_name = giga_nm_ ? giga_nm_ : GIGA_LAUNCH_STR(GIGA_LAUNCH_ARG1(__VA_ARGS__));                        \
             (void)hipEventRecord(static_cast<hipEvent_t>(::giga::g_probe_ev[0]), GIGA_LAUNCH_ARG5(__VA_ARGS__));               \
         }                                                                                                                      \
         hipLaunchKernelGGL(__VA_ARGS__);                                                                                       \
