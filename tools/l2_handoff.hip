@@ -60,7 +60,21 @@ __global__ __launch_bounds__(NT) void k(unsigned* cnt, unsigned* tickets, u32x4*
                 bad += junk == 0xFFFFFFFEu;
             }
         }
-        if (pre_stride < 0) {
+        if (pre_stride == -2 || pre_stride == -3) {
+            // the same with device-scope (sc1) loads, which must not leave a copy in this CU's vector L1; -3: issued by the CONSUMER
+            // for the region it will read (the question: does its later plain read see stale data? -> "wrong values")
+            const u32x4* tgt = pre_stride == -2 ? mine : theirs;
+            u32x4 junk[IT];
+#pragma unroll
+            for (int i = 0; i < IT; ++i) junk[i] = ld16<2>(tgt + i * NT + threadIdx.x);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < IT; ++i) asm volatile("" : "+v"(junk[i]));
+#pragma unroll
+            for (int i = 0; i < IT; ++i) bad += junk[i].w == 0xFFFFFFFEu;
+            if (pre_stride == -3) __syncthreads();
+        }
+        if (pre_stride == -1) {
             // write-allocate by hand: the PRODUCER reads the whole region it is about to write (stale values, discarded), so that its
             // stores hit lines that are already in the L2
             u32x4 junk[IT];
@@ -162,6 +176,8 @@ int main(int argc, char** argv) {
             run<0, 0>("fresh + translation prefetch every 4 KiB", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 0, 0, 4096);
             run<0, 0>("fresh, producer READS its region before writing", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 0, 0, -1);
             run<0, 4>("fresh, producer reads first / consumer load nt", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 0, 0, -1);
+            run<0, 0>("fresh, producer reads first with sc1 loads", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 0, 0, -2);
+            run<0, 0>("fresh, CONSUMER pre-reads with sc1 loads", cnt, tickets, rec, cold, clocks, bad, readers, 0, 0, 0, 0, -3);
         }
         return 0;
     }
