@@ -17,6 +17,7 @@ int pack_bwd_map_host(int head_present, int32_t* map, size_t nwords);
 // giga_encoder_bwd.hip / giga_decoder_bwd.hip
 struct BwdWs { size_t gA6, gA5, gC1, gA4, gA3, gC0, gS2, gA2, gQ1, gS1, gA1, gQ0, gS0, gA0, gP0, WG, total; };
 BwdWs enc_bwd_workspace(int B);
+constexpr size_t ENC_BWD_SYNC_BYTES = 8192;        // behind BwdWs::total: the counters of the persistent data-gradient kernel (giga_bwd_mega.h)
 void persistent_forget();
 int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws,
                             float* gplanes, uint8_t* gws, float* grads, int head_present, int B, hipStream_t s, bool bf16_convs);
@@ -365,7 +366,7 @@ static size_t train_dec_scratch_bytes(int B, int N, int M, int head_present) {
 size_t giga_backward_workspace_bytes(int B, int N, int M, int head_present) {
     if (B <= 0) return 0;
     head_present &= 15;
-    return align_up((size_t)3 * B * RES * RES * CD * sizeof(float), 256) + enc_bwd_workspace(B).total +
+    return align_up((size_t)3 * B * RES * RES * CD * sizeof(float), 256) + enc_bwd_workspace(B).total + ENC_BWD_SYNC_BYTES +
            train_dec_scratch_bytes(B, N, M, head_present);
 }
 
@@ -404,7 +405,7 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
     const size_t gp_bytes = align_up((size_t)3 * B * RES * RES * CD * sizeof(float), 256);
     float* gplanes = reinterpret_cast<float*>(ws);
     uint8_t* gws = ws + gp_bytes;
-    float* scratch = reinterpret_cast<float*>(gws + enc_bwd_workspace(B).total);
+    float* scratch = reinterpret_cast<float*>(gws + enc_bwd_workspace(B).total + ENC_BWD_SYNC_BYTES);
     const uint8_t* blob = static_cast<const uint8_t*>(packed);
     const uint8_t* bblob = static_cast<const uint8_t*>(bwd_packed);
     const bool occ_runs = (head_present & 8) && M > 0 && p_tsdf;

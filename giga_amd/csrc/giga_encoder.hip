@@ -13,6 +13,7 @@
 #include "giga_dev.h"
 #include "giga_conv16.h"
 #include "giga_conv32.h"
+#include "giga_bwd_mega.h"
 #include "giga_args.h"
 
 namespace giga {
@@ -392,7 +393,6 @@ __global__ void plane_finalize_kernel(const float* __restrict__ xz_partial, cons
 // ----------------------------------------------------------------------------------------------------
 // x-parts of conv_in+project: 1 (8*B workgroups, five slices per wave) from 32 scenes up, else 5 (40*B workgroups)
 int enc_nxp(int B) { return B >= 32 ? 1 : 5; }
-constexpr int MEGA_SYNC_WORDS = (8 + 32) * 32;    // barrier words of the persistent U-Net kernel: 8 per-XCD + 32 per-group counters, 128 B apart
 
 EncWs enc_workspace(int B, int precision) {
     const size_t es = precision == 1 ? 2 : 4;
@@ -637,6 +637,105 @@ __global__ __launch_bounds__((MEGA_NW + 1) * 64) void unet_mega_kernel(MegaArgs 
 }
 
 // ----------------------------------------------------------------------------------------------------
+// The DATA-GRADIENT chain of the U-Net (training backward, giga_encoder_bwd.hip) as ONE persistent launch with the forward's launch
+// structure: thirteen data-gradient convolutions (conv16 with the flipped / transposed fragments of the backward blob; the ReLU mask
+// of the layer below applied in the epilogue) and the two max-pool + skip-concat backward passes as stages of one kernel -- groups
+// of 8 workgroups placed by ticket inside one XCD, a group walks its share of the 3B images through all fifteen stages with a
+// barrier among those 8 only.  Replaces 13 + 2 launches (181 + 23 us at 32 scenes in the bf16 step).  The weight gradients, which
+// need only what this chain leaves in memory, run after it.
+// Stage order: L12 L11 L10 L9 L8 L7 L6 L5 L4 pool1 L3 L2 pool0 L1 L0  (reference encoder/unet.py:225-239 reversed).
+// ----------------------------------------------------------------------------------------------------
+#define GIGA_UNET_BWD_STAGES(X, P)                       \
+    X(0, CONV1, 32, 0, 32, 40, 40, 2)                    \
+    X(1, CONV3, 32, 0, 32, 40, 40, 2)                    \
+    X(2, CONV3, 32, 0, 64, 40, 40, 2)                    \
+    X(3, DOWN, 32, 0, 64, 20, 20, 2)                     \
+    X(4, CONV3, 64, 0, 64, 20, 20, 1)                    \
+    X(5, CONV3, 64, 0, 128, 20, 20, 1)                   \
+    X(6, DOWN, 64, 0, 128, 10, 10, 1)                    \
+    X(7, CONV3, 128, 0, 128, 10, 10, 1)                  \
+    X(8, CONV3, 128, 0, 64, 10, 10, 1)                   \
+    P(0)                                                 \
+    X(9, CONV3, 64, 0, 64, 20, 20, 1)                    \
+    X(10, CONV3, 64, 0, 32, 20, 20, 2)                   \
+    P(1)                                                 \
+    X(11, CONV3, 32, 0, 32, 40, 40, 2)                   \
+    X(12, CONV3, 32, 0, 32, 40, 40, 2)
+template <int MATH>
+constexpr size_t bwd_mega_lds_bytes() {
+    size_t m = 0;
+#define X(k, KIND, C0, C1, COUT, H, W, NB) { constexpr size_t v = conv_lds_bytes<float, KIND, C0, C1, COUT, H, W, NB, MATH>(); m = v > m ? v : m; }
+#define P(k)
+    GIGA_UNET_BWD_STAGES(X, P)
+#undef X
+#undef P
+    return m;
+}
+// the pool stage for the images [img0, img0 + per) of a group, dealt over the group's threads (one thread per four channels)
+__device__ __forceinline__ void bwd_pool_stage(const BwdPool& p, int img0, int per, int block, int nblocks) {
+    const int C4 = p.C >> 2;
+    const unsigned total = (unsigned)per * p.H * p.W * C4;
+    for (unsigned i = (unsigned)block * blockDim.x + threadIdx.x; i < total; i += (unsigned)nblocks * blockDim.x) {
+        const int c = 4 * (int)(i % C4);
+        const unsigned pl = i / C4;                                            // pixel inside the group's images
+        const int x = (int)(pl % p.W), y = (int)((pl / p.W) % p.H);
+        const size_t img = (size_t)img0 + pl / ((unsigned)p.W * p.H);
+        const size_t pix = (size_t)img0 * p.H * p.W + pl;
+        const size_t qi = ((img * (p.H / 2) + y / 2) * (p.W / 2) + x / 2) * p.C + c;
+        const float4 s4 = *reinterpret_cast<const float4*>(p.S + pix * p.C + c);
+        const float4 d = *reinterpret_cast<const float4*>(p.dcat + pix * p.cs + p.coff + c);
+        const float4 q = *reinterpret_cast<const float4*>(p.Q + qi);
+        const float4 g = *reinterpret_cast<const float4*>(p.dQ + qi);
+        float4 o;
+        o.x = s4.x > 0.f ? d.x + (s4.x == q.x ? g.x : 0.f) : 0.f;
+        o.y = s4.y > 0.f ? d.y + (s4.y == q.y ? g.y : 0.f) : 0.f;
+        o.z = s4.z > 0.f ? d.z + (s4.z == q.z ? g.z : 0.f) : 0.f;
+        o.w = s4.w > 0.f ? d.w + (s4.w == q.w ? g.w : 0.f) : 0.f;
+        *reinterpret_cast<float4*>(p.dS + pix * p.C + c) = o;
+    }
+}
+template <int MATH>
+__global__ __launch_bounds__(MEGA_NW * 64) void unet_dgrad_mega_kernel(BwdMegaArgs m) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ unsigned s_place[2];                    // placement by ticket: see unet_mega_kernel
+    if (threadIdx.x == 0) {
+        const unsigned xcc = (unsigned)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7);
+        s_place[0] = xcc;
+        s_place[1] = __hip_atomic_fetch_add(m.sync + xcc * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    const int xcd = (int)s_place[0], ticket = (int)s_place[1];
+    const int nq = (int)gridDim.x >> 3, slot = ticket / MEGA_GROUP, q = slot * 8 + xcd, nimg = m.layer[0].nimg;
+    if (slot >= nq >> 3) return;
+    const int img0 = (q * nimg + nq - 1) / nq, per = ((q + 1) * nimg + nq - 1) / nq - img0;
+    if (per == 0) return;
+    const int block = ticket - slot * MEGA_GROUP, nblocks = MEGA_GROUP;
+    unsigned* counter = m.sync + (8 + q) * 32;
+    unsigned epoch = 0;
+    // X(k): [group barrier; stage k's weights stream into LDS while it is waited for] run the stage; the stores are acknowledged and
+    // every wave has left the weights.  P(k): group barrier, the pool pass, stores acknowledged.
+#define X(k, KIND, C0, C1, COUT, H, W, NB)                                                                                  \
+    {                                                                                                                       \
+        const ConvArgs a = conv_image_range<float, KIND, C0, C1, COUT, H, W>(m.layer[k], img0, per);                        \
+        conv16_fill<float, KIND, C0, C1, COUT, NB, MATH>(a, smem, block, nblocks);                                          \
+        if (k > 0) xcd_barrier(counter, ++epoch * (unsigned)nblocks, k, -1);                                                \
+        conv16_run<float, KIND, C0, C1, COUT, H, W, NB, false, false, MATH>(a, smem, block, nblocks);                       \
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                                                                 \
+        __syncthreads();                                                                                                    \
+    }
+#define P(k)                                                                                                                \
+    {                                                                                                                       \
+        xcd_barrier(counter, ++epoch * (unsigned)nblocks, 13 + k, -1);                                                      \
+        bwd_pool_stage(m.pool[k], img0, per, block, nblocks);                                                               \
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                                                                 \
+        __syncthreads();                                                                                                    \
+    }
+    GIGA_UNET_BWD_STAGES(X, P)
+#undef X
+#undef P
+}
+
+// ----------------------------------------------------------------------------------------------------
 // The f16-class U-Net on conv32 (giga_conv32.h): the same persistent launch -- groups of 8 workgroups placed by ticket inside one
 // XCD, a barrier among those 8 per layer -- but a member of a group owns an eighth of the ROWS of the group's stacked images
 // (all output channels), keeps its sub-band of the layer's input resident in LDS and its weights in registers.  4 waves of up to
@@ -797,6 +896,38 @@ void persistent_forget() {
         for (int i = 0; i < MegaSlots::MEGA_TRACKED; ++i) { m.used[i] = false; m.pending[i] = false; m.ev[i] = nullptr; m.stream[i] = nullptr; }
         m.busy.clear(std::memory_order_release);
     }
+}
+
+// The data-gradient chain as one persistent launch (unet_dgrad_mega_kernel).  Returns 1 if it was launched, 0 if the persistent form
+// is not to be used for this call (small batch, partitioned device, GIGA_UNET_PERSIST=0, four persistent launches already in flight
+// on other streams): the caller then issues one launch per stage.  `sync`: MEGA_SYNC_WORDS words of scratch, zeroed here.
+int launch_unet_dgrad_mega(BwdMegaArgs m, bool bf16, hipStream_t s) {
+    static const int env_persist = [] { const char* e = getenv("GIGA_UNET_PERSIST"); return e ? atoi(e) : -1; }();
+    const int nimg = m.layer[0].nimg;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (cus != 256 || env_persist == 0 || (env_persist < 0 && nimg < 24)) return 0;
+    const int slot = persistent_slot(s);
+    if (slot == -1) return 0;
+    for (int k = 0; k < 13; ++k) m.layer[k].xcd_local = 0;                    // (the kernel hands every group its images itself)
+    if (hipMemsetAsync(m.sync, 0, MEGA_SYNC_WORDS * sizeof(unsigned), s) != hipSuccess) { persistent_launched(slot, s); return -10; }
+    const int slots = (nimg + 7) / 8 < MEGA_SLOTS ? (nimg + 7) / 8 : MEGA_SLOTS;
+    const unsigned grid = 8u * (unsigned)slots * MEGA_GROUP;
+    if (bf16) {
+        constexpr size_t lds = bwd_mega_lds_bytes<MATH_BF16>();
+        static_assert(lds <= 160 * 1024, "LDS budget of the persistent data-gradient kernel");
+        auto kern = unet_dgrad_mega_kernel<MATH_BF16>;
+        giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
+        GIGA_LAUNCH(kern, dim3(grid), dim3(MEGA_NW * 64), lds, s, m);
+    } else {
+        constexpr size_t lds = bwd_mega_lds_bytes<MATH_NATIVE>();
+        static_assert(lds <= 160 * 1024, "LDS budget of the persistent data-gradient kernel");
+        auto kern = unet_dgrad_mega_kernel<MATH_NATIVE>;
+        giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
+        GIGA_LAUNCH(kern, dim3(grid), dim3(MEGA_NW * 64), lds, s, m);
+    }
+    persistent_launched(slot, s);
+    return hipGetLastError() == hipSuccess ? 1 : -10;
 }
 
 // probe: if probe_stage == k, ev0/ev1 (hipEvent_t) are recorded right before / after launch k

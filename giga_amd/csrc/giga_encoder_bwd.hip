@@ -10,6 +10,7 @@
 // Weight/bias gradients are ACCUMULATED into the flat fp32 gradient buffer (reference state-dict order) with
 // fp32 atomics (summation order is not fixed, as with PyTorch's own CUDA/HIP backward kernels).
 #include "giga_conv16.h"
+#include "giga_bwd_mega.h"
 #include "giga_args.h"
 
 namespace giga {
@@ -1051,7 +1052,7 @@ __global__ __launch_bounds__(256) void convin_bwd_reduce_kernel(const float* __r
 
 // ------------------------------- driver -----------------------------------------------------------------------
 // forward activations: the encoder workspace (giga_encoder.hip::EncWs, fp32).  Gradient workspace carve:
-struct BwdWs { size_t gA6, gA5, gC1, gA4, gA3, gC0, gS2, gA2, gQ1, gS1, gA1, gQ0, gS0, gA0, gP0, WG, total; };
+struct BwdWs { size_t gA6, gA5, gC1, gA4, gA3, gC0, gS2, gA2, gQ1, gS1, gA1, gQ0, gS0, gA0, gP0, WG, total; };   // (+ SYNC: behind WG, see enc_bwd_sync_offset)
 BwdWs enc_bwd_workspace(int B) {
     const size_t n = 3 * (size_t)B;
     BwdWs w{};
@@ -1063,7 +1064,7 @@ BwdWs enc_bwd_workspace(int B) {
     w.gS1 = take(n * 400 * 64);  w.gA1 = take(n * 400 * 64);  w.gQ0 = take(n * 400 * 32);
     w.gS0 = take(n * 1600 * 32); w.gA0 = take(n * 1600 * 32); w.gP0 = take(n * 1600 * 32);
     w.WG = take((size_t)WG3_MAX_PARTS * 32 * 288 + WG3_BIAS_FLOATS);      // per-workgroup weight-gradient partials (conv3_wgrad_kernel)
-    w.total = at;
+    w.total = at;                                  // (+ MEGA_SYNC_WORDS words behind it: the persistent data-gradient kernel's counters)
     return w;
 }
 
@@ -1141,57 +1142,88 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
     };
     const size_t n40 = (size_t)nimg * 1600, n20 = (size_t)nimg * 400, n10 = (size_t)nimg * 100;
 
-    // L12 conv_final (1x1, no activation): gplanes = dOUT
-    wgrad3(12, gplanes, F(f.A6), nullptr, 40);
-    rc |= launch_conv<float, CONV1, 32, 0, 32, 40, 40, 2, false, false, MATH>(dgrad_args(12, gplanes, 0, G(g.gA6), F(f.A6)), s);
-    // L11 up1.conv2: A5 -> A6
-    wgrad3(11, G(g.gA6), F(f.A5), nullptr, 40);
-    rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(dgrad_args(11, G(g.gA6), 0, G(g.gA5), F(f.A5)), s);
-    // L10 up1.conv1: cat(U1, S0) -> A5 ; dgrad output has 64 channels (dU1 | dS0 skip part)
-    wgrad3(10, G(g.gA5), F(f.U1), F(f.S0), 40);
-    rc |= launch_conv<float, CONV3, 32, 0, 64, 40, 40, 2, false, false, MATH>(dgrad_args(10, G(g.gA5), 0, G(g.gC1)), s);
-    // L9 up1.upconv: A4 (20x20x64) -> U1 (40x40x32); dU1 = gC1[..., 0:32]
-    wgrad_up(9, F(f.A4), G(g.gC1), 64, 20);
-    rc |= launch_conv<float, DOWN, 32, 0, 64, 20, 20, 2, false, false, MATH>(dgrad_args(9, G(g.gC1), 64, G(g.gA4), F(f.A4)), s);
-    // L8 up0.conv2: A3 -> A4
-    wgrad3(8, G(g.gA4), F(f.A3), nullptr, 20);
-    rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false, MATH>(dgrad_args(8, G(g.gA4), 0, G(g.gA3), F(f.A3)), s);
-    // L7 up0.conv1: cat(U0, S1) -> A3 ; dgrad output 128 channels
-    wgrad3(7, G(g.gA3), F(f.U0), F(f.S1), 20);
-    rc |= launch_conv<float, CONV3, 64, 0, 128, 20, 20, 1, false, false, MATH>(dgrad_args(7, G(g.gA3), 0, G(g.gC0)), s);
-    // L6 up0.upconv: S2 (10x10x128) -> U0 (20x20x64); dU0 = gC0[..., 0:64]
-    wgrad_up(6, F(f.S2), G(g.gC0), 128, 10);
-    rc |= launch_conv<float, DOWN, 64, 0, 128, 10, 10, 1, false, false, MATH>(dgrad_args(6, G(g.gC0), 128, G(g.gS2), F(f.S2)), s);
-    // L5 down2.conv2: A2 -> S2
-    wgrad3(5, G(g.gS2), F(f.A2), nullptr, 10);
-    rc |= launch_conv<float, CONV3, 128, 0, 128, 10, 10, 1, false, false, MATH>(dgrad_args(5, G(g.gS2), 0, G(g.gA2), F(f.A2)), s);
-    // L4 down2.conv1: Q1 -> A2
-    wgrad3(4, G(g.gA2), F(f.Q1), nullptr, 10);
-    rc |= launch_conv<float, CONV3, 128, 0, 64, 10, 10, 1, false, false, MATH>(dgrad_args(4, G(g.gA2), 0, G(g.gQ1)), s);
-    // pool1 + skip: dS1 = gC0[..., 64:128] + unpool(dQ1)
-    {
-        const size_t tot = n20 * 64 / 4;
-        GIGA_LAUNCH(pool_bwd_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, G(g.gS1),
-                           G(g.gC0), 128, 64, G(g.gQ1), F(f.S1), F(f.Q1), nimg, 20, 20, 64);
+    // ---- the data-gradient chain.  Stage order L12 L11 L10 L9 L8 L7 L6 L5 L4 [pool1] L3 L2 [pool0] L1 L0: one launch per stage, or
+    // ONE persistent launch (unet_dgrad_mega_kernel, giga_encoder.hip).
+    BwdMegaArgs M{};
+    M.layer[0] = dgrad_args(12, gplanes, 0, G(g.gA6), F(f.A6));          // L12 conv_final (1x1, no activation): gplanes = dOUT
+    M.layer[1] = dgrad_args(11, G(g.gA6), 0, G(g.gA5), F(f.A5));         // L11 up1.conv2: A5 -> A6
+    M.layer[2] = dgrad_args(10, G(g.gA5), 0, G(g.gC1));                  // L10 up1.conv1: cat(U1, S0) -> A5; 64 channels out (dU1 | dS0 skip part)
+    M.layer[3] = dgrad_args(9, G(g.gC1), 64, G(g.gA4), F(f.A4));         // L9 up1.upconv: A4 (20x20x64) -> U1; dU1 = gC1[..., 0:32]
+    M.layer[4] = dgrad_args(8, G(g.gA4), 0, G(g.gA3), F(f.A3));          // L8 up0.conv2: A3 -> A4
+    M.layer[5] = dgrad_args(7, G(g.gA3), 0, G(g.gC0));                   // L7 up0.conv1: cat(U0, S1) -> A3; 128 channels out
+    M.layer[6] = dgrad_args(6, G(g.gC0), 128, G(g.gS2), F(f.S2));        // L6 up0.upconv: S2 (10x10x128) -> U0; dU0 = gC0[..., 0:64]
+    M.layer[7] = dgrad_args(5, G(g.gS2), 0, G(g.gA2), F(f.A2));          // L5 down2.conv2: A2 -> S2
+    M.layer[8] = dgrad_args(4, G(g.gA2), 0, G(g.gQ1));                   // L4 down2.conv1: Q1 -> A2
+    M.pool[0] = BwdPool{G(g.gS1), G(g.gC0), G(g.gQ1), F(f.S1), F(f.Q1), 128, 64, 20, 20, 64};   // dS1 = gC0[..., 64:128] + unpool(dQ1)
+    M.layer[9] = dgrad_args(3, G(g.gS1), 0, G(g.gA1), F(f.A1));          // L3 down1.conv2: A1 -> S1
+    M.layer[10] = dgrad_args(2, G(g.gA1), 0, G(g.gQ0));                  // L2 down1.conv1: Q0 -> A1
+    M.pool[1] = BwdPool{G(g.gS0), G(g.gC1), G(g.gQ0), F(f.S0), F(f.Q0), 64, 32, 40, 40, 32};    // dS0 = gC1[..., 32:64] + unpool(dQ0)
+    M.layer[11] = dgrad_args(1, G(g.gS0), 0, G(g.gA0), F(f.A0));         // L1 down0.conv2: A0 -> S0
+    M.layer[12] = dgrad_args(0, G(g.gA0), 0, G(g.gP0));                  // L0 down0.conv1: P0 -> A0
+    M.sync = reinterpret_cast<unsigned*>(gws + g.total);                  // (behind the workspace proper: enc_bwd_workspace_bytes)
+    // The persistent form is an OPT-IN (GIGA_DGRAD_PERSIST=1): measured at 32 scenes it is SLOWER than the fifteen launches it replaces
+    // (bf16 step 1.016 -> 1.057 ms, fp32 1.824 -> 1.849: the kernel takes 212 us against 194 us for the separate launches, whose
+    // dispatch the queue already hides behind the previous kernel's tail, and fifteen group barriers are not free; the weight gradients,
+    // pushed behind the whole chain, find their dY further down the cache hierarchy: +1-2 us each).  profiles/r05/dgrad_mega.txt
+    static const int env_dgrad_persist = [] { const char* e = getenv("GIGA_DGRAD_PERSIST"); return e ? atoi(e) : 0; }();
+    const int mega = env_dgrad_persist ? launch_unet_dgrad_mega(M, MATH == MATH_BF16, s) : 0;
+    if (mega < 0) rc |= mega;
+    if (mega > 0) {
+        // the weight gradients: every one needs only what the chain has left in memory (dPre of its layer, mask applied) and the
+        // forward's activations
+        wgrad3(12, gplanes, F(f.A6), nullptr, 40);
+        wgrad3(11, G(g.gA6), F(f.A5), nullptr, 40);
+        wgrad3(10, G(g.gA5), F(f.U1), F(f.S0), 40);
+        wgrad_up(9, F(f.A4), G(g.gC1), 64, 20);
+        wgrad3(8, G(g.gA4), F(f.A3), nullptr, 20);
+        wgrad3(7, G(g.gA3), F(f.U0), F(f.S1), 20);
+        wgrad_up(6, F(f.S2), G(g.gC0), 128, 10);
+        wgrad3(5, G(g.gS2), F(f.A2), nullptr, 10);
+        wgrad3(4, G(g.gA2), F(f.Q1), nullptr, 10);
+        wgrad3(3, G(g.gS1), F(f.A1), nullptr, 20);
+        wgrad3(2, G(g.gA1), F(f.Q0), nullptr, 20);
+        wgrad3(1, G(g.gS0), F(f.A0), nullptr, 40);
+        wgrad3(0, G(g.gA0), F(f.P0), nullptr, 40);
+    } else {
+        // one launch per stage, the weight gradient of a layer right behind the launch that produced its dPre (it is still in the
+        // Infinity Cache then)
+        wgrad3(12, gplanes, F(f.A6), nullptr, 40);
+        rc |= launch_conv<float, CONV1, 32, 0, 32, 40, 40, 2, false, false, MATH>(M.layer[0], s);
+        wgrad3(11, G(g.gA6), F(f.A5), nullptr, 40);
+        rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(M.layer[1], s);
+        wgrad3(10, G(g.gA5), F(f.U1), F(f.S0), 40);
+        rc |= launch_conv<float, CONV3, 32, 0, 64, 40, 40, 2, false, false, MATH>(M.layer[2], s);
+        wgrad_up(9, F(f.A4), G(g.gC1), 64, 20);
+        rc |= launch_conv<float, DOWN, 32, 0, 64, 20, 20, 2, false, false, MATH>(M.layer[3], s);
+        wgrad3(8, G(g.gA4), F(f.A3), nullptr, 20);
+        rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false, MATH>(M.layer[4], s);
+        wgrad3(7, G(g.gA3), F(f.U0), F(f.S1), 20);
+        rc |= launch_conv<float, CONV3, 64, 0, 128, 20, 20, 1, false, false, MATH>(M.layer[5], s);
+        wgrad_up(6, F(f.S2), G(g.gC0), 128, 10);
+        rc |= launch_conv<float, DOWN, 64, 0, 128, 10, 10, 1, false, false, MATH>(M.layer[6], s);
+        wgrad3(5, G(g.gS2), F(f.A2), nullptr, 10);
+        rc |= launch_conv<float, CONV3, 128, 0, 128, 10, 10, 1, false, false, MATH>(M.layer[7], s);
+        wgrad3(4, G(g.gA2), F(f.Q1), nullptr, 10);
+        rc |= launch_conv<float, CONV3, 128, 0, 64, 10, 10, 1, false, false, MATH>(M.layer[8], s);
+        {
+            const size_t tot = n20 * 64 / 4;
+            GIGA_LAUNCH(pool_bwd_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, G(g.gS1),
+                               G(g.gC0), 128, 64, G(g.gQ1), F(f.S1), F(f.Q1), nimg, 20, 20, 64);
+        }
+        wgrad3(3, G(g.gS1), F(f.A1), nullptr, 20);
+        rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false, MATH>(M.layer[9], s);
+        wgrad3(2, G(g.gA1), F(f.Q0), nullptr, 20);
+        rc |= launch_conv<float, CONV3, 64, 0, 32, 20, 20, 2, false, false, MATH>(M.layer[10], s);
+        {
+            const size_t tot = n40 * 32 / 4;
+            GIGA_LAUNCH(pool_bwd_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, G(g.gS0),
+                               G(g.gC1), 64, 32, G(g.gQ0), F(f.S0), F(f.Q0), nimg, 40, 40, 32);
+        }
+        wgrad3(1, G(g.gS0), F(f.A0), nullptr, 40);
+        rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(M.layer[11], s);
+        wgrad3(0, G(g.gA0), F(f.P0), nullptr, 40);
+        rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(M.layer[12], s);
     }
-    // L3 down1.conv2: A1 -> S1
-    wgrad3(3, G(g.gS1), F(f.A1), nullptr, 20);
-    rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false, MATH>(dgrad_args(3, G(g.gS1), 0, G(g.gA1), F(f.A1)), s);
-    // L2 down1.conv1: Q0 -> A1
-    wgrad3(2, G(g.gA1), F(f.Q0), nullptr, 20);
-    rc |= launch_conv<float, CONV3, 64, 0, 32, 20, 20, 2, false, false, MATH>(dgrad_args(2, G(g.gA1), 0, G(g.gQ0)), s);
-    // pool0 + skip: dS0 = gC1[..., 32:64] + unpool(dQ0)
-    {
-        const size_t tot = n40 * 32 / 4;
-        GIGA_LAUNCH(pool_bwd_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, G(g.gS0),
-                           G(g.gC1), 64, 32, G(g.gQ0), F(f.S0), F(f.Q0), nimg, 40, 40, 32);
-    }
-    // L1 down0.conv2: A0 -> S0
-    wgrad3(1, G(g.gS0), F(f.A0), nullptr, 40);
-    rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(dgrad_args(1, G(g.gS0), 0, G(g.gA0), F(f.A0)), s);
-    // L0 down0.conv1: P0 -> A0
-    wgrad3(0, G(g.gA0), F(f.P0), nullptr, 40);
-    rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(dgrad_args(0, G(g.gA0), 0, G(g.gP0)), s);
     // conv_in + projection
     {
         const int nxp = enc_nxp(B);
