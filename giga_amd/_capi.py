@@ -43,6 +43,8 @@ _SIGNATURES = {
     "giga_pack_map": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]),
     "giga_repack_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                           ctypes.c_void_p]),
+    "giga_repack_device2": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "giga_encoder_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "giga_encoder_workspace_layout": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "giga_encoder_forward": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,

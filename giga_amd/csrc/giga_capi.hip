@@ -4,6 +4,8 @@
 
 #include "../../include/giga_hip.h"
 #include "giga_layout.h"
+#include "giga_conv32_geom.h"
+#include "giga_dect.h"
 #include "giga_args.h"
 
 namespace giga {
@@ -29,7 +31,6 @@ int launch_decoder_backward(const float* planes, const float* p, const uint8_t* 
 int launch_plane_gather(const float* dcbuf, const float* p, float* gplanes, int B, int N, hipStream_t s);
 // giga_decoder_train16.hip (bf16 decoder of the bf16 training step)
 struct DectPending { const float* partial[NHEADS]; int nwg[NHEADS]; int head_id[NHEADS]; int n; };
-int launch_dect_derive(uint8_t* fwd_blob, uint8_t* bwd_blob, hipStream_t s);
 int launch_dect_forward(const float* planes, const float* p, const uint8_t* blob, int head_mask, float* const* outs, int B, int N,
                         int post, hipStream_t s);
 size_t dect_partial_floats(long long P, int nheads);
@@ -88,10 +89,10 @@ __global__ void repack_kernel(const float* __restrict__ params, const int32_t* _
 // bf16 fragment images (f16 fragment layout: lane (j, g) holds channels 8g..8g+7 of k-group kg32) from the fp32 fragments
 // (lane (j, g') holds channels 4g'..4g'+3 of k-group kg16 = 2*kg32 + h): one workgroup per bf16 fragment.
 struct BfRegions { size_t src[2 * NCONV], dst[2 * NCONV]; int first[2 * NCONV + 1]; int n; };
-__global__ void derive_bf16_kernel(uint8_t* fwd, uint8_t* bwd, BfRegions r) {
+__device__ __forceinline__ void derive_bf16_block(uint8_t* fwd, uint8_t* bwd, const BfRegions& r, int blk) {
     int reg = 0;
-    while (reg + 1 < r.n && (int)blockIdx.x >= r.first[reg + 1]) ++reg;
-    const int i16 = (int)blockIdx.x - r.first[reg], lane = threadIdx.x;
+    while (reg + 1 < r.n && blk >= r.first[reg + 1]) ++reg;
+    const int i16 = blk - r.first[reg], lane = threadIdx.x;
     uint8_t* base = reg < NCONV ? fwd : bwd;
     if (!base) return;
     const float* f32 = reinterpret_cast<const float*>(base + r.src[reg]);
@@ -104,25 +105,93 @@ __global__ void derive_bf16_kernel(uint8_t* fwd, uint8_t* bwd, BfRegions r) {
     }
 }
 
+// bf16 conv32 images (A operands of v_mfma_f32_32x32x16_bf16, giga_pack.cpp: lane (i, hi), element e -> W[32 cs + c32_row_cout(i)][16 kc +
+// 8 hi + e][tap], fragment order [sub][cs][tap][kc]) from the fp32 conv16 fragments of the same layer (lane (j, g), element e ->
+// W[16 nb + j][16 kg + 4 g + e][tap], order [sub][nb][tap][kg]): one workgroup per conv32 fragment.
+struct C32bRegions { size_t src[NCONV], dst[NCONV]; int first[NCONV + 1]; int nbt[NCONV], taps[NCONV], kg[NCONV]; };
+__device__ __forceinline__ void derive_c32b_block(uint8_t* fwd, const C32bRegions& r, int blk) {
+    int l = 0;
+    while (l + 1 < NCONV && blk >= r.first[l + 1]) ++l;
+    const int f = blk - r.first[l], lane = threadIdx.x;
+    const int KG = r.kg[l], TAPS = r.taps[l], NBT = r.nbt[l], CS = NBT / 2;
+    const int kc = f % KG, tap = (f / KG) % TAPS, cs = (f / (KG * TAPS)) % CS, sub = f / (KG * TAPS * CS);
+    const int i = lane & 31, hi = lane >> 5;
+    const int co = 32 * cs + c32_row_cout(i), nb = co >> 4, j = co & 15;
+    const float* f32 = reinterpret_cast<const float*>(fwd + r.src[l]);
+    const size_t i32 = ((size_t)(sub * NBT + nb) * TAPS + tap) * KG + kc;
+    __bf16* out = reinterpret_cast<__bf16*>(fwd + r.dst[l]) + ((size_t)f * 64 + lane) * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int rr = 8 * hi + e;
+        out[e] = (__bf16)f32[(i32 * 64 + (rr >> 2) * 16 + j) * 4 + (rr & 3)];
+    }
+}
+
+constexpr int DECT_DERIVE_BLOCKS = (59 + 51) * NHEADS;
+struct DeriveArgs {
+    BfRegions r; C32bRegions c; int n16, n32;
+    size_t dec32_0, dec32_stride, dectf_0, dectf_stride, decb_0, decb_stride, dectb_0, dectb_stride;
+};
+__global__ __launch_bounds__(64) void derive_all_kernel(uint8_t* fwd, uint8_t* bwd, DeriveArgs d) {
+    const int b = blockIdx.x;
+    if (b < d.n16) derive_bf16_block(fwd, bwd, d.r, b);
+    else if (b < d.n16 + d.n32) derive_c32b_block(fwd, d.c, b - d.n16);
+    else {
+        const int k = b - d.n16 - d.n32;
+        dect_derive_block(fwd, bwd, k % (59 + 51), k / (59 + 51), d.dec32_0, d.dec32_stride, d.dectf_0, d.dectf_stride, d.decb_0,
+                          d.decb_stride, d.dectb_0, d.dectb_stride);
+    }
+}
+__global__ void repack2_kernel(const float* __restrict__ params, const int32_t* __restrict__ map_a, float* __restrict__ words_a, size_t na,
+                               const int32_t* __restrict__ map_b, float* __restrict__ words_b, size_t nb) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t* map = map_a; float* words = words_a;
+    if (i >= na) { i -= na; if (i >= nb) return; map = map_b; words = words_b; }
+    const int m = map[i];
+    if (m >= 0) words[i] = params[m];
+    else if (m == -1) words[i] = 0.f;
+}
+
 extern "C" {
 
 int giga_derive_bf16_fragments(void* packed_dev, void* bwd_packed_dev, void* stream) {
     if (!packed_dev && !bwd_packed_dev) return -1;
     const PackOff ko = pack_offsets();
     const BwdPackOff bo = bwd_pack_offsets();
-    BfRegions r{};
+    DeriveArgs d{};
     int at = 0;
-    for (int l = 0; l < NCONV; ++l) { r.src[l] = ko.conv[l].w32; r.dst[l] = ko.conv[l].wbf; r.first[l] = at; at += ko.conv[l].nfrag16; }
+    for (int l = 0; l < NCONV; ++l) { d.r.src[l] = ko.conv[l].w32; d.r.dst[l] = ko.conv[l].wbf; d.r.first[l] = at; at += ko.conv[l].nfrag16; }
     for (int l = 0; l < NCONV; ++l) {
-        r.src[NCONV + l] = bo.conv[l]; r.dst[NCONV + l] = bo.convbf[l]; r.first[NCONV + l] = at; at += bo.nfrag[l] / 2;
+        d.r.src[NCONV + l] = bo.conv[l]; d.r.dst[NCONV + l] = bo.convbf[l]; d.r.first[NCONV + l] = at; at += bo.nfrag[l] / 2;
     }
-    r.first[2 * NCONV] = at;
-    r.n = 2 * NCONV;
-    GIGA_LAUNCH(derive_bf16_kernel, dim3(at), dim3(64), 0, static_cast<hipStream_t>(stream),
-                       static_cast<uint8_t*>(packed_dev), static_cast<uint8_t*>(bwd_packed_dev), r);
-    if (hipGetLastError() != hipSuccess) return -10;
-    // the bf16 images of the decoder heads (bf16 training decoder, giga_dect.h), from the fp32 head images of the same blobs
-    return launch_dect_derive(static_cast<uint8_t*>(packed_dev), static_cast<uint8_t*>(bwd_packed_dev), static_cast<hipStream_t>(stream));
+    d.r.first[2 * NCONV] = at;
+    d.r.n = 2 * NCONV;
+    d.n16 = at;
+    int n32 = 0;
+    for (int l = 0; l < NCONV; ++l) {
+        const ConvLayerDesc& cd = kConv[l];
+        d.c.src[l] = ko.conv[l].w32; d.c.dst[l] = ko.conv[l].c32b; d.c.first[l] = n32; n32 += ko.conv[l].nfragc32;
+        d.c.nbt[l] = cd.cout / 16; d.c.taps[l] = conv_taps(cd); d.c.kg[l] = (cd.cin0 + cd.cin1) / 16;
+    }
+    d.c.first[NCONV] = n32;
+    d.n32 = packed_dev ? n32 : 0;
+    d.dec32_0 = ko.dec32[0]; d.dec32_stride = ko.dec32[1] - ko.dec32[0]; d.dectf_0 = ko.dect[0]; d.dectf_stride = ko.dect[1] - ko.dect[0];
+    d.decb_0 = bo.dec[0]; d.decb_stride = bo.dec[1] - bo.dec[0]; d.dectb_0 = bo.dect[0]; d.dectb_stride = bo.dect[1] - bo.dect[0];
+    // ONE launch: the bf16 conv16 fragments of both blobs, the bf16 conv32 images, the bf16 decoder images (giga_dect.h)
+    GIGA_LAUNCH(derive_all_kernel, dim3(d.n16 + d.n32 + DECT_DERIVE_BLOCKS), dim3(64), 0, static_cast<hipStream_t>(stream),
+                static_cast<uint8_t*>(packed_dev), static_cast<uint8_t*>(bwd_packed_dev), d);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
+/* both weight images in ONE launch (training: every step) */
+int giga_repack_device2(const float* params_dev, const int32_t* map_fwd_dev, void* packed_dev, size_t nwords_fwd,
+                        const int32_t* map_bwd_dev, void* bwd_packed_dev, size_t nwords_bwd, void* stream) {
+    if (!params_dev || !map_fwd_dev || !packed_dev || !map_bwd_dev || !bwd_packed_dev) return -1;
+    const size_t n = nwords_fwd + nwords_bwd;
+    if (n == 0) return 0;
+    GIGA_LAUNCH(repack2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), params_dev,
+                map_fwd_dev, static_cast<float*>(packed_dev), nwords_fwd, map_bwd_dev, static_cast<float*>(bwd_packed_dev), nwords_bwd);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
 int giga_abi_version(void) { return GIGA_ABI_VERSION; }

@@ -663,63 +663,6 @@ __global__ __launch_bounds__(256) void dect_reduce_kernel(DectReduceArgs a) {
     }
 }
 
-// ------------------------------- bf16 images from the fp32 images of the same blobs ------------------------------------------
-// grid (59 + 51 chunks, NHEADS): chunk < 58 forward fragment, 58 C table, 59 .. 108 backward fragment, 109 Wout
-__global__ __launch_bounds__(64) void dect_derive_kernel(uint8_t* fwd_blob, uint8_t* bwd_blob, size_t dec32_0, size_t dec32_stride,
-                                                         size_t dectf_0, size_t dectf_stride, size_t decb_0, size_t decb_stride,
-                                                         size_t dectb_0, size_t dectb_stride) {
-    const int chunk = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
-    if (chunk < 59) {
-        if (!fwd_blob) return;
-        const float* f = reinterpret_cast<const float*>(fwd_blob + dec32_0 + h * dec32_stride);
-        uint8_t* dst = fwd_blob + dectf_0 + h * dectf_stride + (size_t)chunk * FRAG;
-        if (chunk < DECT_FWD_FRAGS) {
-            uint16_t v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = dect_fwd_elem(f, chunk, lane, j);
-            *reinterpret_cast<uint4*>(dst + lane * 16) = make_uint4(v[0] | (unsigned)v[1] << 16, v[2] | (unsigned)v[3] << 16,
-                                                                    v[4] | (unsigned)v[5] << 16, v[6] | (unsigned)v[7] << 16);
-        } else {
-            const float* ctab = f + (size_t)DEC32_FRAGS * 256;
-            float* oc = reinterpret_cast<float*>(dst);
-            for (int i = lane; i < (NBLK + 1) * CD; i += 64) oc[i] = ctab[i];
-        }
-    } else {
-        if (!bwd_blob) return;
-        const int c2 = chunk - 59;
-        const float* g = reinterpret_cast<const float*>(bwd_blob + decb_0 + h * decb_stride);
-        uint8_t* dst = bwd_blob + dectb_0 + h * dectb_stride + (size_t)c2 * FRAG;
-        if (c2 < DECT_BWD_FRAGS) {
-            uint16_t v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = dect_bwd_elem(g, c2, lane, j);
-            *reinterpret_cast<uint4*>(dst + lane * 16) = make_uint4(v[0] | (unsigned)v[1] << 16, v[2] | (unsigned)v[3] << 16,
-                                                                    v[4] | (unsigned)v[5] << 16, v[6] | (unsigned)v[7] << 16);
-        } else {
-            const float* wout = g + (size_t)DECB_FRAGS * 256;
-            float* ow = reinterpret_cast<float*>(dst);
-            for (int i = lane; i < 4 * CD; i += 64) ow[i] = dect_f(dect_bf(wout[i]));
-        }
-    }
-}
-
-#ifdef GIGA_TRACE
-}  // namespace giga
-extern "C" int giga_debug_dect_trace(long long* host_out) {
-    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(giga::g_dect_trace), sizeof(long long) * 2 * 4 * 40) == hipSuccess ? 0 : -10;
-}
-namespace giga {
-#endif
-
-int launch_dect_derive(uint8_t* fwd_blob, uint8_t* bwd_blob, hipStream_t s) {
-    const PackOff ko = pack_offsets();
-    const BwdPackOff bo = bwd_pack_offsets();
-    GIGA_LAUNCH(dect_derive_kernel, dim3(59 + 51, NHEADS), dim3(64), 0, s, fwd_blob, bwd_blob, ko.dec32[0],
-                ko.dec32[1] - ko.dec32[0], ko.dect[0], ko.dect[1] - ko.dect[0], bo.dec[0], bo.dec[1] - bo.dec[0], bo.dect[0],
-                bo.dect[1] - bo.dect[0]);
-    return hipGetLastError() == hipSuccess ? 0 : -10;
-}
-
 // ------------------------------- launchers ---------------------------------------------------------------------------------------
 static int dect_grid(long long P) {
     const long long tiles = (P + 31) / 32;

@@ -91,4 +91,45 @@ inline void dect_pack_bwd_host(const uint8_t* decb_image, uint8_t* dst) {
     for (int i = 0; i < 4 * CD; ++i) ow[i] = dect_f(dect_bf(wout[i]));
 }
 
+// device: one 64-lane block of giga_capi.hip's derive_all_kernel per 1-KiB chunk of a head's two images:
+// chunk < 58 forward fragment, 58 C table, 59 .. 108 backward fragment, 109 Wout
+__device__ inline void dect_derive_block(uint8_t* fwd_blob, uint8_t* bwd_blob, int chunk, int h, size_t dec32_0, size_t dec32_stride,
+                                  size_t dectf_0, size_t dectf_stride, size_t decb_0, size_t decb_stride, size_t dectb_0,
+                                  size_t dectb_stride) {
+    const int lane = threadIdx.x;
+    if (chunk < 59) {
+        if (!fwd_blob) return;
+        const float* f = reinterpret_cast<const float*>(fwd_blob + dec32_0 + h * dec32_stride);
+        uint8_t* dst = fwd_blob + dectf_0 + h * dectf_stride + (size_t)chunk * FRAG;
+        if (chunk < DECT_FWD_FRAGS) {
+            uint16_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = dect_fwd_elem(f, chunk, lane, j);
+            *reinterpret_cast<uint4*>(dst + lane * 16) = make_uint4(v[0] | (unsigned)v[1] << 16, v[2] | (unsigned)v[3] << 16,
+                                                                    v[4] | (unsigned)v[5] << 16, v[6] | (unsigned)v[7] << 16);
+        } else {
+            const float* ctab = f + (size_t)DEC32_FRAGS * 256;
+            float* oc = reinterpret_cast<float*>(dst);
+            for (int i = lane; i < (NBLK + 1) * CD; i += 64) oc[i] = ctab[i];
+        }
+    } else {
+        if (!bwd_blob) return;
+        const int c2 = chunk - 59;
+        const float* g = reinterpret_cast<const float*>(bwd_blob + decb_0 + h * decb_stride);
+        uint8_t* dst = bwd_blob + dectb_0 + h * dectb_stride + (size_t)c2 * FRAG;
+        if (c2 < DECT_BWD_FRAGS) {
+            uint16_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = dect_bwd_elem(g, c2, lane, j);
+            *reinterpret_cast<uint4*>(dst + lane * 16) = make_uint4(v[0] | (unsigned)v[1] << 16, v[2] | (unsigned)v[3] << 16,
+                                                                    v[4] | (unsigned)v[5] << 16, v[6] | (unsigned)v[7] << 16);
+        } else {
+            const float* wout = g + (size_t)DECB_FRAGS * 256;
+            float* ow = reinterpret_cast<float*>(dst);
+            for (int i = lane; i < 4 * CD; i += 64) ow[i] = dect_f(dect_bf(wout[i]));
+        }
+    }
+}
+
+
 }  // namespace giga

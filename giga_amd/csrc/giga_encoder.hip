@@ -589,12 +589,12 @@ __global__ __launch_bounds__((MEGA_NW + 1) * 64) void unet_mega_kernel(MegaArgs 
     if (l < m.nlayers) {                                                                                                   \
         ConvArgs a = conv_image_range<T, KIND, C0, C1, COUT, H, W>(m.layer[l], img0, per);                                 \
         if (l == 0) conv16_fill<T, KIND, C0, C1, COUT, (sizeof(T) == 2 ? NB16 : NB), MATH>(a, smem, block, nblocks);                \
-        if (m.touch && l + 1 < m.nlayers) {            /* the helper wave reads the lines layer l + 1 will write (conv16_touch) */ \
-            a.touch[0] = reinterpret_cast<const char*>(m.layer[l + 1].out) + (size_t)img0 * m.out_img_bytes[l + 1];        \
-            a.touch_bytes[0] = (unsigned)per * m.out_img_bytes[l + 1];                                                     \
-            if (m.pool_img_bytes[l + 1]) {                                                                                 \
-                a.touch[1] = reinterpret_cast<const char*>(m.layer[l + 1].out_pool) + (size_t)img0 * m.pool_img_bytes[l + 1]; \
-                a.touch_bytes[1] = (unsigned)per * m.pool_img_bytes[l + 1];                                                \
+        if (m.touch && l + 1 < NCONV && l + 1 < m.nlayers) { /* the helper wave reads the lines layer l + 1 will write (conv16_touch) */ \
+            a.touch[0] = reinterpret_cast<const char*>(m.layer[(l + 1) % NCONV].out) + (size_t)img0 * m.out_img_bytes[(l + 1) % NCONV];        \
+            a.touch_bytes[0] = (unsigned)per * m.out_img_bytes[(l + 1) % NCONV];                                                     \
+            if (m.pool_img_bytes[(l + 1) % NCONV]) {                                                                                 \
+                a.touch[1] = reinterpret_cast<const char*>(m.layer[(l + 1) % NCONV].out_pool) + (size_t)img0 * m.pool_img_bytes[(l + 1) % NCONV]; \
+                a.touch_bytes[1] = (unsigned)per * m.pool_img_bytes[(l + 1) % NCONV];                                                \
             }                                                                                                              \
         }                                                                                                                  \
         conv16_run<T, KIND, C0, C1, COUT, H, W, (sizeof(T) == 2 ? NB16 : NB), POOL, KIND == CONV3, MATH>(a, smem, block, nblocks); \
@@ -1034,7 +1034,7 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     // 3-9 % faster up to 32 scenes, but from ~24 scenes on -- every CU busy -- the chip holds a 3-5 % lower shader clock while and after
     // the conv32 launch runs (at LOWER socket power: a current limit), which costs a sustained 32-scene step up to 4 % and a
     // 128-scene step up to 6 % (tools/gpu_sustained_power.py, profiles/r04/final/sustained_power.txt).
-    constexpr int C32MODE = sizeof(T) == 2 ? C32_NATIVE : MATH == MATH_SPLIT ? C32_SPLIT : -1;
+    constexpr int C32MODE = sizeof(T) == 2 ? C32_NATIVE : MATH == MATH_SPLIT ? C32_SPLIT : MATH == MATH_BF16 ? C32_BF16 : -1;
     constexpr int C32_AUTO_MAX_IMAGES = 48;
     static const int env_c32 = [] { const char* e = getenv("GIGA_CONV32"); return e ? (atoi(e) ? 1 : -1) : 0; }();
     if constexpr (C32MODE >= 0) {

@@ -89,10 +89,9 @@ class _TrainState:
                 raise _capi.GigaHipError("parameter list does not match the head set")
             torch._foreach_copy_(views, [q.detach() for q in params])
         s = _capi.stream_ptr(self.device)
-        _capi.check(L.giga_repack_device(_capi.ptr(flat), _capi.ptr(self.map_fwd), _capi.ptr(self.blob),
-                                         self.map_fwd.numel(), s), "giga_repack_device")
-        _capi.check(L.giga_repack_device(_capi.ptr(flat), _capi.ptr(self.map_bwd), _capi.ptr(self.bwd_blob),
-                                         self.map_bwd.numel(), s), "giga_repack_device")
+        _capi.check(L.giga_repack_device2(_capi.ptr(flat), _capi.ptr(self.map_fwd), _capi.ptr(self.blob), self.map_fwd.numel(),
+                                          _capi.ptr(self.map_bwd), _capi.ptr(self.bwd_blob), self.map_bwd.numel(), s),
+                    "giga_repack_device2")
         if self.bf16:                   # bf16 images of the convolution fragments, from the fp32 fragments just rebuilt
             _capi.check(L.giga_derive_bf16_fragments(_capi.ptr(self.blob), _capi.ptr(self.bwd_blob), s),
                         "giga_derive_bf16_fragments")

@@ -74,6 +74,9 @@ int giga_pack_weights(const float* params_host, size_t n_params, int head_presen
 int giga_pack_map(int head_present, int32_t* map_host, size_t nwords);
 int giga_repack_device(const float* params_dev, const int32_t* map_dev, void* packed_dev, size_t nwords,
                        void* stream);
+/* the forward and the backward blob in ONE launch (the training step rebuilds both every step) */
+int giga_repack_device2(const float* params_dev, const int32_t* map_fwd_dev, void* packed_dev, size_t nwords_fwd,
+                        const int32_t* map_bwd_dev, void* bwd_packed_dev, size_t nwords_bwd, void* stream);
 
 /* Scratch bytes giga_encoder_forward needs for a batch of B scenes. */
 size_t giga_encoder_workspace_bytes(int B, int precision);
