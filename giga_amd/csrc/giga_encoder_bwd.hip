@@ -690,6 +690,179 @@ __global__ __launch_bounds__(512) void conv3_wgrad_bf16_kernel(Wgrad3Args a) {
     }
 }
 
+// ---- the same kernel with the OUTPUT split over the workgroups as well (the layers with eight or sixteen 32x32 blocks) -------------
+// In conv3_wgrad_bf16_kernel a workgroup computes eight blocks for its share of the strips and leaves a partial image of 8 x 36 KiB:
+// with 256 workgroups that is 75 MB written and 75 MB read back by the reduce kernel PER LAYER (up0.conv1, down2.conv1, down2.conv2:
+// 450 MB of the step's traffic for 7 MB of gradients) against 20-40 MB of operands.  Here a workgroup owns BX blocks that share
+// their dY channels (one 32-channel block mb, the X blocks nb0 .. nb0 + BX - 1), the grid is (strips' share, all block groups), and
+// only the channels those blocks need are staged: 32 of dY and 32 BX of X.  Same strips, k-chunks, MFMAs and epilogue; 8 / BX
+// waves share a block (K split inside the workgroup).  Partial images: 256 workgroups x BX x 36 KiB = 19 MB at BX = 2.
+template <int C0, int C1, int COUT, int H, int RS, int BX>
+__global__ __launch_bounds__(512) void conv3_wgrad_bf16_ns_kernel(Wgrad3Args a) {
+    constexpr int W = H, CIN = C0 + C1;
+    constexpr int NBK = CIN / 32, NBLK = (COUT / 32) * NBK;
+    constexpr int BPG = BX;                           // blocks per workgroup: (mb, nb0 .. nb0 + BX - 1)
+    constexpr int KS = 8 / BPG;                       // waves sharing a block (K split)
+    constexpr int NGX = NBK / BX;                     // X block groups per dY block
+    static_assert(NBK % BX == 0 && 8 % BX == 0 && (C1 == 0 || C0 % (32 * BX) == 0), "block groups");
+    constexpr int CINW = 32 * BX, COUTW = 32;         // channels this workgroup stages
+    constexpr int G = (W + 7) / 8;                    // 8-pixel groups per row
+    constexpr int PY = 8 * G, PX = 8 * G + 16;        // row pitches (bf16 elements)
+    constexpr int XR = RS + 2;
+    constexpr int NVX = (CINW / 4) * XR * G, NVY = (COUTW / 4) * RS * G, NV = NVX + NVY;
+    static_assert(NV <= 512, "one staging item per thread");
+    constexpr int XCS = wg_cs(XR * PX), YCS = wg_cs(RS * PY);        // channel strides
+    constexpr int XELEMS = CINW * XCS, YELEMS = COUTW * YCS;
+    constexpr int NCH = RS * G / 2;                   // k-chunks (two groups each) per strip
+    static_assert((RS * G) % 2 == 0 && H % RS == 0, "strip geometry");
+    extern __shared__ __attribute__((aligned(16))) float wg_lds[];
+    __bf16* Xt = reinterpret_cast<__bf16*>(wg_lds);
+    __bf16* Yt = Xt + XELEMS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 31, hi = lane >> 5;
+    const int mb = blockIdx.y / NGX, nb0 = (blockIdx.y % NGX) * BX;       // this workgroup's dY block and first X block
+    const int nbl = wave / KS, ks = wave % KS;                            // this wave's block (local X block index) and K share
+
+    // zero the whole X image once: the halo columns are never written again
+    for (int v = tid; v < XELEMS / 8; v += 512) reinterpret_cast<uint4*>(Xt)[v] = make_uint4(0, 0, 0, 0);
+
+    // this thread's staging item
+    const bool isx = tid < NVX, isy = !isx && tid < NV;
+    const int u = isx ? tid : tid - NVX;
+    const int cq = isx ? u % (CINW / 4) : u % (COUTW / 4);       // channel quad inside the staged channels
+    const int rest = isx ? u / (CINW / 4) : u / (COUTW / 4);
+    const int sg = rest % G, sr = rest / G;           // group within the row, strip row
+    constexpr int SPI = H / RS;
+    const int nstrips = a.nimg * SPI;
+    // All eight loads of a staging item are issued UNCONDITIONALLY from clamped addresses and zeroed when they are stored
+    // (`ok`): behind `if`s every load sat in its own basic block, the register allocator overlapped their destinations and the
+    // compiler put s_waitcnt vmcnt(0) between them -- an item cost two to three dependent memory round trips instead of one
+    // (the strip loop ran at ~6 k clocks per strip, tools/gpu_wgrad_trace.py).
+    float4 stg[8];
+    unsigned ok = 0;                                  // bit e: element e of the staged item is inside the image
+    auto issue = [&](int st) {
+        const int img = st / SPI, y0 = (st % SPI) * RS;
+        const int gy = y0 - 1 + sr, gyc = gy < 0 ? 0 : gy >= H ? H - 1 : gy;
+        const int c = 4 * cq + (isx ? 32 * nb0 : 32 * mb);          // channel in the tensor
+        // (threads without an item read like a dY item of row 0: always a valid address)
+        const float* rowp = !isx ? a.dY + ((size_t)(img * H + y0 + (isy ? sr : 0)) * W) * COUT + c
+                                 : c < C0 ? a.in0 + ((size_t)(img * H + gyc) * W) * C0 + c
+                                          : a.in1 + ((size_t)(img * H + gyc) * W) * C1 + (c - C0);
+        const int ps = !isx ? COUT : c < C0 ? C0 : C1;
+        const bool row_ok = isy || (isx && gy >= 0 && gy < H);
+        ok = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int x = 8 * sg + e, xc = x < W ? x : W - 1;
+            stg[e] = *reinterpret_cast<const float4*>(rowp + (size_t)xc * ps);
+            ok |= (row_ok && x < W) ? 1u << e : 0u;
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const __bf16* ya = Yt + (size_t)n * YCS;                           // this lane's dY channel (of block mb)
+    const __bf16* xb = Xt + (size_t)(nbl * 32 + n) * XCS + 8;          // this lane's X channel, col of x = 0
+
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    int st = blockIdx.x;
+    if (st < nstrips) issue(st);
+    for (; st < nstrips; st += gridDim.x) {
+        __syncthreads();                              // everyone is done reading the previous strip (and the zero fill)
+        const unsigned okc = ok;
+        if (isx || isy) {
+            __bf16* dst = isx ? Xt + (size_t)(4 * cq) * XCS + sr * PX + 8 + 8 * sg : Yt + (size_t)(4 * cq) * YCS + sr * PY + 8 * sg;
+            const int cstride = isx ? XCS : YCS;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                float v8[8] = {ch == 0 ? stg[0].x : ch == 1 ? stg[0].y : ch == 2 ? stg[0].z : stg[0].w,
+                                     ch == 0 ? stg[1].x : ch == 1 ? stg[1].y : ch == 2 ? stg[1].z : stg[1].w,
+                                     ch == 0 ? stg[2].x : ch == 1 ? stg[2].y : ch == 2 ? stg[2].z : stg[2].w,
+                                     ch == 0 ? stg[3].x : ch == 1 ? stg[3].y : ch == 2 ? stg[3].z : stg[3].w,
+                                     ch == 0 ? stg[4].x : ch == 1 ? stg[4].y : ch == 2 ? stg[4].z : stg[4].w,
+                                     ch == 0 ? stg[5].x : ch == 1 ? stg[5].y : ch == 2 ? stg[5].z : stg[5].w,
+                                     ch == 0 ? stg[6].x : ch == 1 ? stg[6].y : ch == 2 ? stg[6].z : stg[6].w,
+                                     ch == 0 ? stg[7].x : ch == 1 ? stg[7].y : ch == 2 ? stg[7].z : stg[7].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = (okc >> e & 1u) ? v8[e] : 0.f;
+                wbf8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (__bf16)v8[e];
+                *reinterpret_cast<wbf8*>(dst + (size_t)ch * cstride) = o;
+                if (isy && nb0 == 0)                  // bias gradient: column sums of dY (this block's 32 channels), from the fp32 values
+                    bsum[ch] += ((v8[0] + v8[1]) + (v8[2] + v8[3])) + ((v8[4] + v8[5]) + (v8[6] + v8[7]));
+            }
+        }
+        __syncthreads();
+        if (st + (int)gridDim.x < nstrips) issue(st + gridDim.x);      // flies under this strip's MFMAs
+        for (int j = ks; j < NCH; j += KS) {
+            const int gi = 2 * j + hi, r = gi / G, xg = gi % G;
+            const wbf8 A = *reinterpret_cast<const wbf8*>(ya + r * PY + 8 * xg);
+#pragma unroll
+            for (int ty = 0; ty < 3; ++ty) {
+                const __bf16* row = xb + (r + ty) * PX + 8 * xg;                 // X row y + ty - 1, col of the group's x0
+                const uint4 mid = *reinterpret_cast<const uint4*>(row);
+                const unsigned wp = *reinterpret_cast<const unsigned*>(row - 2);  // elements x0-2, x0-1
+                const unsigned wn = *reinterpret_cast<const unsigned*>(row + 8);  // elements x0+8, x0+9
+                const uint4 left = {__builtin_amdgcn_alignbyte(mid.x, wp, 2), __builtin_amdgcn_alignbyte(mid.y, mid.x, 2),
+                                    __builtin_amdgcn_alignbyte(mid.z, mid.y, 2), __builtin_amdgcn_alignbyte(mid.w, mid.z, 2)};
+                const uint4 right = {__builtin_amdgcn_alignbyte(mid.y, mid.x, 2), __builtin_amdgcn_alignbyte(mid.z, mid.y, 2),
+                                     __builtin_amdgcn_alignbyte(mid.w, mid.z, 2), __builtin_amdgcn_alignbyte(wn, mid.w, 2)};
+                acc[3 * ty + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(wbf8, left), acc[3 * ty + 0], 0, 0, 0);
+                acc[3 * ty + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(wbf8, mid), acc[3 * ty + 1], 0, 0, 0);
+                acc[3 * ty + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, __builtin_bit_cast(wbf8, right), acc[3 * ty + 2], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: as conv3_wgrad_kernel (the D layout of the bf16 MFMA is the same 32x32 map) ----------------------
+    if (nb0 == 0) {
+        __syncthreads();
+        // per-channel totals: threads of the dY items hold 4 channels each for their (row, group)
+        float* red = wg_lds;                                          // [32] after zeroing
+        for (int c = tid; c < COUTW; c += 512) red[c] = 0.f;
+        __syncthreads();
+        if (isy) {
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) atomicAdd(red + 4 * cq + ch, bsum[ch]);      // LDS, <= RS*G addends per channel
+        }
+        __syncthreads();
+        if (tid < COUTW)
+            a.partial[(size_t)gridDim.y * gridDim.x * BPG * 9 * 1024 + (size_t)blockIdx.x * COUT + 32 * mb + tid] = red[tid];
+    }
+    float4* slot = reinterpret_cast<float4*>(wg_lds);                 // [wave][tap of the round][r4][lane]
+    constexpr int RN = 9 * 1024;
+    float* part = a.partial + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * BPG) * RN;
+#pragma unroll
+    for (int g3 = 0; g3 < 3; ++g3) {
+        __syncthreads();
+#pragma unroll
+        for (int tl = 0; tl < 3; ++tl)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                slot[((wave * 3 + tl) * 4 + r4) * 64 + lane] =
+                    make_float4(acc[3 * g3 + tl][4 * r4], acc[3 * g3 + tl][4 * r4 + 1], acc[3 * g3 + tl][4 * r4 + 2],
+                                acc[3 * g3 + tl][4 * r4 + 3]);
+        __syncthreads();
+        for (int v = tid; v < BPG * 3 * 4 * 64; v += 512) {
+            const int ln = v & 63, r4 = (v >> 6) & 3, tl = (v >> 8) % 3, b = v / 768;
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < KS; ++q) {
+                const float4 x = slot[(((b * KS + q) * 3 + tl) * 4 + r4) * 64 + ln];
+                sum.x += x.x; sum.y += x.y; sum.z += x.z; sum.w += x.w;
+            }
+            const int nn = ln & 31, m0 = 8 * r4 + 4 * (ln >> 5);      // D rows of registers 4*r4 .. 4*r4+3: m0 .. m0+3
+            float* dst = part + ((size_t)(b * 9 + 3 * g3 + tl) * 32 + m0) * 32 + nn;
+            dst[0] = sum.x; dst[32] = sum.y; dst[64] = sum.z; dst[96] = sum.w;
+        }
+    }
+}
+
 // ---- the same weight gradient for layers with at most four 32x32 blocks: the NINE TAPS go to nine waves ----------------------
 // In conv3_wgrad_bf16_kernel a wave owns a block for all nine taps (144 accumulator registers) and the waves of a block split the
 // pixels.  For the layers with one to four blocks (32 -> 32 and 32 + 32 -> 32 at 40x40, 32 -> 64 and 64 -> 64 at 20x20) that leaves
@@ -874,6 +1047,23 @@ static int launch_wgrad3_bf16(const Wgrad3Args& a, hipStream_t s) {
             GIGA_LAUNCH(kern, dim3(gx), dim3(576), strip, s, a);
             GIGA_LAUNCH((wgrad3_reduce_kernel<CIN, BPG>), dim3(9 * 1024 / 64 + 1, NBLK), dim3(256), 0, s, a.partial, gx,
                                a.dW, a.db, COUT, NY);
+            return hipGetLastError() == hipSuccess ? 0 : -10;
+        }
+    }
+    if constexpr (NBLK > 4) {                         // the output split over the workgroups too (conv3_wgrad_bf16_ns_kernel)
+        static const bool nsplit = [] { const char* e = getenv("GIGA_WGRAD_NSPLIT"); return !e || atoi(e) != 0; }();
+        if (nsplit) {
+            constexpr int BX = 2, NYS = NBLK / BX;
+            constexpr size_t strip_ns = ((size_t)32 * BX * wg_cs((RS + 2) * (8 * G + 16)) + (size_t)32 * wg_cs(RS * 8 * G)) * 2;
+            constexpr size_t slots = (size_t)8 * 3 * 4 * 64 * 16;                          // the epilogue's LDS slots (96 KiB)
+            constexpr size_t lds_ns = strip_ns > slots ? strip_ns : slots;
+            int gxs = 256 / NYS;
+            if (gxs > nstrips) gxs = nstrips;
+            auto kns = conv3_wgrad_bf16_ns_kernel<C0, C1, COUT, H, RS, BX>;
+            giga::dyn_lds_once(reinterpret_cast<const void*>(kns), (int)lds_ns);
+            GIGA_LAUNCH(kns, dim3(gxs, NYS), dim3(512), lds_ns, s, a);
+            GIGA_LAUNCH((wgrad3_reduce_kernel<CIN, BX>), dim3(9 * 1024 / 64 + 1, NBLK), dim3(256), 0, s, a.partial, gxs,
+                               a.dW, a.db, COUT, NYS);
             return hipGetLastError() == hipSuccess ? 0 : -10;
         }
     }
