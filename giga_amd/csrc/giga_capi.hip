@@ -131,12 +131,28 @@ constexpr int DECT_DERIVE_BLOCKS = (59 + 51) * NHEADS;
 struct DeriveArgs {
     BfRegions r; C32bRegions c; int n16, n32;
     size_t dec32_0, dec32_stride, dectf_0, dectf_stride, decb_0, decb_stride, dectb_0, dectb_stride;
+    size_t convin_w, convin_ws;
 };
 __global__ __launch_bounds__(64) void derive_all_kernel(uint8_t* fwd, uint8_t* bwd, DeriveArgs d) {
     const int b = blockIdx.x;
     if (b < d.n16) derive_bf16_block(fwd, bwd, d.r, b);
     else if (b < d.n16 + d.n32) derive_c32b_block(fwd, d.c, b - d.n16);
-    else {
+    else if (b == d.n16 + d.n32 + DECT_DERIVE_BLOCKS) {
+        // f16x3 split conv_in operands (giga_pack.cpp): [2 channel halves][hi | lo][lane (j, g)][8 halfs e] <- W[16 h + j][ci16_tap(g, e)],
+        // from the fp32 image [h][K-step s of 4 taps][lane (j, k)] = W[16 h + j][4 s + k]
+        if (!fwd) return;
+        const float* cw = reinterpret_cast<const float*>(fwd + d.convin_w);
+        _Float16* cs = reinterpret_cast<_Float16*>(fwd + d.convin_ws);
+        const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+        for (int h = 0; h < 2; ++h)
+            for (int e = 0; e < 8; ++e) {
+                const int tap = ci16_tap(g, e);
+                const float w = tap >= 0 ? cw[(h * 7 + tap / 4) * 64 + (tap % 4) * 16 + j] : 0.f;
+                const _Float16 hi = (_Float16)w;
+                cs[((2 * h) * 64 + lane) * 8 + e] = hi;
+                cs[((2 * h + 1) * 64 + lane) * 8 + e] = (_Float16)(w - (float)hi);
+            }
+    } else {
         const int k = b - d.n16 - d.n32;
         dect_derive_block(fwd, bwd, k % (59 + 51), k / (59 + 51), d.dec32_0, d.dec32_stride, d.dectf_0, d.dectf_stride, d.decb_0,
                           d.decb_stride, d.dectb_0, d.dectb_stride);
@@ -177,8 +193,9 @@ int giga_derive_bf16_fragments(void* packed_dev, void* bwd_packed_dev, void* str
     d.n32 = packed_dev ? n32 : 0;
     d.dec32_0 = ko.dec32[0]; d.dec32_stride = ko.dec32[1] - ko.dec32[0]; d.dectf_0 = ko.dect[0]; d.dectf_stride = ko.dect[1] - ko.dect[0];
     d.decb_0 = bo.dec[0]; d.decb_stride = bo.dec[1] - bo.dec[0]; d.dectb_0 = bo.dect[0]; d.dectb_stride = bo.dect[1] - bo.dect[0];
-    // ONE launch: the bf16 conv16 fragments of both blobs, the bf16 conv32 images, the bf16 decoder images (giga_dect.h)
-    GIGA_LAUNCH(derive_all_kernel, dim3(d.n16 + d.n32 + DECT_DERIVE_BLOCKS), dim3(64), 0, static_cast<hipStream_t>(stream),
+    d.convin_w = ko.convin_w; d.convin_ws = ko.convin_ws;
+    // ONE launch: the bf16 conv16 fragments of both blobs, the bf16 conv32 images, the bf16 decoder images (giga_dect.h), the f16x3 conv_in operands
+    GIGA_LAUNCH(derive_all_kernel, dim3(d.n16 + d.n32 + DECT_DERIVE_BLOCKS + 1), dim3(64), 0, static_cast<hipStream_t>(stream),
                 static_cast<uint8_t*>(packed_dev), static_cast<uint8_t*>(bwd_packed_dev), d);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }

@@ -952,25 +952,35 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     float* XZP = reinterpret_cast<float*>(ws + w.YZ);
     float* YZP = XZP + 4 * per;
     const int nxp = enc_nxp(B);
-    constexpr bool CI_F16 = SPLIT || sizeof(T) == 2;        // conv_in on the f16 MFMA: split mode (hi/lo) and plain f16 (hi only)
-    constexpr bool CI_LO = SPLIT;
-    const float* cw = reinterpret_cast<const float*>(blob + (CI_F16 ? ko.convin_ws : ko.convin_w));
-    const float* cb = reinterpret_cast<const float*>(blob + ko.convin_b);
+    // conv_in arithmetic: fp32 MFMA (precision 0), the f16 MFMA with hi only (plain f16) or with f16x3 split operands (precision 2).
+    // The bf16 training forward (MATH_BF16) takes the f16x3 form too -- fp32-grade results (<= 1e-5 of the fp32 kernel: the backward's
+    // fp32 recomputation of the ReLU mask agrees with it) on three f16 MFMAs per unit instead of seven fp32 ones; its operand image
+    // (convin_ws) is rebuilt on the device with the other derived images (giga_derive_bf16_fragments).  GIGA_BF16_CONVIN=0: fp32.
+    static const bool bf_ci16 = [] { const char* e = getenv("GIGA_BF16_CONVIN"); return !e || atoi(e) != 0; }();
+    auto run_convin = [&](auto f16c, auto lo) {
+        constexpr bool CI_F16 = decltype(f16c)::value, CI_LO = decltype(lo)::value;
+        const float* cw = reinterpret_cast<const float*>(blob + (CI_F16 ? ko.convin_ws : ko.convin_w));
+        const float* cb = reinterpret_cast<const float*>(blob + ko.convin_b);
+        // 8 waves x 5 slices.  (4 waves x 10 slices -- one wave per SIMD, half the yz partials -- measured slower for the fp32
+        // path, 50.5 vs 47.3 us at 32 scenes: the second wave of a SIMD hides the slice-boundary and LDS-issue bubbles.)
+        constexpr int NW = 8;
+        if (nxp == 1) {
+            auto kern = convin_project_kernel<T, RES / NW, CI_F16, NW, CI_LO>;
+            constexpr size_t lds = ci_lds_bytes(RES, NW, CI_F16);
+            giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
+            GIGA_LAUNCH(kern, dim3(8 * B), dim3(NW * 64), lds, s, tsdf, cw, cb, P0, XZP, YZP, B);
+        } else {
+            auto kern = convin_project_kernel<T, 8 / NW, CI_F16, NW, CI_LO>;
+            constexpr size_t lds = ci_lds_bytes(8, NW, CI_F16);
+            giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
+            GIGA_LAUNCH(kern, dim3(5, 8, B), dim3(NW * 64), lds, s, tsdf, cw, cb, P0, XZP, YZP, B);
+        }
+    };
     pre();
-    // 8 waves x 5 slices.  (4 waves x 10 slices -- one wave per SIMD, half the yz partials -- measured slower for the fp32
-    // path, 50.5 vs 47.3 us at 32 scenes: the second wave of a SIMD hides the slice-boundary and LDS-issue bubbles.)
-    constexpr int NW = 8;
-    if (nxp == 1) {
-        auto kern = convin_project_kernel<T, RES / NW, CI_F16, NW, CI_LO>;
-        constexpr size_t lds = ci_lds_bytes(RES, NW, CI_F16);
-        giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
-        GIGA_LAUNCH(kern, dim3(8 * B), dim3(NW * 64), lds, s, tsdf, cw, cb, P0, XZP, YZP, B);
-    } else {
-        auto kern = convin_project_kernel<T, 8 / NW, CI_F16, NW, CI_LO>;
-        constexpr size_t lds = ci_lds_bytes(8, NW, CI_F16);
-        giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
-        GIGA_LAUNCH(kern, dim3(5, 8, B), dim3(NW * 64), lds, s, tsdf, cw, cb, P0, XZP, YZP, B);
-    }
+    if constexpr (SPLIT) run_convin(std::true_type{}, std::true_type{});
+    else if constexpr (sizeof(T) == 2) run_convin(std::true_type{}, std::false_type{});
+    else if constexpr (MATH == MATH_BF16) { if (bf_ci16) run_convin(std::true_type{}, std::true_type{}); else run_convin(std::false_type{}, std::false_type{}); }
+    else run_convin(std::false_type{}, std::false_type{});
     post();
     {
         pre();
