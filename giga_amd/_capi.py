@@ -17,6 +17,8 @@ HEAD_QUAL, HEAD_ROT, HEAD_WIDTH, HEAD_TSDF = 1, 2, 4, 8
 DETACH_OCC = 16          # GIGA_DETACH_OCC: flag for giga_backward's head_present
 BF16_CONVS = 32          # GIGA_BF16_CONVS: dgrad convolutions on bf16 MFMA (giga_backward's head_present)
 BF16_DECODER = 64        # GIGA_BF16_DECODER: the decoder backward as one fused bf16 kernel per call (giga_backward's head_present)
+CONVIN_MASK = 512        # GIGA_CONVIN_MASK: training forward keeps conv_in's ReLU mask (encoder `precision` flag)
+CONVIN_MASK_BWD = 128    # GIGA_CONVIN_MASK_BWD: giga_backward reads it (head_present flag)
 ENC_BF16 = 3             # encoder `precision` 3: bf16 U-Net convolutions, fp32 activations in memory
 DEC_BF16 = 3             # decoder `precision` 3: bf16 linear layers on fp32 planes (the forward of the bf16 training decoder)
 FOLD_FINAL = 16          # GIGA_FOLD_FINAL: OR-ed into `precision` of an encoder call and of the decoder calls on its planes

@@ -31,6 +31,7 @@ struct DecArgs {
 struct EncWs {
     size_t P0, A0, S0, Q0, A1, S1, Q1, A2, S2, U0, A3, A4, U1, A5, A6, YZ, XZ, total;   // XZ unused (kept for the ABI)
     size_t SYNC;               // barrier counter + timeout flag of the persistent U-Net kernel
+    size_t MASK;               // conv_in ReLU mask of a training forward (GIGA_CONVIN_MASK): [B][8][40][64 lanes] x 16 bytes
 };
 
 }  // namespace giga

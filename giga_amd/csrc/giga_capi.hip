@@ -22,7 +22,7 @@ BwdWs enc_bwd_workspace(int B);
 constexpr size_t ENC_BWD_SYNC_BYTES = 8192;        // behind BwdWs::total: the counters of the persistent data-gradient kernel (giga_bwd_mega.h)
 void persistent_forget();
 int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws,
-                            float* gplanes, uint8_t* gws, float* grads, int head_present, int B, hipStream_t s, bool bf16_convs);
+                            float* gplanes, uint8_t* gws, float* grads, int head_present, int B, hipStream_t s, bool bf16_convs, bool convin_mask);
 size_t dec_bwd_scratch_floats(long long P, int nheads);
 bool dec_bwd_writes_planes(int nheads, int B, int N);
 int launch_decoder_backward(const float* planes, const float* p, const uint8_t* blob, const uint8_t* bwd_blob,
@@ -254,14 +254,14 @@ int giga_repack_device(const float* params_dev, const int32_t* map_dev, void* pa
 }
 
 size_t giga_encoder_workspace_bytes(int B, int precision) {
-    precision &= ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET);
+    precision &= ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET | GIGA_CONVIN_MASK);
     if (B <= 0) return 0;
     return enc_workspace(B, precision).total;
 }
 
 int giga_encoder_workspace_layout(int B, int precision, size_t* offsets) {
     if (B <= 0 || !offsets) return -1;
-    precision &= ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET);
+    precision &= ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET | GIGA_CONVIN_MASK);
     if (precision < 0 || precision > 3) return -5;
     const EncWs w = enc_workspace(B, precision);
     const size_t v[17] = {w.P0, w.A0, w.S0, w.Q0, w.A1, w.S1, w.Q1, w.A2, w.S2, w.U0, w.A3, w.A4, w.U1, w.A5, w.A6,
@@ -276,8 +276,8 @@ int giga_encoder_forward_probe(const float* tsdf, const void* packed, void* plan
     if (B < 0 || (B > 0 && (!tsdf || !packed || !planes_nhwc || !workspace))) return -1;
     if (B > GIGA_MAX_SCENES) return -7;
     const bool fold = (precision & GIGA_FOLD_FINAL) != 0;     // stop before conv_final (folded decoder images)
-    const int persist = precision & (GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET);   // U-Net launch form and kernels (see the header)
-    precision &= ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET);
+    const int persist = precision & (GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET | GIGA_CONVIN_MASK);   // U-Net launch form and kernels (see the header)
+    precision &= ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET | GIGA_CONVIN_MASK);
     if (precision < 0 || precision > 3) return -5;
     if (fold && planes_nchw) return -1;                       // the reference-layout copy is the FINAL planes only
     if (workspace_bytes < giga_encoder_workspace_bytes(B, precision)) return -4;
@@ -477,6 +477,7 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
     const bool detach_occ = (head_present & GIGA_DETACH_OCC) != 0;     // detach_tsdf, models/__init__.py:61-63
     const bool bf16_convs = (head_present & GIGA_BF16_CONVS) != 0;     // data-gradient convolutions on bf16 MFMA
     const bool bf16_dec = (head_present & GIGA_BF16_DECODER) != 0;     // decoder backward on the fused bf16 kernel
+    const bool convin_mask = (head_present & GIGA_CONVIN_MASK_BWD) != 0;   // the forward kept conv_in's ReLU mask (GIGA_CONVIN_MASK)
     head_present &= 15;
     if (N < 0 || M < 0) return -1;
     if (n_params != param_offsets(head_present).total) return -2;
@@ -528,7 +529,7 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
     }
     }
     rc |= launch_encoder_backward(tsdf, blob, bblob, static_cast<const uint8_t*>(enc_workspace_fwd), gplanes, gws,
-                                  grads, head_present, B, s, bf16_convs);
+                                  grads, head_present, B, s, bf16_convs, convin_mask);
     return rc;
 }
 

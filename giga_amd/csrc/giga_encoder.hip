@@ -58,7 +58,11 @@ static __device__ long long g_ci_trace[8 * 64];
 #else
 #define CI_T(idx) do {} while (0)
 #endif
-template <typename TOut, int SXW, bool SPLIT = false, int NW = 8, bool LO = true>
+// MASK (training forward): the sign bits of the pre-activations go to `relu_mask` -- per (scene, workgroup row wy, ix) and lane one
+// 16-byte word, value k = (zg * 5 + ip) * 4 + r of the lane's 100 in word k >> 5, shifted in from the right (v_alignbit: one VALU
+// instruction per value) -- so that the backward (convin_bwd_kernel<.., true>) does not recompute the convolution for its ReLU mask.
+// A set bit = negative (or -0): gradient 0; +0 counts as positive (measure zero).
+template <typename TOut, int SXW, bool SPLIT = false, int NW = 8, bool LO = true, bool MASK = false>
 __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for NW = 4: a 256-thread bound makes the compiler put the MFMA results into AGPRs and copy them out for the epilogue)
     const float* __restrict__ tsdf,        // [B][40][40][40]
     const float* __restrict__ wpk,         // [2][7][64] packed B operands (SPLIT: [2][hi|lo][64] x 8 halfs)
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
     TOut* __restrict__ planes,             // [3][B][40][40][32] NHWC (xy written here)
     float* __restrict__ xz_partial,        // [4 iy-groups][B][40(iz)][40(ix)][32] sums over the group's 10 iy
     float* __restrict__ yz_partial,        // [NXP][B][40(iz)][40(iy)][32] sums over the part's ix
-    int B) {
+    int B, uint4* __restrict__ relu_mask = nullptr) {
     constexpr int XW = NW * SXW, NT = NW * 64;
     // row / slab strides of the staged sub-volume in words: the f16-class instantiations use the layout that makes their 8-tap
     // gather conflict-free (giga_layout.h: ci16_tap), fp32 the compact one (its 4-tap k-steps are conflict-free there)
@@ -203,6 +207,7 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
     if constexpr (SPLIT) {
     for (int sx = 0; sx < SXW; ++sx) {
         const int ixl = wave * SXW + sx, ix = x0 + ixl;
+        unsigned mw[4] = {0u, 0u, 0u, 0u};
         f32x2v sum_z[5];                  // per iy-pair: sum over the 5 iz-groups and the 4 in-lane iz (two partials)
 #pragma unroll
         for (int ip = 0; ip < 5; ++ip) sum_z[ip] = f32x2v{0.f, 0.f};
@@ -243,6 +248,14 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
             f32x4v part_y = zero4;            // per r: sum over the 5 iy-pairs of this group
 #pragma unroll
             for (int ip = 0; ip < 5; ++ip) {
+                if constexpr (MASK) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = (zg * 5 + ip) * 4 + r;
+                        const float dv = d[ip][r];       // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0 of the vector)
+                        mw[k >> 5] = __builtin_amdgcn_alignbit(mw[k >> 5], __builtin_bit_cast(unsigned, dv), 31);
+                    }
+                }
                 const f32x4v v = {relu(d[ip][0]), relu(d[ip][1]), relu(d[ip][2]), relu(d[ip][3])};
                 acc_yz[ip][zg] += v;
                 // pin the accumulation here: the IR sinking pass otherwise moves it to the loop latch and keeps all 100
@@ -255,6 +268,7 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
             __builtin_amdgcn_sched_barrier(0);
         }
         xy_store(sum_z, plane_xy + ix * CD);
+        if constexpr (MASK) relu_mask[(((size_t)b * 8 + (2 * grp + chh)) * RES + ix) * 64 + lane] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
     }
     } else {
     // ---- fp32-input MFMA path.  On gfx950 v_mfma_f32_*_f32 and ordinary VALU work share one pipe (no co-execution, not even
@@ -284,6 +298,7 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
     load_a(0, 0); load_a(1, 0); load_a(2, 0);
     for (int sx = 0; sx < SXW; ++sx) {
         const int ix = x0 + wave * SXW + sx;
+        unsigned mw[4] = {0u, 0u, 0u, 0u};
         f32x2v sum_z[5];                  // per iy-pair: sum over the 5 iz-groups and the 4 in-lane iz (two partials)
 #pragma unroll
         for (int zg = 0; zg < 5; ++zg) {
@@ -300,6 +315,14 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
             f32x4v part_y;                // per r: sum over the 5 iy-pairs of this group
 #pragma unroll
             for (int ip = 0; ip < 5; ++ip) {
+                if constexpr (MASK) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = (zg * 5 + ip) * 4 + r;
+                        const float dv = d[ip][r];       // (a copy: __builtin_bit_cast of a vector ELEMENT reads element 0 of the vector)
+                        mw[k >> 5] = __builtin_amdgcn_alignbit(mw[k >> 5], __builtin_bit_cast(unsigned, dv), 31);
+                    }
+                }
                 const f32x4v v = {relu(d[ip][0]), relu(d[ip][1]), relu(d[ip][2]), relu(d[ip][3])};
                 acc_yz[ip][zg] += v;
                 asm volatile("" : "+v"(acc_yz[ip][zg]));         // keep the accumulation here (see the split path)
@@ -318,6 +341,7 @@ __global__ __launch_bounds__(512) void convin_project_kernel(   // (512 also for
             __builtin_amdgcn_sched_barrier(0);
         }
         xy_store(sum_z, plane_xy + ix * CD);
+        if constexpr (MASK) relu_mask[(((size_t)b * 8 + (2 * grp + chh)) * RES + ix) * 64 + lane] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
 #pragma unroll
         for (int s = 3; s < 7; ++s) {
             a_lo[s] += 4 * SLICE; a_hi[s] += 4 * SLICE;
@@ -408,6 +432,7 @@ EncWs enc_workspace(int B, int precision) {
     w.YZ = take((size_t)(4 + enc_nxp(B)) * B * 1600 * 32, 4);   // 4 xz partials (iy-groups) + NXP yz partials (x-parts)
     w.XZ = w.YZ;
     w.SYNC = take(MEGA_SYNC_WORDS * 4, 4); // barrier counters of the persistent U-Net kernel (8 per-XCD + 32 per-group, 128 B apart)
+    w.MASK = take((size_t)B * 8 * RES * 64 * 4, 4);   // conv_in ReLU mask (training forward with GIGA_CONVIN_MASK; 10 MB at 32 scenes)
     w.total = at;
     return w;
 }
@@ -939,7 +964,7 @@ static std::atomic<int> g_last_unet_path{0};
 
 template <typename T, int MATH = MATH_NATIVE>
 static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc, float* planes_nchw, int B,
-                       uint8_t* ws, hipStream_t s, const Probe& pr, bool fold_final, int persist, int conv32) {
+                       uint8_t* ws, hipStream_t s, const Probe& pr, bool fold_final, int persist, int conv32, bool keep_mask = false) {
     constexpr bool SPLIT = MATH == MATH_SPLIT;
     int stage_no = 0;
     auto pre = [&]() { if (pr.stage == stage_no) (void)hipEventRecord(pr.ev0, s); };
@@ -957,30 +982,34 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     // fp32 recomputation of the ReLU mask agrees with it) on three f16 MFMAs per unit instead of seven fp32 ones; its operand image
     // (convin_ws) is rebuilt on the device with the other derived images (giga_derive_bf16_fragments).  GIGA_BF16_CONVIN=0: fp32.
     static const bool bf_ci16 = [] { const char* e = getenv("GIGA_BF16_CONVIN"); return !e || atoi(e) != 0; }();
-    auto run_convin = [&](auto f16c, auto lo) {
-        constexpr bool CI_F16 = decltype(f16c)::value, CI_LO = decltype(lo)::value;
+    uint4* mask_out = keep_mask ? reinterpret_cast<uint4*>(ws + w.MASK) : nullptr;
+    auto run_convin = [&](auto f16c, auto lo, auto msk) {
+        constexpr bool CI_F16 = decltype(f16c)::value, CI_LO = decltype(lo)::value, MK = decltype(msk)::value;
         const float* cw = reinterpret_cast<const float*>(blob + (CI_F16 ? ko.convin_ws : ko.convin_w));
         const float* cb = reinterpret_cast<const float*>(blob + ko.convin_b);
         // 8 waves x 5 slices.  (4 waves x 10 slices -- one wave per SIMD, half the yz partials -- measured slower for the fp32
         // path, 50.5 vs 47.3 us at 32 scenes: the second wave of a SIMD hides the slice-boundary and LDS-issue bubbles.)
         constexpr int NW = 8;
         if (nxp == 1) {
-            auto kern = convin_project_kernel<T, RES / NW, CI_F16, NW, CI_LO>;
+            auto kern = convin_project_kernel<T, RES / NW, CI_F16, NW, CI_LO, MK>;
             constexpr size_t lds = ci_lds_bytes(RES, NW, CI_F16);
             giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
-            GIGA_LAUNCH(kern, dim3(8 * B), dim3(NW * 64), lds, s, tsdf, cw, cb, P0, XZP, YZP, B);
+            GIGA_LAUNCH(kern, dim3(8 * B), dim3(NW * 64), lds, s, tsdf, cw, cb, P0, XZP, YZP, B, mask_out);
         } else {
-            auto kern = convin_project_kernel<T, 8 / NW, CI_F16, NW, CI_LO>;
+            auto kern = convin_project_kernel<T, 8 / NW, CI_F16, NW, CI_LO, MK>;
             constexpr size_t lds = ci_lds_bytes(8, NW, CI_F16);
             giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
-            GIGA_LAUNCH(kern, dim3(5, 8, B), dim3(NW * 64), lds, s, tsdf, cw, cb, P0, XZP, YZP, B);
+            GIGA_LAUNCH(kern, dim3(5, 8, B), dim3(NW * 64), lds, s, tsdf, cw, cb, P0, XZP, YZP, B, mask_out);
         }
     };
     pre();
-    if constexpr (SPLIT) run_convin(std::true_type{}, std::true_type{});
-    else if constexpr (sizeof(T) == 2) run_convin(std::true_type{}, std::false_type{});
-    else if constexpr (MATH == MATH_BF16) { if (bf_ci16) run_convin(std::true_type{}, std::true_type{}); else run_convin(std::false_type{}, std::false_type{}); }
-    else run_convin(std::false_type{}, std::false_type{});
+    using TT = std::true_type; using FF = std::false_type;
+    if constexpr (SPLIT) run_convin(TT{}, TT{}, FF{});
+    else if constexpr (sizeof(T) == 2) run_convin(TT{}, FF{}, FF{});
+    else if constexpr (MATH == MATH_BF16) {
+        if (bf_ci16) { if (keep_mask) run_convin(TT{}, TT{}, TT{}); else run_convin(TT{}, TT{}, FF{}); }
+        else { if (keep_mask) run_convin(FF{}, FF{}, TT{}); else run_convin(FF{}, FF{}, FF{}); }
+    } else { if (keep_mask) run_convin(FF{}, FF{}, TT{}); else run_convin(FF{}, FF{}, FF{}); }
     post();
     {
         pre();
@@ -1135,12 +1164,13 @@ int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, fl
     Probe pr{ev0 && ev1 ? probe_stage : -1, static_cast<hipEvent_t>(ev0), static_cast<hipEvent_t>(ev1)};
     const bool fold = (precision & GIGA_FOLD_FINAL) != 0;
     const int persist = (precision & GIGA_LAYERWISE_UNET) ? -1 : (precision & GIGA_PERSIST_UNET) ? 1 : 0;   // -1 per-layer launches, 0 auto, 1 persistent
-    const int prec = precision & ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET);
+    const int prec = precision & ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET | GIGA_CONVIN_MASK);
     const int c32 = (precision & GIGA_CONV32_UNET) ? 1 : (precision & GIGA_CONV16_UNET) ? -1 : 0;      // 1 conv32, -1 conv16, 0 default
+    const bool km = (precision & GIGA_CONVIN_MASK) != 0;      // training forward (precisions 0 and 3): keep conv_in's ReLU mask for the backward
     if (prec == 2) return encoder_run<float, MATH_SPLIT>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32);
-    if (prec == 3) return encoder_run<float, MATH_BF16>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32);
+    if (prec == 3) return encoder_run<float, MATH_BF16>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32, km);
     return prec == 1 ? encoder_run<half_t>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32)
-                     : encoder_run<float>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32);
+                     : encoder_run<float>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32, km);
 }
 
 }  // namespace giga

@@ -1088,12 +1088,15 @@ constexpr int CB_RS = 44, CB_ROWS = 12;           // staged sub-volume: (XW+2) x
 constexpr int CB_PART = 27 * 16 + 16;             // floats per workgroup partial: dW^T[tap][ch16], db[ch16]
 constexpr size_t cb_lds_bytes(int sxw) { return (size_t)(8 * sxw + 2) * CB_ROWS * CB_RS * sizeof(float); }
 
-template <int SXW>
+// MASK: the forward (convin_project_kernel<.., MASK = true>, GIGA_CONVIN_MASK) has left the sign bits of the pre-activations -- per
+// (scene, workgroup row, ix) and lane one 16-byte word, value k = (zg * 5 + ip) * 4 + r in word k >> 5 at bit (n - 1 - (k & 31)),
+// n = 32 (4 in the last word) -- and the seven recomputation MFMAs of every unit fall away (8 instead of 15 per unit).
+template <int SXW, bool MASK = false>
 __global__ __launch_bounds__(512) void convin_bwd_kernel(const float* __restrict__ tsdf, const float* __restrict__ wpk,
                                                          const float* __restrict__ bias,
                                                          const float* __restrict__ gplanes,   // [3][B][40][40][32]
                                                          float* __restrict__ partial,         // [workgroup][CB_PART]
-                                                         int B) {
+                                                         int B, const uint4* __restrict__ relu_mask = nullptr) {
     constexpr int XW = 8 * SXW;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1159,6 +1162,11 @@ __global__ __launch_bounds__(512) void convin_bwd_kernel(const float* __restrict
         // upstream gradients of this slice that do not depend on the unit: xy row per iy-pair, xz rows per (zg, r)
         float gy[5];
         f32x4v gx[5];
+        unsigned mwv[4] = {0u, 0u, 0u, 0u};
+        if constexpr (MASK) {
+            const uint4 m4 = relu_mask[(((size_t)b * 8 + blockIdx.y) * RES + ix) * 64 + lane];
+            mwv[0] = m4.x; mwv[1] = m4.y; mwv[2] = m4.z; mwv[3] = m4.w;
+        }
 #pragma unroll
         for (int ip = 0; ip < 5; ++ip) gy[ip] = gxy[((grp * 10 + 2 * ip + (g >> 1)) * RES + ix) * CD + ch];
 #pragma unroll
@@ -1167,15 +1175,17 @@ __global__ __launch_bounds__(512) void convin_bwd_kernel(const float* __restrict
             for (int r = 0; r < 4; ++r) gx[zg][r] = gxz[((8 * zg + 4 * (g & 1) + r) * RES + ix) * CD + ch];
 #pragma unroll
         for (int zg = 0; zg < 5; ++zg) {
-            // forward recompute: five independent 7-MFMA chains (bias in the C operand, as the forward does)
+            // forward recompute: five independent 7-MFMA chains (bias in the C operand, as the forward does) -- or the stored sign bits
             f32x4v d[5];
+            if constexpr (!MASK) {
 #pragma unroll
-            for (int ip = 0; ip < 5; ++ip) d[ip] = bias4;
+                for (int ip = 0; ip < 5; ++ip) d[ip] = bias4;
 #pragma unroll
-            for (int s = 0; s < 7; ++s)
+                for (int s = 0; s < 7; ++s)
 #pragma unroll
-                for (int ip = 0; ip < 5; ++ip)
-                    d[ip] = mfma32_16(lds[abase[s] + so + 2 * ip * CB_RS + 8 * zg], wreg[s], d[ip]);
+                    for (int ip = 0; ip < 5; ++ip)
+                        d[ip] = mfma32_16(lds[abase[s] + so + 2 * ip * CB_RS + 8 * zg], wreg[s], d[ip]);
+            }
 #pragma unroll
             for (int ip = 0; ip < 5; ++ip) {
                 const int uo = so + 2 * ip * CB_RS + 8 * zg;
@@ -1183,7 +1193,14 @@ __global__ __launch_bounds__(512) void convin_bwd_kernel(const float* __restrict
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float gsum = gx[zg][r] + gy[ip] + gz[ip][zg][r];
-                    dF[r] = d[ip][r] > 0.f ? gsum * inv : 0.f;
+                    bool pos;
+                    if constexpr (MASK) {
+                        const int k = (zg * 5 + ip) * 4 + r, wd = k >> 5, bit = (wd == 3 ? 3 : 31) - (k & 31);
+                        pos = ((mwv[wd] >> bit) & 1u) == 0u;                 // sign bit clear
+                    } else {
+                        pos = d[ip][r] > 0.f;
+                    }
+                    dF[r] = pos ? gsum * inv : 0.f;
                     accb += dF[r];
                 }
 #pragma unroll
@@ -1266,7 +1283,7 @@ int enc_nxp(int B);
 template <int MATH>
 static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws,
                                  float* gplanes /* [3B][40][40][32], in: dLoss/dPlanes, clobbered */, uint8_t* gws,
-                                 float* grads /* flat, state-dict order */, int head_present, int B, hipStream_t s) {
+                                 float* grads /* flat, state-dict order */, int head_present, int B, hipStream_t s, bool convin_mask) {
     if (B <= 0) return 0;
     const PackOff ko = pack_offsets();
     const BwdPackOff bo = bwd_pack_offsets();
@@ -1420,15 +1437,13 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
         const float* cw = reinterpret_cast<const float*>(blob + ko.convin_w);
         const float* cb = reinterpret_cast<const float*>(blob + ko.convin_b);
         float* part = G(g.WG);                        // free again: the 3x3 weight gradients are done
-        if (nxp == 1) {
-            auto kern = convin_bwd_kernel<5>;
-            giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)cb_lds_bytes(5));
-            GIGA_LAUNCH(kern, dim3(1, 8, B), dim3(512), cb_lds_bytes(5), s, tsdf, cw, cb, G(g.gP0), part, B);
-        } else {
-            auto kern = convin_bwd_kernel<1>;
-            giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)cb_lds_bytes(1));
-            GIGA_LAUNCH(kern, dim3(5, 8, B), dim3(512), cb_lds_bytes(1), s, tsdf, cw, cb, G(g.gP0), part, B);
-        }
+        const uint4* mask = convin_mask ? reinterpret_cast<const uint4*>(fws + f.MASK) : nullptr;
+        auto go = [&](auto kern, int sxw, dim3 grid) {
+            giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)cb_lds_bytes(sxw));
+            GIGA_LAUNCH(kern, grid, dim3(512), cb_lds_bytes(sxw), s, tsdf, cw, cb, G(g.gP0), part, B, mask);
+        };
+        if (nxp == 1) { if (mask) go(convin_bwd_kernel<5, true>, 5, dim3(1, 8, B)); else go(convin_bwd_kernel<5, false>, 5, dim3(1, 8, B)); }
+        else          { if (mask) go(convin_bwd_kernel<1, true>, 1, dim3(5, 8, B)); else go(convin_bwd_kernel<1, false>, 1, dim3(5, 8, B)); }
         GIGA_LAUNCH(convin_bwd_reduce_kernel, dim3(CB_PART, 2), dim3(256), 0, s, part, B, nxp, grads + po.conv_in_w,
                            grads + po.conv_in_b);
     }
@@ -1437,9 +1452,9 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
 }
 
 int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws, float* gplanes,
-                            uint8_t* gws, float* grads, int head_present, int B, hipStream_t s, bool bf16_convs) {
-    return bf16_convs ? encoder_backward_impl<MATH_BF16>(tsdf, blob, bwd_blob, fws, gplanes, gws, grads, head_present, B, s)
-                      : encoder_backward_impl<MATH_NATIVE>(tsdf, blob, bwd_blob, fws, gplanes, gws, grads, head_present, B, s);
+                            uint8_t* gws, float* grads, int head_present, int B, hipStream_t s, bool bf16_convs, bool convin_mask) {
+    return bf16_convs ? encoder_backward_impl<MATH_BF16>(tsdf, blob, bwd_blob, fws, gplanes, gws, grads, head_present, B, s, convin_mask)
+                      : encoder_backward_impl<MATH_NATIVE>(tsdf, blob, bwd_blob, fws, gplanes, gws, grads, head_present, B, s, convin_mask);
 }
 
 }  // namespace giga

@@ -163,7 +163,7 @@ class GigaFunction(torch.autograd.Function):
             sb = state.acquire(B, N, M)
             s = _capi.stream_ptr(dev)
             _capi.check(L.giga_encoder_forward(_capi.ptr(x), _capi.ptr(state.blob), _capi.ptr(sb.nhwc), None, B,
-                                               _capi.ENC_BF16 if state.bf16 else 0,
+                                               (_capi.ENC_BF16 if state.bf16 else 0) | _capi.CONVIN_MASK,
                                                _capi.ptr(sb.ws), sb.ws.numel(), s), "giga_encoder_forward")
             hp = state.head_present
             o = [torch.empty((B, N), device=dev) if hp & 1 and N > 0 else None,
@@ -212,7 +212,7 @@ class GigaFunction(torch.autograd.Function):
                 _capi.ptr(x), _capi.ptr(state.blob), _capi.ptr(state.bwd_blob), _capi.ptr(sb.ws), _capi.ptr(sb.nhwc),
                 _capi.ptr(p), _capi.ptr(p_tsdf), _ptr_array(outs), _ptr_array(douts), _capi.ptr(grads),
                 grads.numel(), state.head_present | state.bwd_flags | (_capi.BF16_CONVS if ctx.bf16 else 0) |
-                (_capi.BF16_DECODER if ctx.bf16_dec else 0), B, N, M,
+                (_capi.BF16_DECODER if ctx.bf16_dec else 0) | _capi.CONVIN_MASK_BWD, B, N, M,
                 _capi.ptr(sb.wsb), sb.wsb.numel(),
                 _capi.stream_ptr(dev)), "giga_backward")
         if state.data_parallel:

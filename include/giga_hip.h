@@ -157,6 +157,10 @@ int giga_decoder_forward(const void* planes_nhwc, const float* p, const void* pa
  *   this call; the environment variable GIGA_CONV32=1 / 0 does the same for a whole process (the flag of a call wins). */
 #define GIGA_CONV32_UNET 128
 #define GIGA_CONV16_UNET 256
+/* GIGA_CONVIN_MASK, OR-ed into `precision` (0 or 3) of giga_encoder_forward*: a TRAINING forward -- conv_in also stores the sign bits of
+ * its pre-activations (10 MB at 32 scenes, in the encoder workspace), and giga_backward called with GIGA_CONVIN_MASK_BWD on that workspace
+ * takes the ReLU mask of conv_in from them instead of recomputing the convolution (8 instead of 15 MFMAs per unit). */
+#define GIGA_CONVIN_MASK 512
 
 /* Inference fast path for the FIXED QUERY LATTICE of VGNImplicit (detection_implicit.py:28-31,107):
  * the R^3 points meshgrid(lin, lin, lin, 'ij') with z fastest, shared by all B scenes.  Each plane is
@@ -202,6 +206,8 @@ int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, cons
  * bf16 arithmetic; the backward recomputes it bit for bit).  Operands (features, activations, gradients, weights) are rounded to
  * bf16 once, accumulation and the residual stream are fp32, fc_p / the biases are carried as hi + lo bf16 pairs. */
 #define GIGA_BF16_DECODER 64
+/* GIGA_CONVIN_MASK_BWD, OR-ed into giga_backward's head_present: enc_workspace_fwd comes from a forward with GIGA_CONVIN_MASK. */
+#define GIGA_CONVIN_MASK_BWD 128
 /* bf16 images of the convolution fragments, derived ON THE DEVICE from the fp32 fragments of the same blob(s) after
  * giga_repack_device (either pointer may be NULL).  giga_pack_weights / giga_pack_bwd_weights fill them on the host too. */
 int giga_derive_bf16_fragments(void* packed_dev, void* bwd_packed_dev, void* stream);

@@ -611,3 +611,38 @@ def test_bf16_weight_gradient_kernels_with_rounded_operands(sd7, B):
         wb = dy32.double().sum(dim=(0, 2, 3))
         assert float((gb - wb).abs().max()) <= 2e-5 * max(1.0, float(wb.abs().max())) + 1e-6 * float(dy32.double().abs().sum(dim=(0, 2, 3)).max()), key
     print("bf16 weight gradients with rounded operands: worst error / tolerance", worst)
+
+
+def test_conv_in_relu_mask_of_the_training_forward(sd7):
+    """GIGA_CONVIN_MASK: the training forward leaves the sign bits of conv_in's pre-activations in the encoder workspace (the
+    backward takes its ReLU mask from them instead of recomputing the convolution).  Layout (csrc/giga_encoder.hip): per
+    (scene, workgroup row wy = 2 * iy-group + channel half, ix) and lane (j = lane & 15, g = lane >> 4) one 16-byte word; value
+    k = (zg * 5 + ip) * 4 + r -- channel 16 (wy & 1) + j, iy = 10 (wy >> 1) + 2 ip + (g >> 1), iz = 8 zg + 4 (g & 1) + r -- in
+    word k >> 5 at bit (n - 1 - (k & 31)), n = 32 (4 in the last word); a set bit = negative.  Against the oracle's Conv3d
+    (voxels.py:36,106-107) for both batch regimes of the kernel (5 x-parts below 32 scenes, 1 from 32 up)."""
+    import ctypes
+    import torch.nn.functional as F
+    from giga_amd import _capi
+    dev = torch.device("cuda:0")
+    for B in (3, 32):
+        x, pos, pos_occ, y = _batch(700, B, 64)
+        net = networks.get_network("giga"); net.load_state_dict(sd7); net = net.to(dev).train()
+        net(x.to(dev), pos.to(dev), p_tsdf=pos_occ.to(dev))
+        sb = net._train_state._pool[0]
+        n = B * 8 * 40 * 64 * 4
+        total = _capi.lib().giga_encoder_workspace_bytes(B, 0)
+        words = sb.ws[total - ((n * 4 + 255) // 256 * 256):][:n * 4].view(torch.int32).cpu().numpy().view(np.uint32).reshape(B, 8, 40, 64, 4)
+        pre = F.conv3d(x[:, None], sd7["encoder.conv_in.weight"], sd7["encoder.conv_in.bias"], padding=1).numpy()   # (B, 32, ix, iy, iz)
+        bad = tot = 0
+        lane = np.arange(64); j = lane & 15; g = lane >> 4
+        for k in range(100):
+            zg, ip, r = k // 20, (k // 4) % 5, k % 4
+            wd, bit = k >> 5, (3 if k >= 96 else 31) - (k & 31)
+            got = (words[..., wd] >> np.uint32(bit)) & 1                      # (B, 8, 40, 64)
+            for wy in range(8):
+                ch = 16 * (wy & 1) + j; iy = 10 * (wy >> 1) + 2 * ip + (g >> 1); iz = 8 * zg + 4 * (g & 1) + r
+                ref = pre[:, ch, :, iy, iz].transpose(1, 2, 0)                # (lanes, B, ix) -> (B, ix, lanes)
+                want = ref < 0
+                sure = np.abs(ref) > 1e-5                                     # (fp32 summation order near zero)
+                bad += int(((got[:, wy] != want) & sure).sum()); tot += int(sure.sum())
+        assert bad == 0, (B, bad, tot)
