@@ -42,6 +42,7 @@ _SIGNATURES = {
     "giga_packed_bytes": (ctypes.c_size_t, []),
     "giga_pack_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_size_t]),
+    "giga_packed_check": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]),
     "giga_pack_map": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]),
     "giga_repack_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
                                           ctypes.c_void_p]),
@@ -223,4 +224,5 @@ def pack_weights(flat_params_cpu, head_present):
     blob = torch.empty(L.giga_packed_bytes(), dtype=torch.uint8)
     check(L.giga_pack_weights(ptr(flat), flat.numel(), head_present, ptr(blob), blob.numel()),
           "giga_pack_weights")
+    check(L.giga_packed_check(ptr(blob), blob.numel(), 0), "giga_packed_check")      # (the stamp every uploaded blob must carry)
     return blob

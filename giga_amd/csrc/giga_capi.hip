@@ -16,6 +16,7 @@ int pack_map_host(int head_present, int32_t* map, size_t nwords);
 size_t bwd_packed_bytes();
 int pack_bwd_host(const float* P, size_t n_params, int head_present, uint8_t* blob, size_t blob_bytes);
 int pack_bwd_map_host(int head_present, int32_t* map, size_t nwords);
+int packed_check_host(const uint8_t* blob, size_t bytes, int backward);
 // giga_encoder_bwd.hip / giga_decoder_bwd.hip
 struct BwdWs { size_t gA6, gA5, gC1, gA4, gA3, gC0, gS2, gA2, gQ1, gS1, gA1, gQ0, gS0, gA0, gP0, WG, total; };
 BwdWs enc_bwd_workspace(int B);
@@ -211,7 +212,13 @@ int giga_repack_device2(const float* params_dev, const int32_t* map_fwd_dev, voi
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
+static_assert(GIGA_ABI_VERSION == PACK_ABI_VERSION, "the blob stamp carries the ABI version");
 int giga_abi_version(void) { return GIGA_ABI_VERSION; }
+
+int giga_packed_check(const void* packed_host, size_t bytes, int backward) {
+    if (!packed_host) return -1;
+    return packed_check_host(static_cast<const uint8_t*>(packed_host), bytes, backward ? 1 : 0);
+}
 
 const char* giga_strerror(int code) {
     switch (code) {
@@ -223,6 +230,7 @@ const char* giga_strerror(int code) {
         case -5: return "unsupported precision";
         case -6: return "null pointer for a requested output";
         case -7: return "more than GIGA_MAX_SCENES scenes in one call";
+        case -8: return "packed blob was not produced by this version of the library (repack the weights)";
         case -10: return "HIP launch failed";
         default: return "unknown error";
     }

@@ -160,6 +160,7 @@ struct PackOff {
     size_t dec16s[NHEADS], dec16sf[NHEADS];  // f16x3 split images (plain, folded)
     size_t convin_ws;       // f16x3 split conv_in B operands: [2 channel halves][hi, lo] fragments of v_mfma_f32_16x16x32_f16
     size_t dect[NHEADS];    // bf16 forward images of the bf16 training decoder (giga_dect.h), derived from dec32
+    size_t stamp;           // PackStamp: magic, ABI version, blob size (giga_packed_check)
     size_t total;
 };
 
@@ -204,6 +205,7 @@ inline PackOff pack_offsets() {
         o.conv[l].c32b = at; at += (size_t)o.conv[l].nfragc32 * FRAG;
     }
     for (int h = 0; h < NHEADS; ++h) { o.dect[h] = at; at += align_up(DEC16_BYTES, 256); }     // round 5 (ABI 2)
+    o.stamp = at; at += 256;
     o.total = at;
     return o;
 }
@@ -220,6 +222,7 @@ struct BwdPackOff {
     size_t dec[NHEADS];          // transposed decoder matrices of head h
     size_t convbf[NCONV];        // bf16 images of the dgrad fragments (f16 fragment layout, nfrag[l] / 2 fragments)
     size_t dect[NHEADS];         // bf16 transposed decoder matrices of the bf16 training decoder (giga_dect.h), derived from dec
+    size_t stamp;                // PackStamp
     size_t total;
 };
 // decoder backward image per head: 5 blocks x (Wc^T: 3 row blocks x 4 frags, W0^T 4 frags, W1^T 4 frags)
@@ -240,9 +243,16 @@ inline BwdPackOff bwd_pack_offsets() {
     for (int h = 0; h < NHEADS; ++h) { o.dec[h] = at; at += DECB_BYTES; }
     for (int l = 0; l < NCONV; ++l) { o.convbf[l] = at; at += (size_t)(o.nfrag[l] / 2) * FRAG; }
     for (int h = 0; h < NHEADS; ++h) { o.dect[h] = at; at += (size_t)(NBLK * 10 + 1) * FRAG; }  // DECT_BWD_BYTES (giga_dect.h)
+    o.stamp = at; at += 256;
     o.total = at;
     return o;
 }
+
+// Last 256 bytes of both blobs: which layout the blob was packed for.  The layout changes with the ABI version (new images are appended,
+// slot orders change); a blob of another version run through this library reads weights from the wrong places, silently.
+// giga_packed_check() validates a HOST copy before it is uploaded; the kernels cannot afford to.
+struct PackStamp { char magic[8]; int abi_version; int backward; unsigned long long total; };
+constexpr int PACK_ABI_VERSION = 2;               // == GIGA_ABI_VERSION (include/giga_hip.h; giga_capi.hip static_asserts it)
 
 // feature index held in D-register r of lane-half hi after a 32x32 MFMA with weights as the A
 // operand (rows = output features):  row = (r&3) + 8*(r>>2) + 4*hi   (C/D map, dtype independent)

@@ -260,6 +260,22 @@ static void pack_conv(const float* P, const ParamOff& po, const PackOff& ko, int
             }
 }
 
+static void write_stamp(uint8_t* at, int backward, size_t total) {
+    PackStamp st{};
+    std::memcpy(st.magic, "GIGAPACK", 8);
+    st.abi_version = PACK_ABI_VERSION; st.backward = backward; st.total = total;
+    std::memcpy(at, &st, sizeof st);
+}
+// 0: a blob of this library's layout; -8 otherwise
+int packed_check_host(const uint8_t* blob, size_t bytes, int backward) {
+    const size_t total = backward ? bwd_pack_offsets().total : pack_offsets().total;
+    const size_t stamp = backward ? bwd_pack_offsets().stamp : pack_offsets().stamp;
+    if (bytes != total) return -8;
+    PackStamp st;
+    std::memcpy(&st, blob + stamp, sizeof st);
+    return std::memcmp(st.magic, "GIGAPACK", 8) == 0 && st.abi_version == PACK_ABI_VERSION && st.backward == backward && st.total == total ? 0 : -8;
+}
+
 size_t packed_bytes() { return pack_offsets().total; }
 
 // returns 0 on success
@@ -335,6 +351,7 @@ int pack_weights_host(const float* P, size_t n_params, int head_present, uint8_t
             pack_head16s(Pf.data(), ho, HEAD_OUT[h], blob + ko.dec16sf[h]);
         }
     }
+    write_stamp(blob + ko.stamp, 0, ko.total);
     return 0;
 }
 
@@ -412,6 +429,7 @@ int pack_bwd_host(const float* P, size_t n_params, int head_present, uint8_t* bl
                         f2bf(f32[((size_t)(2 * i16 + c / 16) * 64 + ((c % 16) / 4) * 16 + j) * 4 + c % 4]);
                 }
     }
+    write_stamp(blob + bo.stamp, 1, bo.total);
     return 0;
 }
 

@@ -66,6 +66,13 @@ size_t giga_packed_bytes(void);
 int giga_pack_weights(const float* params_host, size_t n_params, int head_present,
                       void* packed_host, size_t packed_bytes);
 
+/* The blob layout belongs to the ABI version: new images are appended and slot orders change between versions, and the compute entry
+ * points take no blob size -- a blob packed by another version would be read at the wrong offsets, silently.  Blobs are not
+ * portable across versions: REPACK from the parameters after an upgrade.  Both packers stamp the last 256 bytes of their blob (magic,
+ * ABI version, size); giga_packed_check validates a HOST copy (`backward` != 0: a giga_pack_bwd_weights blob) before it is uploaded:
+ * 0, or -8 for a foreign / truncated / stale blob.  (A blob rebuilt on the device by giga_repack_device carries no stamp.) */
+int giga_packed_check(const void* packed_host, size_t bytes, int backward);
+
 /* Training support (scripts/train_giga.py:198-211: weights change every optimizer step): the fp32
  * words of the blob are pure gathers of single parameters.  giga_pack_map fills a HOST int32 map with one
  * entry per 4-byte blob word (>= 0 parameter index, -1 constant zero, -2 not an fp32 word);

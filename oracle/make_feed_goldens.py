@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE, build container only (needs /root/reference).  Golden G12: the reference's OWN
 `DatasetVoxelOccFile.__getitem__` (src/vgn/dataset_voxel.py:55-106) on the synthetic on-disk dataset of
-oracle/make_dataset.py (seed 1), with torch/numpy seeded before every item.
+giga_amd/synth.py (write_training_set) (seed 1), with torch/numpy seeded before every item.
 
     python -m oracle.make_feed_goldens        ->  tests/golden/g12_dataset_items.npz, g13_dataset_items_augmented.npz (augment=True)
 """
@@ -11,7 +11,8 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from oracle import make_dataset, ref_bootstrap
+from giga_amd import synth as make_dataset
+from oracle import ref_bootstrap
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "g12_dataset_items.npz")
 OUT_AUG = os.path.join(os.path.dirname(OUT), "g13_dataset_items_augmented.npz")
@@ -32,7 +33,7 @@ def reference_items(root, raw_root, items, num_point_occ, augment=False):
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         root, raw = os.path.join(tmp, "data"), os.path.join(tmp, "raw")
-        make_dataset.write_dataset(root, raw, seed=DATASET_SEED, occ_files=(1, 1))     # one occupancy file per scene: the
+        make_dataset.write_training_set(root, raw, seed=DATASET_SEED, occ_files=(1, 1))     # one occupancy file per scene: the
         n, items = reference_items(root, raw, ITEMS, NUM_POINT_OCC)                     # glob order cannot matter
         _, aug_items = reference_items(root, raw, ITEMS, NUM_POINT_OCC, augment=True)   # G13: the same items with augment=True
     rec = {"n": n, "items": np.array(ITEMS), "num_point_occ": NUM_POINT_OCC, "dataset_seed": DATASET_SEED}

@@ -253,3 +253,20 @@ def test_ordered_param_cache_tracks_replaced_parameters(sd7):
     assert torch.equal(new[0], sd7["decoder_qual.fc_c.0.weight"])
     net.double()                                                       # _apply drops the cache as well
     assert net._ordered_params() is not new and net._ordered_params()[0].dtype == torch.float64
+
+
+def test_packed_blob_stamp_and_check():
+    """Both packers stamp their blob (magic, ABI version, size) and giga_packed_check refuses a blob of another layout: a stale
+    blob from a previous build would otherwise be read at the wrong offsets, silently (the compute entry points take no size)."""
+    import torch
+    from giga_amd import weights
+    lib = _capi.lib()
+    flat = torch.cat([v.reshape(-1) for v in weights.make_state_dict(3).values()])
+    blob, bblob = _capi.pack_weights(flat, 15), _capi.pack_bwd_weights(flat, 15)
+    assert lib.giga_packed_check(_capi.ptr(blob), blob.numel(), 0) == 0
+    assert lib.giga_packed_check(_capi.ptr(bblob), bblob.numel(), 1) == 0
+    assert lib.giga_packed_check(_capi.ptr(bblob), bblob.numel(), 0) == -8          # a backward blob is not a forward blob
+    assert lib.giga_packed_check(_capi.ptr(blob), blob.numel() - 256, 0) == -8      # truncated (e.g. a blob of the previous layout)
+    stale = blob.clone(); stale[-256 + 8] = 1                                       # ABI version 1 in the stamp
+    assert lib.giga_packed_check(_capi.ptr(stale), stale.numel(), 0) == -8
+    assert lib.giga_packed_check(None, 0, 0) == -1 and lib.giga_strerror(-8).startswith(b"packed blob was not produced")

@@ -1,5 +1,5 @@
 """SURVEY 8f-3, reader half: the batched reader of the reference's training data (giga_amd/dataset.py) against golden G12
-(the reference's own DatasetVoxelOccFile.__getitem__ on the synthetic on-disk dataset of oracle/make_dataset.py) and, when
+(the reference's own DatasetVoxelOccFile.__getitem__ on the synthetic on-disk dataset of giga_amd/synth.py (write_training_set)) and, when
 /root/reference is present, against the live reference class including the random occupancy-file choice."""
 import os
 
@@ -8,7 +8,8 @@ import pytest
 import torch
 
 from giga_amd import dataset
-from oracle import make_dataset, ref_bootstrap
+from giga_amd import synth as make_dataset
+from oracle import ref_bootstrap
 
 
 def _same_item(a, b):
@@ -23,7 +24,7 @@ def _same_item(a, b):
 def test_items_match_golden_g12(tmp_path, golden):
     g = golden("g12_dataset_items.npz")
     root, raw = str(tmp_path / "data"), str(tmp_path / "raw")
-    n = make_dataset.write_dataset(root, raw, seed=int(g["dataset_seed"]), occ_files=(1, 1))
+    n = make_dataset.write_training_set(root, raw, seed=int(g["dataset_seed"]), occ_files=(1, 1))
     ds = dataset.GraspOccDataset(root, raw, num_point_occ=int(g["num_point_occ"]))
     assert len(ds) == n == int(g["n"])
     for k in g["items"]:
@@ -40,7 +41,7 @@ def test_items_match_golden_g12(tmp_path, golden):
 
 def test_batches_and_epoch_iteration(tmp_path):
     root, raw = str(tmp_path / "data"), str(tmp_path / "raw")
-    n = make_dataset.write_dataset(root, raw, n_scenes=4, grasps_per_scene=3, seed=2)
+    n = make_dataset.write_training_set(root, raw, n_scenes=4, grasps_per_scene=3, seed=2)
     ds = dataset.GraspOccDataset(root, raw, num_point_occ=50, workers=3)
     torch.manual_seed(5); np.random.seed(6)
     b = ds.batch([4, 1, 7])                                   # "global" rng: item by item, like a 0-worker DataLoader
@@ -75,7 +76,7 @@ def test_shared_memory_ring_delivers_the_same_batches(tmp_path):
     """GraspOccRing (reader processes writing into shared-memory slots) == GraspOccBatches(workers > 0) for the same seed,
     in order, including the short last batch and a second (reshuffled) epoch; slots are recycled through release()."""
     root, raw = str(tmp_path / "data"), str(tmp_path / "raw")
-    n = make_dataset.write_dataset(root, raw, n_scenes=5, grasps_per_scene=5, seed=6)
+    n = make_dataset.write_training_set(root, raw, n_scenes=5, grasps_per_scene=5, seed=6)
     ds = dataset.GraspOccDataset(root, raw, num_point_occ=40, workers=2)
     ring = dataset.GraspOccRing(ds, 4, workers=3, shuffle=True, seed=11, slots=5)
     ref = dataset.GraspOccBatches(ds, 4, shuffle=True, seed=11, workers=2)
@@ -103,7 +104,7 @@ def test_shared_memory_ring_survives_an_abandoned_epoch(tmp_path):
     starve the ring.  Three abandoned passes, then two complete ones that equal
     GraspOccBatches for the same seed and epoch count."""
     root, raw = str(tmp_path / "data"), str(tmp_path / "raw")
-    n = make_dataset.write_dataset(root, raw, n_scenes=6, grasps_per_scene=6, seed=8)
+    n = make_dataset.write_training_set(root, raw, n_scenes=6, grasps_per_scene=6, seed=8)
     ds = dataset.GraspOccDataset(root, raw, num_point_occ=40, workers=2)
     ring = dataset.GraspOccRing(ds, 4, workers=3, shuffle=True, seed=21, slots=4)
     ref = dataset.GraspOccBatches(ds, 4, shuffle=True, seed=21, workers=2)
@@ -139,7 +140,7 @@ def test_shared_memory_ring_survives_an_abandoned_epoch(tmp_path):
 def test_items_match_live_reference_class(tmp_path):
     from oracle.make_feed_goldens import reference_items
     root, raw = str(tmp_path / "data"), str(tmp_path / "raw")
-    make_dataset.write_dataset(root, raw, seed=4, occ_files=(2, 4))          # several occupancy files: the random pick matters
+    make_dataset.write_training_set(root, raw, seed=4, occ_files=(2, 4))          # several occupancy files: the random pick matters
     idx = (0, 5, 9, 17, 23)
     _, ref = reference_items(root, raw, idx, 128)
     ds = dataset.GraspOccDataset(root, raw, num_point_occ=128)
@@ -155,7 +156,7 @@ def test_augmented_items_match_golden_g13(tmp_path, golden):
     values AND dtypes must match, the numpy draws happen in the reference's order (choice(4), uniform, then the point sample)."""
     g = golden("g13_dataset_items_augmented.npz")
     root, raw = str(tmp_path / "data"), str(tmp_path / "raw")
-    n = make_dataset.write_dataset(root, raw, seed=int(g["dataset_seed"]), occ_files=(1, 1))
+    n = make_dataset.write_training_set(root, raw, seed=int(g["dataset_seed"]), occ_files=(1, 1))
     ds = dataset.GraspOccDataset(root, raw, num_point_occ=int(g["num_point_occ"]), augment=True)
     plain = dataset.GraspOccDataset(root, raw, num_point_occ=int(g["num_point_occ"]))
     assert len(ds) == n == int(g["n"])
@@ -191,7 +192,7 @@ def test_augmented_items_match_golden_g13(tmp_path, golden):
 def test_augmented_items_match_live_reference_class(tmp_path):
     from oracle.make_feed_goldens import reference_items
     root, raw = str(tmp_path / "data"), str(tmp_path / "raw")
-    make_dataset.write_dataset(root, raw, seed=5, occ_files=(2, 3))
+    make_dataset.write_training_set(root, raw, seed=5, occ_files=(2, 3))
     idx = (1, 6, 12, 20)
     _, ref = reference_items(root, raw, idx, 96, augment=True)
     ds = dataset.GraspOccDataset(root, raw, num_point_occ=96, augment=True)

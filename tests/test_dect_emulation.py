@@ -27,8 +27,8 @@ def _images(sd):
     blob = _capi.pack_weights(flat, 15).numpy()
     bblob = _capi.pack_bwd_weights(flat, 15).numpy()
     up = lambda x: (x + 255) // 256 * 256  # noqa: E731
-    fwd = [blob[blob.size - (4 - h) * up(FWD_BYTES):][:FWD_BYTES] for h in range(4)]        # the last regions of both blobs
-    bwd = [bblob[bblob.size - (4 - h) * BWD_BYTES:][:BWD_BYTES] for h in range(4)]
+    fwd = [blob[blob.size - 256 - (4 - h) * up(FWD_BYTES):][:FWD_BYTES] for h in range(4)]   # the last regions of both blobs (before the stamp)
+    bwd = [bblob[bblob.size - 256 - (4 - h) * BWD_BYTES:][:BWD_BYTES] for h in range(4)]
     return fwd, bwd
 
 

@@ -69,21 +69,55 @@ def test_decoder_heads_on_foreign_planes_g2b(net, dev, sd7, golden, prec, tol):
             assert maxerr(out, g["raw_" + h]) < tol * max(1.0, float(np.abs(g["raw_" + h]).max())), h
 
 
-# (plain 'fp16' is the mode OUTSIDE the 1e-3 contract: its envelope here is 1.5e-2 -- the quaternion output sits at 1.0-1.1e-2 against
-#  the oracle, a few per cent up or down with the summation order of the f16 kernels: conv16 / conv32 U-Net, tap order of conv_in)
-@pytest.mark.parametrize("prec,tol", [("fp32", 1e-4), ("fp16x3", 1e-4), ("fp16", 1.5e-2)])
-def test_model_forward_g2(net, dev, sd7, golden, prec, tol):
+# Plain 'fp16' is the mode OUTSIDE the 1e-3 contract.  Its stated envelope is 1e-2 for the conv16 U-Net kernels; the conv32 kernels
+# (another summation order: 32x32x16 register tiles, K chunks of 16 channels) put the quaternion output of this golden at 1.0-1.1e-2,
+# so the kernel is a PARAMETER of the test and conv32 carries its own bound (1.5e-2) instead of a blanket one.
+@pytest.mark.parametrize("prec,tol,kernel", [("fp32", 1e-4, None), ("fp16x3", 1e-4, None), ("fp16", 1e-2, "conv16"), ("fp16", 1.5e-2, "conv32")])
+def test_model_forward_g2(net, dev, sd7, golden, prec, tol, kernel):
     net.set_precision(prec)
+    if kernel is not None:
+        net.set_unet_kernel(kernel)
     g = golden("g2_decoder.npz")
     x = torch.from_numpy(synth.tsdf_batch(0, 2)).to(dev)
     p = torch.from_numpy(synth.query_points(0, 2, 2048, stream=1, half_width=0.6)).to(dev)
-    with torch.no_grad():
-        qual, rot, width, tsdf = net(x, p, p_tsdf=p)
+    try:
+        with torch.no_grad():
+            qual, rot, width, tsdf = net(x, p, p_tsdf=p)
+    finally:
+        if kernel is not None:
+            net.set_unet_kernel("auto")
     assert qual.shape == (2, 2048) and rot.shape == (2, 2048, 4) and width.shape == (2, 2048) and tsdf.shape == (2, 2048)
     assert maxerr(qual, g["qual"]) < tol
     assert maxerr(rot, g["rot"]) < tol
     assert maxerr(width, g["width"]) < tol * 2
     assert maxerr(tsdf, g["tsdf"]) < tol * 2
+
+
+@pytest.mark.parametrize("prec,tol", [("fp16x3", 2e-5), ("fp16", 1.5e-2)])
+def test_auto_kernel_choice_across_the_16_scene_threshold(net, dev, sd7, prec, tol):
+    """`auto` runs the f16-class U-Net on conv32 up to 16 scenes and on conv16 beyond (include/giga_hip.h): the same scene evaluated
+    in a batch of 16 and in a batch of 17 goes through different kernels.  Both stay inside the mode's envelope of each other
+    (f16x3: 2e-5 -- fp32-grade either way; plain f16: the f16 envelope), a forced kernel makes the two batches agree bit for bit,
+    and giga_encoder_last_path reports which kernels ran."""
+    from giga_amd import _capi
+    net.set_precision(prec)
+    x17 = torch.from_numpy(synth.tsdf_batch(40, 17)).to(dev)
+    p17 = torch.from_numpy(synth.query_points(40, 17, 512, stream=1)).to(dev)
+    L = _capi.lib()
+    with torch.no_grad():
+        a = net(x17[:16], p17[:16]); path16 = L.giga_encoder_last_path()
+        b = net(x17, p17); path17 = L.giga_encoder_last_path()
+        assert (path16 & _capi.PATH_CONV32) and not (path17 & _capi.PATH_CONV32), (path16, path17)
+        for u, v in zip(a, b):
+            scale = max(1.0, float(v.abs().max()))
+            assert maxerr(u[0], v[0].cpu().numpy()) <= tol * scale
+        net.set_unet_kernel("conv16")
+        try:
+            c = net(x17[:16], p17[:16]); d = net(x17, p17)
+        finally:
+            net.set_unet_kernel("auto")
+        for u, v in zip(c, d):
+            assert torch.equal(u[0], v[0])
 
 
 @pytest.mark.parametrize("prec,tol", [("fp32", 1e-4), ("fp16x3", 1e-4), ("fp16", 1e-2)])
