@@ -629,7 +629,8 @@ def bench_c4(net, dev, L, _capi, synth, decode_heads, prec, Bc=32, steps=10):
     ach = flops / (dec_ms * 1e-3) / 1e12
     net.set_precision("fp32")
     split = prec == "fp16x3"
-    tr, tr_src = traffic_lookup("c4step_x3" if split else "c4step", "decoder_lat_kernel") if Bc == 32 else (None, None)
+    mixed = prec == "fp16x3+fp16"          # f16x3 encoder (fp32 planes) under the plain-f16 lattice decoder
+    tr, tr_src = traffic_lookup("c4step_x3" if split else "c4step", "decoder_lat_kernel") if Bc == 32 and not mixed else (None, None)
     kname = "decoder_lat_kernel" if (split or Bc >= 4) else "decoder_f16s_kernel"
     roof = {"kernel": kname, "bound": "mfma", "achieved": ach,
             "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": tr, "traffic_source": tr_src,
@@ -638,7 +639,7 @@ def bench_c4(net, dev, L, _capi, synth, decode_heads, prec, Bc=32, steps=10):
             "empty_event_bracket_ms": bracket_ms,
             "frac_net_of_bracket": flops / (max(dec_ms - bracket_ms, 1e-6) * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS}
     if kname == "decoder_lat_kernel":
-        r = ISSUED_PER_ALGORITHMIC[prec]
+        r = ISSUED_PER_ALGORITHMIC["fp16" if mixed else prec]
         roof["issued_mfma_tflops"] = ach * r
         roof["issued_mfma_frac_of_peak"] = ach * r / PEAK_F16_MFMA_TFLOPS
         roof["note"] = ("`achieved`/`frac` count ALGORITHMIC FLOPs (154 560 per point, SURVEY 8d).  The kernel evaluates the xz / xy thirds of "
@@ -648,11 +649,13 @@ def bench_c4(net, dev, L, _capi, synth, decode_heads, prec, Bc=32, steps=10):
     return {
         "workload": f"c4: batch={Bc} scenes x the 64000-point inference lattice, 3 grasp heads, "
                     + ("f16x3 split-operand f16-MFMA encoder and decoder (fp32-grade, <= 6e-6 vs oracle)" if split else
+                       "f16x3 split-operand encoder (fp32-grade planes) + plain f16 MFMA decoder (lattice path)" if mixed else
                        "f16 MFMA decoder (lattice path) + f16 encoder"),
         "checked_vs_oracle": checked,
         "scenes_per_sec": Bc * steps / el, "query_points_per_sec": Bc * steps * N / el,
         "ms_per_step": el / steps * 1e3, "step_ms_median": float(np.median(per_step)), "step_ms_max": float(np.max(per_step)),
-        "dtype": "f16x3 split operands / f32 accumulate" if split else "f16 operands / f32 accumulate",
+        "dtype": "f16x3 split operands / f32 accumulate" if split else
+                 "encoder f16x3 split operands, decoder f16 operands / f32 accumulate" if mixed else "f16 operands / f32 accumulate",
         "roofline": roof,
     }
 
@@ -698,7 +701,7 @@ def bench_c4_graph(net, dev, synth, decode_heads, prec, Bc=1, replays=300):
 
 
 _C4_ORACLE = {}
-C4_TOL = {"fp32": 1e-4, "fp16x3": 1e-4, "fp16": 1e-2}       # the tolerances of tests/test_gpu_c4_shapes.py (rot, width: x2)
+C4_TOL = {"fp32": 1e-4, "fp16x3": 1e-4, "fp16": 1e-2, "fp16x3+fp16": 5e-3}       # the tolerances of tests/test_gpu_c4_shapes.py (rot, width: x2)
 
 
 def check_c4_scene(out, prec, synth):
@@ -816,6 +819,10 @@ def bench_c4_all(net, dev, L, _capi, synth, decode_heads):
         out[key + "_sweep"] = sweep
         out[key + "_single_scene_graph_replay"] = bench_c4_graph(net, dev, synth, decode_heads, prec)
         out[key + "_generic_queries"] = bench_c4_generic(net, dev, L, _capi, synth, decode_heads, prec)
+    # the mixed mode: the f16x3 encoder (fp32-grade planes) under the plain-f16 lattice decoder -- the throughput decoder without
+    # plain f16's encoder error.  Its errors against the oracle are the f16 decoder's own floor (tests/test_f16_error_budget.py)
+    out["c4_mixed"] = bench_c4(net, dev, L, _capi, synth, decode_heads, "fp16x3+fp16")
+    out["c4_mixed"]["within_1e-3_contract"] = all(v < 1e-3 for v in out["c4_mixed"]["checked_vs_oracle"]["max_abs_err"].values())
     # Which of the two c4 modes is inside the north star's 1e-3: ONLY the split mode.  Plain f16 (`c4`) is a throughput mode: its
     # head outputs are 1e-3 ... 1e-2 off the fp32 reference (11-bit operands in encoder and decoder; tests/test_f16_error_budget.py),
     # so the >= 40 % of MFMA peak it reaches is not a contract-grade figure; `c4_fp16x3` (<= 1e-5) is.

@@ -29,9 +29,14 @@ CONV16_UNET = 256        # GIGA_CONV16_UNET: ... on the conv16 kernels
 PATH_PERSISTENT, PATH_CONV32, PATH_FUSED_PAIRS = 1, 2, 4          # giga_encoder_last_path()
 MAX_SCENES = 3072        # GIGA_MAX_SCENES: scenes per encoder / training call (error -7 beyond)
 HEAD_BITS = {"decoder_qual": 1, "decoder_rot": 2, "decoder_width": 4, "decoder_tsdf": 8}
-PRECISION = {"fp32": 0, "fp16": 1, "fp16x3": 2, "bf16": 3}     # include/giga_hip.h `precision` (3: encoder only)
-PLANE_DTYPE = {0: torch.float32, 1: torch.float16, 2: torch.float32, 3: torch.float32}   # element type of the NHWC planes
-DECODER_PRECISION = {0: 0, 1: 1, 2: 2, 3: 0}         # "bf16" = bf16 U-Net convolutions; the decoders run their fp32 kernels
+PLANES_FP32 = 1024       # GIGA_PLANES_FP32: fp32 planes into the plain-f16 lattice decoder
+# include/giga_hip.h `precision` (3: the training forward's arithmetic).  "fp16x3+fp16" (4, Python-side only): the f16x3 encoder
+# (fp32-grade planes) under the plain-f16 LATTICE decoder; its generic-query decoder is the f16x3 one
+PRECISION = {"fp32": 0, "fp16": 1, "fp16x3": 2, "bf16": 3, "fp16x3+fp16": 4}
+ENCODER_PRECISION = {0: 0, 1: 1, 2: 2, 3: 3, 4: 2}
+PLANE_DTYPE = {0: torch.float32, 1: torch.float16, 2: torch.float32, 3: torch.float32, 4: torch.float32}   # element type of the NHWC planes
+DECODER_PRECISION = {0: 0, 1: 1, 2: 2, 3: 0, 4: 2}   # "bf16" = bf16 U-Net convolutions; the decoders run their fp32 kernels
+LATTICE_PRECISION = {0: 0, 1: 1, 2: 2, 3: 0, 4: 1 | PLANES_FP32}
 
 _lib = None
 

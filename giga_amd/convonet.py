@@ -241,7 +241,7 @@ class LocalVoxelEncoder(nn.Module):
         fold_final: stop before conv_final (unet.py:238); the planes are then only valid for `decode_heads(...,
         folded=True)`, whose head images carry that 1x1 convolution inside fc_c (GIGA_FOLD_FINAL, include/giga_hip.h)."""
         _capi.require_device(x)
-        prec = _capi.PRECISION[precision or self.precision]
+        prec = _capi.ENCODER_PRECISION[_capi.PRECISION[precision or self.precision]]
         if x.dim() != 4 or tuple(x.shape[1:]) != (RES, RES, RES):
             raise ValueError(f"expected a (B,{RES},{RES},{RES}) TSDF batch, got {tuple(x.shape)}")
         x = x.contiguous().float()
@@ -372,7 +372,7 @@ def decode_heads(nhwc, p, blob, head_mask, precision, post, probe=None, folded=F
     LATTICE_STATS["fast" if lat is not None else "generic"] += 1
     if lat is not None:
         lin, R = lat
-        prec = _capi.DECODER_PRECISION[_capi.PRECISION[precision]]
+        prec = _capi.LATTICE_PRECISION[_capi.PRECISION[precision]]
         fold = _capi.FOLD_FINAL if folded else 0
         L = _capi.lib()
         ws = _LATTICE_WS.get((B, R, prec), dev, lambda: L.giga_lattice_workspace_bytes(B, R, prec))
@@ -502,8 +502,10 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
 
     # -- weights ----------------------------------------------------------------------------------
     def set_precision(self, precision):
-        """'fp32' (exact fp32 MFMA, default), 'fp16' (f16 operands, fp32 accumulate: 2-5e-3 on raw logits) or 'fp16x3'
-        (f16 MFMA on split hi/lo operands in encoder and decoders: fp32-grade results, <= 1e-5, at ~5x the fp32-MFMA rate);
+        """'fp32' (exact fp32 MFMA, default), 'fp16' (f16 operands, fp32 accumulate: 2-5e-3 on raw logits), 'fp16x3'
+        (f16 MFMA on split hi/lo operands in encoder and decoders: fp32-grade results, <= 1e-5, at ~5x the fp32-MFMA rate) or
+        'fp16x3+fp16' (the f16x3 encoder under the plain-f16 LATTICE decoder: the throughput decoder without plain f16's encoder error;
+        other query sets take the f16x3 decoder);
         'bf16' = the training step's forward arithmetic (bf16 U-Net convolutions, everything else fp32), ~1e-2."""
         if precision not in _capi.PRECISION:
             raise ValueError(precision)

@@ -59,7 +59,8 @@ int launch_decoder(const DecArgs& a, int precision, hipStream_t s, void* ev0, vo
 int launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps, double wd,
                      int step, hipStream_t s);
 int launch_planes_pack(const float* xz, const float* xy, const float* yz, void* dst, int B, int precision, hipStream_t s);
-int launch_lattice_resample(const void* planes, const float* lin, void* out, int B, int R, int precision, hipStream_t s);
+int launch_lattice_resample(const void* planes, const float* lin, void* out, int B, int R, int precision, hipStream_t s,
+                            bool planes_fp32 = false);
 int launch_planes_unpack(const void* src, float* dst, int B, int precision, hipStream_t s);
 }  // namespace giga
 
@@ -394,7 +395,7 @@ int giga_decoder_forward_probe(const void* planes_nhwc, const float* p, const vo
 }
 
 size_t giga_lattice_workspace_bytes(int B, int R, int precision) {
-    precision &= ~GIGA_FOLD_FINAL;
+    precision &= ~(GIGA_FOLD_FINAL | GIGA_PLANES_FP32);
     if (B <= 0 || R <= 0) return 0;
     return (size_t)3 * B * R * R * CD * (precision == 1 ? 2 : 4);
 }
@@ -405,8 +406,9 @@ int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, cons
                                  void* ev_stop) {
     if (B < 0 || R < 0 || R > 64) return -1;
     const bool fold = (precision & GIGA_FOLD_FINAL) != 0;
-    precision &= ~GIGA_FOLD_FINAL;
-    if (precision < 0 || precision > 2) return -5;
+    const bool planes32 = (precision & GIGA_PLANES_FP32) != 0;        // fp32 planes into the plain-f16 decoder
+    precision &= ~(GIGA_FOLD_FINAL | GIGA_PLANES_FP32);
+    if (precision < 0 || precision > 2 || (planes32 && precision != 1)) return -5;
     if (B == 0 || R == 0 || (head_mask & 15) == 0) return 0;
     if (!planes_nhwc || !lin || !packed || !workspace) return -1;
     if (workspace_bytes < giga_lattice_workspace_bytes(B, R, precision)) return -4;
@@ -414,7 +416,7 @@ int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, cons
     for (int h = 0; h < NHEADS; ++h)
         if ((head_mask >> h & 1) && !outs[h]) return -6;      // before anything is enqueued
     hipStream_t s = static_cast<hipStream_t>(stream);
-    int rc = launch_lattice_resample(planes_nhwc, lin, workspace, B, R, precision, s);
+    int rc = launch_lattice_resample(planes_nhwc, lin, workspace, B, R, precision, s, planes32);
     if (rc) return rc;
     const PackOff ko = pack_offsets();
     DecArgs a{};

@@ -1337,8 +1337,9 @@ __global__ void planes_nhwc_to_nchw_kernel(const TIn* __restrict__ src, float* _
 // Inference queries the fixed R^3 lattice (detection_implicit.py:28-31), so every plane is sampled at
 // only R*R distinct positions, each shared by R points.  One thread per (plane, scene, j, i, 8
 // channels) evaluates sample_plane_feature (decoder.py:117-122) once; out [3][B][R(v)][R(u)][32].
-template <typename TP>
-__global__ void lattice_resample_kernel(const TP* __restrict__ planes, const float* __restrict__ lin,
+// (TIn = float, TP = half: fp32 planes of an fp32 / f16x3 encoder feeding the plain-f16 decoder -- GIGA_PLANES_FP32)
+template <typename TP, typename TIn = TP>
+__global__ void lattice_resample_kernel(const TIn* __restrict__ planes, const float* __restrict__ lin,
                                         TP* __restrict__ out, int B, int R) {
     const long long total = 3LL * B * R * R * 4;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1348,15 +1349,16 @@ __global__ void lattice_resample_kernel(const TP* __restrict__ planes, const flo
     const int iu = (int)(pix % R), iv = (int)((pix / R) % R);
     const long long img = pix / ((long long)R * R);
     const Bilin bl = bilin_setup(norm_coord(lin[iu]), norm_coord(lin[iv]));
-    const TP* src = planes + (size_t)img * RES * RES * CD + 8 * cg;
+    const TIn* src = planes + (size_t)img * RES * RES * CD + 8 * cg;
     TP* dst = out + (size_t)pix * CD + 8 * cg;
     // the thread's 8 channels of a tap are 16 (f16) or 32 (fp32) contiguous bytes: one or two 16-byte loads per tap, one or two
     // 16-byte stores (element-wise 2-byte accesses made this kernel 14 us at 32 scenes for 17 MB)
     typedef TP vec8 __attribute__((ext_vector_type(8)));
-    const vec8 v00 = *reinterpret_cast<const vec8*>(src + (size_t)bl.o00 * CD);
-    const vec8 v01 = *reinterpret_cast<const vec8*>(src + (size_t)bl.o01 * CD);
-    const vec8 v10 = *reinterpret_cast<const vec8*>(src + (size_t)bl.o10 * CD);
-    const vec8 v11 = *reinterpret_cast<const vec8*>(src + (size_t)bl.o11 * CD);
+    typedef TIn vin8 __attribute__((ext_vector_type(8)));
+    const vin8 v00 = *reinterpret_cast<const vin8*>(src + (size_t)bl.o00 * CD);
+    const vin8 v01 = *reinterpret_cast<const vin8*>(src + (size_t)bl.o01 * CD);
+    const vin8 v10 = *reinterpret_cast<const vin8*>(src + (size_t)bl.o10 * CD);
+    const vin8 v11 = *reinterpret_cast<const vin8*>(src + (size_t)bl.o11 * CD);
     vec8 r;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -1538,12 +1540,15 @@ int launch_decoder(const DecArgs& a0, int precision, hipStream_t s, void* ev0, v
 }
 
 int launch_lattice_resample(const void* planes, const float* lin, void* out, int B, int R, int precision,
-                            hipStream_t s) {
+                            hipStream_t s, bool planes_fp32) {
     const long long total = 3LL * B * R * R * 4;
     if (total <= 0) return 0;
     const unsigned grid = (unsigned)((total + 255) / 256);
     if (precision == 2)
         GIGA_LAUNCH(lattice_resample_split_kernel, dim3(grid), dim3(256), 0, s,
+                           reinterpret_cast<const float*>(planes), lin, reinterpret_cast<half_t*>(out), B, R);
+    else if (precision == 1 && planes_fp32)
+        GIGA_LAUNCH((lattice_resample_kernel<half_t, float>), dim3(grid), dim3(256), 0, s,
                            reinterpret_cast<const float*>(planes), lin, reinterpret_cast<half_t*>(out), B, R);
     else if (precision == 1)
         GIGA_LAUNCH(lattice_resample_kernel<half_t>, dim3(grid), dim3(256), 0, s,

@@ -176,6 +176,10 @@ int giga_decoder_forward(const void* planes_nhwc, const float* p, const void* pa
  * (giga_lattice_workspace_bytes) and the fused decoder then reads three pixels per point instead of
  * twelve bilinear taps.  lin: device pointer to the R lattice coordinates (R <= 64).
  * Outputs as giga_decoder_forward with N = R^3; ev_start/ev_stop (may be NULL) bracket the decoder launch. */
+/* GIGA_PLANES_FP32, OR-ed into `precision` 1 of giga_decoder_forward_lattice: planes_nhwc are FP32 planes (an encoder at precision 0 or
+ * 2); the resampling reads them and writes the f16 lattice planes the plain-f16 decoder consumes.  The throughput decoder under an
+ * fp32-grade encoder: most of plain f16's error against the fp32 reference comes from its ENCODER (tests/test_f16_error_budget.py). */
+#define GIGA_PLANES_FP32 1024
 size_t giga_lattice_workspace_bytes(int B, int R, int precision);
 int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, const void* packed, int head_mask,
                                  float* qual, float* rot, float* width, float* occ, int B, int R, int precision,

@@ -93,3 +93,45 @@ def test_c4_bench_shapes_against_oracle_and_single_scene_runs(net, oracle_scene,
             del full
     finally:
         net.set_precision("fp32")
+
+
+TOL_MIXED = 5e-3                 # 'fp16x3+fp16': the plain-f16 decoder's own floor (1.5-3e-3 raw, test_f16_error_budget.py); measured below
+
+
+@pytest.mark.parametrize("B", [3, 32])
+def test_c4_mixed_mode_f16x3_encoder_under_the_plain_f16_lattice_decoder(net, oracle_scene, B):
+    """'fp16x3+fp16' (include/giga_hip.h GIGA_PLANES_FP32): the f16x3 encoder's fp32 planes resampled straight into the f16 lattice
+    planes of `decoder_lat_kernel`.  Against the oracle it is held to the f16 DECODER's floor (5e-3 on sigmoid(qual), 1e-2 on rot / width),
+    half of plain fp16's envelope, and it must not be worse than plain fp16 on the same scenes; queries that are not the lattice take
+    the f16x3 decoder, bit for bit the 'fp16x3' result."""
+    from giga_amd.detection import predict_batch, query_lattice
+    dev = torch.device("cuda:0")
+    lat = query_lattice(40, dev)
+    x = torch.from_numpy(synth.tsdf_batch(FIRST, B)).to(dev)
+    picks = sorted({0, B - 1})
+    try:
+        errs = {}
+        for prec in ("fp16", "fp16x3+fp16"):
+            net.set_precision(prec)
+            full = predict_batch(x, lat, net)
+            worst = [0.0, 0.0, 0.0]
+            for k in picks:
+                ref = oracle_scene(k)
+                for i, (got, want) in enumerate(zip(full, ref)):
+                    worst[i] = max(worst[i], _err(got[k:k + 1], want))
+            errs[prec] = worst
+        print(f"c4 B={B}: max |err| vs oracle (qual, rot, width): fp16 {errs['fp16']}, fp16x3+fp16 {errs['fp16x3+fp16']}")
+        for e, scale in zip(errs["fp16x3+fp16"], (1.0, 2.0, 2.0)):
+            assert e < TOL_MIXED * scale, errs
+        assert sum(errs["fp16x3+fp16"]) <= 1.25 * sum(errs["fp16"]), errs
+        # generic queries: the f16x3 decoder
+        p = torch.from_numpy(synth.query_points(FIRST, B, 257, stream=6)).to(dev)
+        outs = {}
+        for prec in ("fp16x3", "fp16x3+fp16"):
+            net.set_precision(prec)
+            with torch.no_grad():
+                outs[prec] = net(x, p)
+        for a, b in zip(outs["fp16x3"], outs["fp16x3+fp16"]):
+            assert torch.equal(a, b)
+    finally:
+        net.set_precision("fp32")
