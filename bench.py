@@ -40,6 +40,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MATRIX_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32-input MFMA == fp32 vector peak
 PEAK_F16_MFMA_TFLOPS = 2500.0         # dense f16/bf16 MFMA
+PEAK_HBM_GBS = 8000.0                 # HBM3E
 # Sustained peaks measured on the round-1 box by tools/mfma_peak.hip (profiles/r01j_hw_peaks.txt): back-to-back
 # register-resident MFMAs on all 1024 SIMDs.  Reported beside the spec fraction; `frac` stays spec-based.
 MEASURED_F32_MATRIX_TFLOPS = 156.3    # v_mfma_f32_32x32x2_f32 (99.4 % of spec)
@@ -80,7 +81,7 @@ def traffic_lookup(workload, fragment):
     (bytes or None, provenance or None)."""
     if not fragment:
         return None, None
-    for rnd in ("r04", "r03", "r02"):                             # the newest committed table that knows the kernel
+    for rnd in ("r05", "r04", "r03", "r02"):                      # the newest committed table that knows the kernel
         try:
             tab = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_traffic_{workload}.json")))
         except (OSError, ValueError):
@@ -89,6 +90,21 @@ def traffic_lookup(workload, fragment):
             if fragment in name:
                 return ent["bytes"], {"table": f"profiles/{rnd}_traffic_{workload}.json", "commit": tab.get("commit"), "kernel": name,
                                       "fetch_kib": ent["fetch_kib"], "write_kib": ent["write_kib"]}
+    return None, None
+
+
+def traffic_c5(precision):
+    """HBM bytes of ONE c5 training step (every kernel of it) from profiles/r0N_traffic_c5.json, and the five kernels that move the
+    most.  Returns (bytes or None, provenance or None)."""
+    for rnd in ("r05",):
+        try:
+            tab = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_traffic_c5.json")))["bf16" if precision.startswith("bf16") else "fp32"]
+        except (OSError, ValueError, KeyError):
+            continue
+        top = sorted(tab["kernels"].items(), key=lambda kv: -kv[1]["bytes_per_step"])[:5]
+        return tab["bytes_per_step"], {"table": f"profiles/{rnd}_traffic_c5.json", "commit": tab.get("commit"),
+                                       "five_heaviest_kernels": [{"kernel": k.split("(")[0][-80:], "MB_per_step": round(v["bytes_per_step"] / 1e6, 2),
+                                                                  "launches_per_step": v["launches_per_step"]} for k, v in top]}
     return None, None
 
 
@@ -942,9 +958,11 @@ def bench_train(net, dev, synth, B, M, steps=50, rank=0, world=1, sync=None, pre
         e[0] += t; e[1] += 1
     top = sorted(by_kernel.items(), key=lambda kv: -kv[1][0])[:5]
     peak = PEAK_F16_MFMA_TFLOPS if precision.startswith("bf16") else PEAK_F32_MATRIX_TFLOPS
+    tr5, tr5_src = traffic_c5(precision) if (B == 32 and M == 2048 and precision != "bf16_convs") else (None, None)
     roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
             "frac_of_fp32_matrix_peak": ach / PEAK_F32_MATRIX_TFLOPS, "frac_of_bf16_mfma_peak": ach / PEAK_F16_MFMA_TFLOPS,
-            "flops_per_step": step_flop, "traffic": None,
+            "flops_per_step": step_flop, "traffic": tr5, "traffic_source": tr5_src,
+            "hbm_time_at_peak_ms": round(tr5 / (PEAK_HBM_GBS * 1e9) * 1e3, 4) if tr5 else None,
             "note": "whole step: 3 x the algorithmic forward FLOPs of the literal train_giga call / the wall time of a step; the "
                     "per-kernel times below are HIP events around each launch of the step (giga_launch_probe), medians of three",
             "sum_of_launch_ms": round(sum(t for t, _, _ in kernels), 4) if kernels else None,

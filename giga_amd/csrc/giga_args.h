@@ -34,4 +34,9 @@ struct EncWs {
     size_t MASK;               // conv_in ReLU mask of a training forward (GIGA_CONVIN_MASK): [B][8][40][64 lanes] x 16 bytes
 };
 
+// gradient workspace of the encoder backward (giga_encoder_bwd.hip carves it, giga_capi.hip sizes the caller's buffer with it): ONE
+// definition for both translation units
+struct BwdWs { size_t gA6, gA5, gC1, gA4, gA3, gC0, gS2, gA2, gQ1, gS1, gA1, gQ0, gS0, gA0, gP0, WG, WG3[12], CINP, total; };   // (+ SYNC behind `total`)
+BwdWs enc_bwd_workspace(int B);
+
 }  // namespace giga

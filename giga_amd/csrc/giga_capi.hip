@@ -18,10 +18,9 @@ int pack_bwd_host(const float* P, size_t n_params, int head_present, uint8_t* bl
 int pack_bwd_map_host(int head_present, int32_t* map, size_t nwords);
 int packed_check_host(const uint8_t* blob, size_t bytes, int backward);
 // giga_encoder_bwd.hip / giga_decoder_bwd.hip
-struct BwdWs { size_t gA6, gA5, gC1, gA4, gA3, gC0, gS2, gA2, gQ1, gS1, gA1, gQ0, gS0, gA0, gP0, WG, total; };
-BwdWs enc_bwd_workspace(int B);
 constexpr size_t ENC_BWD_SYNC_BYTES = 8192;        // behind BwdWs::total: the counters of the persistent data-gradient kernel (giga_bwd_mega.h)
 void persistent_forget();
+void wgrad_side_forget();
 int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws,
                             float* gplanes, uint8_t* gws, float* grads, int head_present, int B, hipStream_t s, bool bf16_convs, bool convin_mask);
 size_t dec_bwd_scratch_floats(long long P, int nheads);
@@ -316,6 +315,7 @@ const char* giga_launch_probe_name(void) { return g_probe_name; }
 void giga_forget_device_state(void) {
     giga::dyn_lds_forget();
     giga::persistent_forget();
+    giga::wgrad_side_forget();
 }
 
 void* giga_event_create(void) {

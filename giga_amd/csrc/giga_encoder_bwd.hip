@@ -10,6 +10,8 @@
 // Weight/bias gradients are ACCUMULATED into the flat fp32 gradient buffer (reference state-dict order) with
 // fp32 atomics (summation order is not fixed, as with PyTorch's own CUDA/HIP backward kernels).
 #include "giga_conv16.h"
+#include <mutex>
+
 #include "giga_bwd_mega.h"
 #include "giga_args.h"
 
@@ -489,8 +491,88 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restr
     }
 }
 
+// ONE reduce launch for the 3x3 layers of a backward pass (round 5): every layer's weight-gradient launch leaves its partial images in
+// its OWN region of the workspace and a descriptor here; this kernel runs the blocks of wgrad3_reduce_kernel for all of them (same
+// element -> thread map, same order of summation: bit-identical results) in one grid.  Ten launches of 145 x NBLK blocks -- 9-13 us
+// each, none of them filling the chip -- become one of ~6 800 blocks.
+struct Wg3RedLayer {
+    const float* partial; float* dW; float* db;
+    int nx, ny, bpg, cin, cout, first_block;      // first_block: prefix sum of (144 * nblk + 1) over the layers before this one
+};
+constexpr int WG3_RED_MAX = 10;
+struct Wg3RedArgs { Wg3RedLayer L[WG3_RED_MAX]; int nlayers; int nblocks; };
+
+__global__ __launch_bounds__(256) void wgrad3_reduce_all_kernel(Wg3RedArgs A) {
+    constexpr int RN = 9 * 1024;
+    __shared__ float sb[256];
+    const int bid = blockIdx.x;
+    const float* partial = A.L[0].partial; float* dW = A.L[0].dW; float* db = A.L[0].db;
+    int nx = A.L[0].nx, ny = A.L[0].ny, bpg = A.L[0].bpg, cin = A.L[0].cin, cout = A.L[0].cout, first = 0;
+#pragma unroll
+    for (int i = 1; i < WG3_RED_MAX; ++i)
+        if (i < A.nlayers && bid >= A.L[i].first_block) {
+            partial = A.L[i].partial; dW = A.L[i].dW; db = A.L[i].db;
+            nx = A.L[i].nx; ny = A.L[i].ny; bpg = A.L[i].bpg; cin = A.L[i].cin; cout = A.L[i].cout; first = A.L[i].first_block;
+        }
+    const int local = bid - first, nbk = cin >> 5, nblk = (cout >> 5) * nbk;
+    if (local == 144 * nblk) {                                  // the layer's bias gradient
+        const int c = threadIdx.x % cout, part = threadIdx.x / cout, np = 256 / cout;     // cout divides 256
+        const float* bsrc = partial + (size_t)ny * nx * bpg * RN + c;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int x = part;
+        for (; x + 3 * np < nx; x += 4 * np) {
+            v0 += bsrc[(size_t)x * cout]; v1 += bsrc[(size_t)(x + np) * cout];
+            v2 += bsrc[(size_t)(x + 2 * np) * cout]; v3 += bsrc[(size_t)(x + 3 * np) * cout];
+        }
+        for (; x < nx; x += np) v0 += bsrc[(size_t)x * cout];
+        sb[threadIdx.x] = (v0 + v1) + (v2 + v3);
+        __syncthreads();
+        if ((int)threadIdx.x < cout) {
+            float t = 0.f;
+            for (int q = 0; q < np; ++q) t += sb[q * cout + threadIdx.x];
+            db[threadIdx.x] += t;
+        }
+        return;
+    }
+    const int gb = local / 144, ex = local - gb * 144;
+    const int e = ex * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int by = gb / bpg, b = gb - by * bpg;
+    const float* src = partial + ((size_t)by * nx * bpg + b) * RN + e;
+    const size_t ST = (size_t)bpg * RN;
+    float sacc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sacc[k] = 0.f;
+    int x = q;
+    for (; x + 28 < nx; x += 32) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sacc[k] += src[(size_t)(x + 4 * k) * ST];
+    }
+    for (; x < nx; x += 4) sacc[0] += src[(size_t)x * ST];
+    sb[threadIdx.x] = ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) + ((sacc[4] + sacc[5]) + (sacc[6] + sacc[7]));
+    __syncthreads();
+    if (q == 0) {
+        const float v = (sb[threadIdx.x] + sb[64 + threadIdx.x]) + (sb[128 + threadIdx.x] + sb[192 + threadIdx.x]);
+        const int t = e >> 10, m = (e >> 5) & 31, n = e & 31;
+        const int gmb = gb / nbk, gnb = gb - gmb * nbk;
+        dW[((size_t)(gmb * 32 + m) * cin + gnb * 32 + n) * 9 + t] += v;
+    }
+}
+
+// what a layer's launcher does with its reduce: launch it (defer == nullptr) or describe it for wgrad3_reduce_all_kernel
+static void wg3_defer(Wg3RedArgs* R, const float* partial, int nx, int ny, int bpg, int cin, int cout, float* dW, float* db) {
+    Wg3RedLayer& L = R->L[R->nlayers++];
+    L.partial = partial; L.dW = dW; L.db = db; L.nx = nx; L.ny = ny; L.bpg = bpg; L.cin = cin; L.cout = cout;
+    L.first_block = R->nblocks;
+    R->nblocks += 144 * (cout / 32) * (cin / 32) + 1;
+}
+static int launch_wgrad3_reduce_all(const Wg3RedArgs& R, hipStream_t s) {
+    if (R.nlayers == 0) return 0;
+    GIGA_LAUNCH(wgrad3_reduce_all_kernel, dim3(R.nblocks), dim3(256), 0, s, R);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
 template <int C0, int C1, int COUT, int H, int RS>
-static int launch_wgrad3(const Wgrad3Args& a, hipStream_t s) {
+static int launch_wgrad3(const Wgrad3Args& a, hipStream_t s, Wg3RedArgs* defer = nullptr) {
     constexpr int CIN = C0 + C1, W = H;
     constexpr int NBLK = (COUT / 32) * (CIN / 32), BPG = NBLK < 8 ? NBLK : 8, NY = NBLK / BPG;
     constexpr int XS = CIN + (CIN % 64 == 0 ? 32 : 0), YS = COUT + (COUT % 64 == 0 ? 32 : 0);
@@ -503,6 +585,7 @@ static int launch_wgrad3(const Wgrad3Args& a, hipStream_t s) {
     auto kern = conv3_wgrad_kernel<C0, C1, COUT, H, RS>;
     giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
     GIGA_LAUNCH(kern, dim3(gx, NY), dim3(512), lds, s, a);
+    if (defer) { wg3_defer(defer, a.partial, gx, NY, BPG, CIN, COUT, a.dW, a.db); return hipGetLastError() == hipSuccess ? 0 : -10; }
     GIGA_LAUNCH((wgrad3_reduce_kernel<CIN, BPG>), dim3(9 * 1024 / 64 + 1, NBLK), dim3(256), 0, s, a.partial, gx,
                        a.dW, a.db, COUT, NY);
     return hipGetLastError() == hipSuccess ? 0 : -10;
@@ -1029,7 +1112,7 @@ __global__ __launch_bounds__(576) void conv3_wgrad_bf16_taps_kernel(Wgrad3Args a
 }
 
 template <int C0, int C1, int COUT, int H, int RS>
-static int launch_wgrad3_bf16(const Wgrad3Args& a, hipStream_t s) {
+static int launch_wgrad3_bf16(const Wgrad3Args& a, hipStream_t s, Wg3RedArgs* defer = nullptr) {
     constexpr int CIN = C0 + C1, W = H;
     constexpr int NBLK = (COUT / 32) * (CIN / 32), BPG = NBLK < 8 ? NBLK : 8, NY = NBLK / BPG;
     constexpr int G = (W + 7) / 8;
@@ -1045,6 +1128,7 @@ static int launch_wgrad3_bf16(const Wgrad3Args& a, hipStream_t s) {
             auto kern = conv3_wgrad_bf16_taps_kernel<C0, C1, COUT, H, RS>;
             giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)strip);
             GIGA_LAUNCH(kern, dim3(gx), dim3(576), strip, s, a);
+            if (defer) { wg3_defer(defer, a.partial, gx, NY, BPG, CIN, COUT, a.dW, a.db); return hipGetLastError() == hipSuccess ? 0 : -10; }
             GIGA_LAUNCH((wgrad3_reduce_kernel<CIN, BPG>), dim3(9 * 1024 / 64 + 1, NBLK), dim3(256), 0, s, a.partial, gx,
                                a.dW, a.db, COUT, NY);
             return hipGetLastError() == hipSuccess ? 0 : -10;
@@ -1062,6 +1146,7 @@ static int launch_wgrad3_bf16(const Wgrad3Args& a, hipStream_t s) {
             auto kns = conv3_wgrad_bf16_ns_kernel<C0, C1, COUT, H, RS, BX>;
             giga::dyn_lds_once(reinterpret_cast<const void*>(kns), (int)lds_ns);
             GIGA_LAUNCH(kns, dim3(gxs, NYS), dim3(512), lds_ns, s, a);
+            if (defer) { wg3_defer(defer, a.partial, gxs, NYS, BX, CIN, COUT, a.dW, a.db); return hipGetLastError() == hipSuccess ? 0 : -10; }
             GIGA_LAUNCH((wgrad3_reduce_kernel<CIN, BX>), dim3(9 * 1024 / 64 + 1, NBLK), dim3(256), 0, s, a.partial, gxs,
                                a.dW, a.db, COUT, NYS);
             return hipGetLastError() == hipSuccess ? 0 : -10;
@@ -1070,6 +1155,7 @@ static int launch_wgrad3_bf16(const Wgrad3Args& a, hipStream_t s) {
     auto kern = conv3_wgrad_bf16_kernel<C0, C1, COUT, H, RS>;
     giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
     GIGA_LAUNCH(kern, dim3(gx, NY), dim3(512), lds, s, a);
+    if (defer) { wg3_defer(defer, a.partial, gx, NY, BPG, CIN, COUT, a.dW, a.db); return hipGetLastError() == hipSuccess ? 0 : -10; }
     GIGA_LAUNCH((wgrad3_reduce_kernel<CIN, BPG>), dim3(9 * 1024 / 64 + 1, NBLK), dim3(256), 0, s, a.partial, gx,
                        a.dW, a.db, COUT, NY);
     return hipGetLastError() == hipSuccess ? 0 : -10;
@@ -1257,9 +1343,43 @@ __global__ __launch_bounds__(256) void convin_bwd_reduce_kernel(const float* __r
     }
 }
 
+// ------------------------------- the weight gradients' own stream -------------------------------------------------
+// The data-gradient chain (13 convolutions + 2 pooling steps, each waiting for its predecessor) and the 13 weight gradients (each
+// waiting only for ONE link of that chain) are two sequences of latency-bound launches at 2-3 TB/s: run on one stream they take the
+// sum of their times.  The weight gradients therefore go to a second, library-owned stream of the device: forked from the caller's
+// stream with an event behind the link each one needs, joined back into it with one event behind the last reduce, so the caller
+// sees ordinary stream semantics (and a capturing stream captures both branches).  One side stream per device; a mutex covers
+// the enqueue of a whole backward pass because the events are shared by the device's callers.
+struct WgradSide {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork[16] = {};
+    hipEvent_t done = nullptr;
+    bool ok = false;
+};
+static std::mutex g_side_mutex;
+static WgradSide g_side[64];
+static WgradSide* wgrad_side_locked() {            // (g_side_mutex held)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    WgradSide& w = g_side[dev];
+    if (!w.ok) {
+        if (hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        bool ok = hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 16 && ok; ++i) ok = hipEventCreateWithFlags(&w.fork[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) return nullptr;
+        w.ok = true;
+    }
+    return &w;
+}
+// giga_forget_device_state(): the handles died with the device's context
+void wgrad_side_forget() {
+    std::lock_guard<std::mutex> lk(g_side_mutex);
+    for (WgradSide& w : g_side) w = WgradSide{};
+}
+
 // ------------------------------- driver -----------------------------------------------------------------------
 // forward activations: the encoder workspace (giga_encoder.hip::EncWs, fp32).  Gradient workspace carve:
-struct BwdWs { size_t gA6, gA5, gC1, gA4, gA3, gC0, gS2, gA2, gQ1, gS1, gA1, gQ0, gS0, gA0, gP0, WG, total; };   // (+ SYNC: behind WG, see enc_bwd_sync_offset)
+// (struct BwdWs: giga_bwd_mega.h)
 BwdWs enc_bwd_workspace(int B) {
     const size_t n = 3 * (size_t)B;
     BwdWs w{};
@@ -1271,6 +1391,15 @@ BwdWs enc_bwd_workspace(int B) {
     w.gS1 = take(n * 400 * 64);  w.gA1 = take(n * 400 * 64);  w.gQ0 = take(n * 400 * 32);
     w.gS0 = take(n * 1600 * 32); w.gA0 = take(n * 1600 * 32); w.gP0 = take(n * 1600 * 32);
     w.WG = take((size_t)WG3_MAX_PARTS * 32 * 288 + WG3_BIAS_FLOATS);      // per-workgroup weight-gradient partials (conv3_wgrad_kernel)
+    // one region per 3x3 layer for the single reduce launch at the end (wgrad3_reduce_all_kernel): 256 x min(blocks, 8) partial
+    // images of 36 KiB + the bias partials; 368 MB in all, whatever the batch size
+    for (int l = 0; l < 12; ++l) {
+        w.WG3[l] = 0;
+        if (kConv[l].kind != CONV3) continue;
+        const int nblk = (kConv[l].cout / 32) * ((kConv[l].cin0 + kConv[l].cin1) / 32);
+        w.WG3[l] = take((size_t)256 * (nblk < 8 ? nblk : 8) * 32 * 288 + WG3_BIAS_FLOATS);
+    }
+    w.CINP = take((size_t)B * 8 * 5 * CB_PART);    // conv_in's workgroup partials (their own: the backward runs beside the weight gradients' stream)
     w.total = at;                                  // (+ MEGA_SYNC_WORDS words behind it: the persistent data-gradient kernel's counters)
     return w;
 }
@@ -1294,6 +1423,22 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
     auto F = [&](size_t off) { return reinterpret_cast<const float*>(fws + off); };
     auto G = [&](size_t off) { return reinterpret_cast<float*>(gws + off); };
     int rc = 0;
+    // the ten reduces of the 3x3 layers' partial weight gradients as ONE launch behind the last of them (GIGA_WGRAD_ONE_REDUCE=0: one
+    // launch per layer, right behind its weight-gradient kernel, as before round 5)
+    const bool one_reduce = [] { const char* e = getenv("GIGA_WGRAD_ONE_REDUCE"); return !e || atoi(e) != 0; }();     // (per call)
+    Wg3RedArgs RED{};
+    // the weight gradients on the device's side stream (GIGA_WGRAD_STREAM=0: on the caller's stream, between the data gradients)
+    const bool want_side = [] { const char* e = getenv("GIGA_WGRAD_STREAM"); return !e || atoi(e) != 0; }();
+    std::unique_lock<std::mutex> side_lock(g_side_mutex, std::defer_lock);
+    WgradSide* side = nullptr;
+    if (want_side) { side_lock.lock(); side = wgrad_side_locked(); if (!side) side_lock.unlock(); }
+    const hipStream_t ws = side ? side->stream : s;
+    int nfork = 0;
+    auto fork = [&]() {                               // what the caller's stream has enqueued so far precedes what follows on `ws`
+        if (!side) return;
+        hipEvent_t e = side->fork[nfork++ & 15];
+        if (hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(ws, e, 0) != hipSuccess) rc |= -10;
+    };
     // weight gradient of layer l: R = dPre (channels = cout), columns = layer input (in0 [, in1])
     auto wgrad3 = [&](int l, const float* dpre, const float* in0, const float* in1, int H) {
         const ConvLayerDesc& d = kConv[l];
@@ -1307,8 +1452,9 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
         a.partial = G(g.WG);
         a.db = grads + po.conv_b[l]; a.nbias = d.cout;          // bias gradient = column sums of dPre, folded into the same two launches
         if (d.kind == CONV3) {
-            Wgrad3Args w3{dpre, in0, in1, grads + po.conv_w[l], grads + po.conv_b[l], G(g.WG), nimg};
-#define WG3(...) (MATH == MATH_BF16 ? launch_wgrad3_bf16<__VA_ARGS__>(w3, s) : launch_wgrad3<__VA_ARGS__>(w3, s))
+            Wgrad3Args w3{dpre, in0, in1, grads + po.conv_w[l], grads + po.conv_b[l], one_reduce ? G(g.WG3[l]) : G(g.WG), nimg};
+            Wg3RedArgs* defer = one_reduce ? &RED : nullptr;
+#define WG3(...) (MATH == MATH_BF16 ? launch_wgrad3_bf16<__VA_ARGS__>(w3, ws, defer) : launch_wgrad3<__VA_ARGS__>(w3, ws, defer))
             switch (l) {   // <C0, C1, COUT, H, rows per strip>
                 case 0: case 1: case 11: rc |= WG3(32, 0, 32, 40, 4); break;
                 case 10: rc |= WG3(32, 32, 32, 40, 2); break;
@@ -1318,10 +1464,10 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
                 case 4: rc |= WG3(64, 0, 128, 10, 2); break;
                 case 5: rc |= WG3(128, 0, 128, 10, 2); break;
 #undef WG3
-                default: rc |= launch_wgrad(a, s);
+                default: rc |= launch_wgrad(a, ws);
             }
         } else {
-            rc |= launch_wgrad(a, s);
+            rc |= launch_wgrad(a, ws);
         }
     };
     // ConvTranspose2d(cin, cout, 2, 2): dW[ci][co][d] = sum In[p][ci] * dU[up(p,d)][co]; dU = channels [0,cout) of dcat
@@ -1335,7 +1481,7 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
         a.nimg = nimg; a.H = H; a.W = H;
         a.partial = G(g.WG);
         a.db = grads + po.conv_b[l]; a.nbias = d.cout;          // bias gradient = column sums of dU over all four taps
-        rc |= launch_wgrad(a, s);
+        rc |= launch_wgrad(a, ws);
     };
     // data gradient of layer l; relu_of: the forward activation the gradient flows into next (ReLU output of the layer
     // below): its backward mask is applied in the convolution's epilogue instead of by a separate pass over the tensor
@@ -1378,6 +1524,7 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
     if (mega > 0) {
         // the weight gradients: every one needs only what the chain has left in memory (dPre of its layer, mask applied) and the
         // forward's activations
+        fork();
         wgrad3(12, gplanes, F(f.A6), nullptr, 40);
         wgrad3(11, G(g.gA6), F(f.A5), nullptr, 40);
         wgrad3(10, G(g.gA5), F(f.U1), F(f.S0), 40);
@@ -1394,49 +1541,51 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
     } else {
         // one launch per stage, the weight gradient of a layer right behind the launch that produced its dPre (it is still in the
         // Infinity Cache then)
-        wgrad3(12, gplanes, F(f.A6), nullptr, 40);
+        fork(); wgrad3(12, gplanes, F(f.A6), nullptr, 40);
         rc |= launch_conv<float, CONV1, 32, 0, 32, 40, 40, 2, false, false, MATH>(M.layer[0], s);
-        wgrad3(11, G(g.gA6), F(f.A5), nullptr, 40);
+        fork(); wgrad3(11, G(g.gA6), F(f.A5), nullptr, 40);
         rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(M.layer[1], s);
-        wgrad3(10, G(g.gA5), F(f.U1), F(f.S0), 40);
+        fork(); wgrad3(10, G(g.gA5), F(f.U1), F(f.S0), 40);
         rc |= launch_conv<float, CONV3, 32, 0, 64, 40, 40, 2, false, false, MATH>(M.layer[2], s);
-        wgrad_up(9, F(f.A4), G(g.gC1), 64, 20);
+        fork(); wgrad_up(9, F(f.A4), G(g.gC1), 64, 20);
         rc |= launch_conv<float, DOWN, 32, 0, 64, 20, 20, 2, false, false, MATH>(M.layer[3], s);
-        wgrad3(8, G(g.gA4), F(f.A3), nullptr, 20);
+        fork(); wgrad3(8, G(g.gA4), F(f.A3), nullptr, 20);
         rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false, MATH>(M.layer[4], s);
-        wgrad3(7, G(g.gA3), F(f.U0), F(f.S1), 20);
+        fork(); wgrad3(7, G(g.gA3), F(f.U0), F(f.S1), 20);
         rc |= launch_conv<float, CONV3, 64, 0, 128, 20, 20, 1, false, false, MATH>(M.layer[5], s);
-        wgrad_up(6, F(f.S2), G(g.gC0), 128, 10);
+        fork(); wgrad_up(6, F(f.S2), G(g.gC0), 128, 10);
         rc |= launch_conv<float, DOWN, 64, 0, 128, 10, 10, 1, false, false, MATH>(M.layer[6], s);
-        wgrad3(5, G(g.gS2), F(f.A2), nullptr, 10);
+        fork(); wgrad3(5, G(g.gS2), F(f.A2), nullptr, 10);
         rc |= launch_conv<float, CONV3, 128, 0, 128, 10, 10, 1, false, false, MATH>(M.layer[7], s);
-        wgrad3(4, G(g.gA2), F(f.Q1), nullptr, 10);
+        fork(); wgrad3(4, G(g.gA2), F(f.Q1), nullptr, 10);
         rc |= launch_conv<float, CONV3, 128, 0, 64, 10, 10, 1, false, false, MATH>(M.layer[8], s);
         {
             const size_t tot = n20 * 64 / 4;
             GIGA_LAUNCH(pool_bwd_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, G(g.gS1),
                                G(g.gC0), 128, 64, G(g.gQ1), F(f.S1), F(f.Q1), nimg, 20, 20, 64);
         }
-        wgrad3(3, G(g.gS1), F(f.A1), nullptr, 20);
+        fork(); wgrad3(3, G(g.gS1), F(f.A1), nullptr, 20);
         rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false, MATH>(M.layer[9], s);
-        wgrad3(2, G(g.gA1), F(f.Q0), nullptr, 20);
+        fork(); wgrad3(2, G(g.gA1), F(f.Q0), nullptr, 20);
         rc |= launch_conv<float, CONV3, 64, 0, 32, 20, 20, 2, false, false, MATH>(M.layer[10], s);
         {
             const size_t tot = n40 * 32 / 4;
             GIGA_LAUNCH(pool_bwd_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, G(g.gS0),
                                G(g.gC1), 64, 32, G(g.gQ0), F(f.S0), F(f.Q0), nimg, 40, 40, 32);
         }
-        wgrad3(1, G(g.gS0), F(f.A0), nullptr, 40);
+        fork(); wgrad3(1, G(g.gS0), F(f.A0), nullptr, 40);
         rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(M.layer[11], s);
-        wgrad3(0, G(g.gA0), F(f.P0), nullptr, 40);
+        fork(); wgrad3(0, G(g.gA0), F(f.P0), nullptr, 40);
         rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(M.layer[12], s);
     }
+    rc |= launch_wgrad3_reduce_all(RED, ws);
+    if (side && (hipEventRecord(side->done, ws) != hipSuccess)) rc |= -10;
     // conv_in + projection
     {
         const int nxp = enc_nxp(B);
         const float* cw = reinterpret_cast<const float*>(blob + ko.convin_w);
         const float* cb = reinterpret_cast<const float*>(blob + ko.convin_b);
-        float* part = G(g.WG);                        // free again: the 3x3 weight gradients are done
+        float* part = G(g.CINP);
         const uint4* mask = convin_mask ? reinterpret_cast<const uint4*>(fws + f.MASK) : nullptr;
         auto go = [&](auto kern, int sxw, dim3 grid) {
             giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)cb_lds_bytes(sxw));
@@ -1447,6 +1596,7 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
         GIGA_LAUNCH(convin_bwd_reduce_kernel, dim3(CB_PART, 2), dim3(256), 0, s, part, B, nxp, grads + po.conv_in_w,
                            grads + po.conv_in_b);
     }
+    if (side && hipStreamWaitEvent(s, side->done, 0) != hipSuccess) rc |= -10;      // join: the caller's stream carries every gradient
     if (hipGetLastError() != hipSuccess) rc |= -10;
     return rc;
 }

@@ -392,8 +392,16 @@ def test_flattened_parameters_train_identically(sd7):
     (l0, s0, _), (l1, s1, netf) = runs
     assert np.allclose(l0, l1, rtol=1e-4, atol=0), (l0, l1)      # (weight gradients are reduced with atomics: not bit-identical)
     assert list(s0.keys()) == list(s1.keys()) == list(sd7.keys())
+    # Adam normalises every element's step to ~lr: an element whose gradient is at rounding-noise level (the plane gradients are
+    # summed with atomics: two runs of the SAME configuration differ there in the last bit) takes +lr in one run and -lr in the
+    # other, so single elements are 2-3 lr apart after five steps in any two runs (measured: discrete outcomes 5e-7, 2.5e-5, 6.7e-5,
+    # 2.3e-4 for lr = 1e-4, flat or not).  Bound: half of what five steps can move an element apart, and all but 1e-3 of the elements
+    # within a fifth of one step.
     for k in s0:
-        assert s1[k].shape == sd7[k].shape and (s0[k] - s1[k]).abs().max().item() < 2e-4, k
+        d = (s0[k] - s1[k]).abs()
+        assert s1[k].shape == sd7[k].shape and d.max().item() < 5e-4, k
+    far = sum((s0[k] - s1[k]).abs().gt(2e-5).sum().item() for k in s0) / sum(v.numel() for v in s0.values())
+    assert far < 1e-3, far
     with torch.no_grad():
         out = netf(x, pos, p_tsdf=pos_occ)
         ref = O.model_forward({k: v.cpu() for k, v in s1.items()}, x.cpu(), pos.cpu(), p_tsdf=pos_occ.cpu())

@@ -11,6 +11,7 @@ import os
 import sys
 
 src, dst, workload = sys.argv[1], sys.argv[2], sys.argv[3]
+steps = int(sys.argv[4]) if len(sys.argv) > 4 else None          # steps of the workload the passes sampled (gpu_prof.py: iters + 1)
 tot = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -26,6 +27,14 @@ for k, cs in sorted(tot.items()):
     wsz = cs["WRITE_SIZE"][0] / max(cs["WRITE_SIZE"][1], 1)
     kernels[k] = {"fetch_kib": round(fs, 1), "write_kib": round(wsz, 1), "bytes": int((2 * fs + wsz) * 1024),
                   "launches_sampled": cs["FETCH_SIZE"][1]}
+    if steps:
+        kernels[k]["launches_per_step"] = round(cs["FETCH_SIZE"][1] / steps, 2)
+        kernels[k]["bytes_per_step"] = int(kernels[k]["bytes"] * cs["FETCH_SIZE"][1] / steps)
     print(f"{k[:100]:100s} {fs:16.1f} {wsz:16.1f} {kernels[k]['bytes']:14d}")
-json.dump({"_about": __doc__.strip(), "workload": workload + " (tools/gpu_prof.py), 32 scenes", "commit": os.environ.get("GIGA_COMMIT"),
-           "kernels": kernels}, open(dst, "w"), indent=1)
+tab = {"_about": __doc__.strip(), "workload": workload + " (tools/gpu_prof.py), 32 scenes", "commit": os.environ.get("GIGA_COMMIT"),
+       "kernels": kernels}
+if steps:
+    tab["steps_sampled"] = steps
+    tab["bytes_per_step"] = sum(k["bytes_per_step"] for k in kernels.values())
+    print(f"whole step: {tab['bytes_per_step'] / 1e6:.1f} MB of HBM traffic")
+json.dump(tab, open(dst, "w"), indent=1)
