@@ -938,7 +938,7 @@ def bench_train(net, dev, synth, B, M, steps=50, rank=0, world=1, sync=None, pre
                 step()
                 if L.giga_event_elapsed_ms(ev0, ev1, ctypes.byref(ms)) == 0:
                     reps.append(ms.value)
-                name = (L.giga_launch_probe_name() or b"").decode()
+                name = _kernel_name((L.giga_launch_probe_name() or b"").decode())
             L.giga_launch_probe(0, None, None)
             if reps:
                 kernels.append((float(np.median(reps)), i, name))
@@ -978,6 +978,18 @@ def bench_train(net, dev, synth, B, M, steps=50, rank=0, world=1, sync=None, pre
             "step_ms_p90": float(np.percentile(per, 90)), "scenes_per_sec": world * B / el,
             "launches_per_step": n_launch, "roofline": roof,
             "final_loss": float(last["loss"].detach())}
+
+
+def _kernel_name(mangled):
+    """`_ZN4giga13conv16_kernelIfLi2E...` -> `conv16_kernel<...>` (the name without its template arguments): hipKernelNameRefByPtr
+    returns the mangled symbol."""
+    import re
+    m = re.match(r"_ZN4giga(\d+)", mangled) or re.match(r"_Z(\d+)", mangled)
+    if not m:
+        return mangled
+    n = int(m.group(1))
+    name = mangled[m.end():m.end() + n]
+    return name + ("<...>" if mangled[m.end() + n:m.end() + n + 1] == "I" else "")
 
 
 def cpu_baseline(sd, synth, M, budget_s=20.0):

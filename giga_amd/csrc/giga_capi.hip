@@ -7,6 +7,7 @@
 #include "giga_conv32_geom.h"
 #include "giga_dect.h"
 #include "giga_args.h"
+#include "giga_side.h"
 
 namespace giga {
 // giga_pack.cpp
@@ -20,14 +21,15 @@ int packed_check_host(const uint8_t* blob, size_t bytes, int backward);
 // giga_encoder_bwd.hip / giga_decoder_bwd.hip
 constexpr size_t ENC_BWD_SYNC_BYTES = 8192;        // behind BwdWs::total: the counters of the persistent data-gradient kernel (giga_bwd_mega.h)
 void persistent_forget();
-void wgrad_side_forget();
 int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws,
-                            float* gplanes, uint8_t* gws, float* grads, int head_present, int B, hipStream_t s, bool bf16_convs, bool convin_mask);
+                            float* gplanes, uint8_t* gws, float* grads, int head_present, int B, hipStream_t s, bool bf16_convs, bool convin_mask,
+                            SideScope& side);
 size_t dec_bwd_scratch_floats(long long P, int nheads);
 bool dec_bwd_writes_planes(int nheads, int B, int N);
 int launch_decoder_backward(const float* planes, const float* p, const uint8_t* blob, const uint8_t* bwd_blob,
                             int head_mask, const float* const* outs, const float* const* douts, float* gplanes,
-                            float* grads, int head_present, float* scratch, int B, int N, hipStream_t s, bool writes_planes);
+                            float* grads, int head_present, float* scratch, int B, int N, hipStream_t s, bool writes_planes,
+                            SideScope* side);
 int launch_plane_gather(const float* dcbuf, const float* p, float* gplanes, int B, int N, hipStream_t s);
 // giga_decoder_train16.hip (bf16 decoder of the bf16 training step)
 struct DectPending { const float* partial[NHEADS]; int nwg[NHEADS]; int head_id[NHEADS]; int n; };
@@ -315,7 +317,7 @@ const char* giga_launch_probe_name(void) { return g_probe_name; }
 void giga_forget_device_state(void) {
     giga::dyn_lds_forget();
     giga::persistent_forget();
-    giga::wgrad_side_forget();
+    giga::side_streams_forget();
 }
 
 void* giga_event_create(void) {
@@ -455,7 +457,7 @@ static size_t train_dec_scratch_bytes(int B, int N, int M, int head_present) {
     // reduced together at the end); far below the fp32 path's row arrays except for a handful of points
     const size_t c = (nt && M > 0 ? (size_t)B * M * 96 + dect_partial_floats((long long)B * M, 1) : 0) +
                      (ng ? dect_partial_floats((long long)B * N, ng) : 0);
-    const size_t m = a > b ? a : b;
+    const size_t m = a + b;                          // (both: the occupancy call's weight gradients run beside the grasp call, giga_side.h)
     return align_up((m > c ? m : c) * sizeof(float), 256);
 }
 
@@ -512,6 +514,8 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
     if (!occ_writes && hipMemsetAsync(gplanes, 0, gp_bytes, s) != hipSuccess) return -10;
     if (hipMemsetAsync(grads, 0, n_params * sizeof(float), s) != hipSuccess) return -10;
     int rc = 0;
+    // work that waits for ONE launch of the caller's stream only goes to the device's side stream (giga_side.h; GIGA_WGRAD_STREAM=0: none)
+    SideScope side(s, [] { const char* e = getenv("GIGA_WGRAD_STREAM"); return !e || atoi(e) != 0; }());
     if (bf16_dec) {
         // one fused launch per call (recompute, gradient chain, weight gradients), ONE reduce for every head of the step
         DectPending pend{};
@@ -527,19 +531,22 @@ int giga_backward(const float* tsdf, const void* packed, const void* bwd_packed,
         if ((head_present & 7) && N > 0)
             rc |= launch_dect_backward(static_cast<const float*>(planes_nhwc), p, blob, bblob, head_present & 7, outs, douts,
                                        gplanes, nullptr, sc, B, N, s, &pend);
-        rc |= launch_dect_reduce(pend, grads, head_present, s);
+        rc |= side.fork();                            // the reduce of the heads' partial tiles: beside the encoder's data gradients
+        rc |= launch_dect_reduce(pend, grads, head_present, side.stream());
     } else {
+    float* sc = scratch;
     if (occ_runs) {
         rc |= launch_decoder_backward(static_cast<const float*>(planes_nhwc), p_tsdf, blob, bblob, 8, outs, douts,
-                                      detach_occ ? nullptr : gplanes, grads, head_present, scratch, B, M, s, occ_writes);
+                                      detach_occ ? nullptr : gplanes, grads, head_present, sc, B, M, s, occ_writes, &side);
+        sc += dec_bwd_scratch_floats((long long)B * M, 1);       // (its weight gradients may still be reading their rows)
     }
     if ((head_present & 7) && N > 0) {
         rc |= launch_decoder_backward(static_cast<const float*>(planes_nhwc), p, blob, bblob, head_present & 7, outs,
-                                      douts, gplanes, grads, head_present, scratch, B, N, s, false);
+                                      douts, gplanes, grads, head_present, sc, B, N, s, false, &side);
     }
     }
     rc |= launch_encoder_backward(tsdf, blob, bblob, static_cast<const uint8_t*>(enc_workspace_fwd), gplanes, gws,
-                                  grads, head_present, B, s, bf16_convs, convin_mask);
+                                  grads, head_present, B, s, bf16_convs, convin_mask, side);
     return rc;
 }
 

@@ -14,6 +14,7 @@
 // linear_wgrad_kernel then reduces dW = dY^T X and db = colsum(dY) for all layers of a head in ONE launch
 // (MFMA 32x32x2 over pairs of points, operands straight from HBM, one atomic per gradient element per block).
 #include "giga_args.h"
+#include "giga_side.h"
 #include "giga_dev.h"
 
 namespace giga {
@@ -562,7 +563,9 @@ bool dec_bwd_writes_planes(int nheads, int B, int N) { return nheads == 1 && N >
 
 int launch_decoder_backward(const float* planes, const float* p, const uint8_t* blob, const uint8_t* bwd_blob,
                             int head_mask, const float* const* outs, const float* const* douts, float* gplanes,
-                            float* grads, int head_present, float* scratch, int B, int N, hipStream_t s, bool writes_planes) {
+                            float* grads, int head_present, float* scratch, int B, int N, hipStream_t s, bool writes_planes,
+                            SideScope* side) {
+    // side: the weight-gradient launches (they wait for decoder_bwd_kernel's row arrays only) go to the device's side stream
     // writes_planes: this call's plane gradient is built by plane_gather_kernel and WRITTEN into `gplanes` (the caller runs it before
     // the calls that add with atomics and has checked dec_bwd_writes_planes); otherwise it is added to what `gplanes` holds
     const long long P = (long long)B * N;
@@ -598,6 +601,8 @@ int launch_decoder_backward(const float* planes, const float* p, const uint8_t* 
     // weight / bias gradients: one launch per head, or ONE for all heads when their problems fit one argument struct (the three
     // grasp heads of a one-query call: three 6-us launches of a handful of workgroups each)
     const bool merged = a.nheads > 1 && 17 * a.nheads <= LIN_MAX;
+    int frc = 0;
+    if (side) { frc = side->fork(); s = side->stream(); }
     LinArgs L{};
     auto flush = [&]() {
         L.nb_start[L.nprob] = L.nb_total;
@@ -634,7 +639,7 @@ int launch_decoder_backward(const float* planes, const float* p, const uint8_t* 
         if (!merged) flush();
     }
     if (merged) flush();
-    return hipGetLastError() == hipSuccess ? 0 : -10;
+    return hipGetLastError() == hipSuccess ? frc : -10;
 }
 
 }  // namespace giga

@@ -13,6 +13,7 @@
 #include <mutex>
 
 #include "giga_bwd_mega.h"
+#include "giga_side.h"
 #include "giga_args.h"
 
 namespace giga {
@@ -1343,38 +1344,39 @@ __global__ __launch_bounds__(256) void convin_bwd_reduce_kernel(const float* __r
     }
 }
 
-// ------------------------------- the weight gradients' own stream -------------------------------------------------
-// The data-gradient chain (13 convolutions + 2 pooling steps, each waiting for its predecessor) and the 13 weight gradients (each
-// waiting only for ONE link of that chain) are two sequences of latency-bound launches at 2-3 TB/s: run on one stream they take the
-// sum of their times.  The weight gradients therefore go to a second, library-owned stream of the device: forked from the caller's
-// stream with an event behind the link each one needs, joined back into it with one event behind the last reduce, so the caller
-// sees ordinary stream semantics (and a capturing stream captures both branches).  One side stream per device; a mutex covers
-// the enqueue of a whole backward pass because the events are shared by the device's callers.
-struct WgradSide {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork[16] = {};
-    hipEvent_t done = nullptr;
-    bool ok = false;
-};
+// ------------------------------- the library's side stream (giga_side.h) -------------------------------------------
 static std::mutex g_side_mutex;
-static WgradSide g_side[64];
-static WgradSide* wgrad_side_locked() {            // (g_side_mutex held)
+static SideStream g_side[64];
+SideScope::SideScope(hipStream_t main, bool enable) : main_(main) {
+    if (!enable) return;
+    g_side_mutex.lock();
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    WgradSide& w = g_side[dev];
-    if (!w.ok) {
-        if (hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        bool ok = hipEventCreateWithFlags(&w.done, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; i < 16 && ok; ++i) ok = hipEventCreateWithFlags(&w.fork[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) return nullptr;
-        w.ok = true;
+    SideStream* w = (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) ? &g_side[dev] : nullptr;
+    if (w && !w->ok) {
+        bool ok = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; i < 16 && ok; ++i) ok = hipEventCreateWithFlags(&w->fork[i], hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreateWithFlags(&w->join[i], hipEventDisableTiming) == hipSuccess;
+        w->ok = ok;
     }
-    return &w;
+    if (w && w->ok) side_ = w;
+    else g_side_mutex.unlock();
 }
-// giga_forget_device_state(): the handles died with the device's context
-void wgrad_side_forget() {
+SideScope::~SideScope() {
+    if (side_) g_side_mutex.unlock();
+}
+int SideScope::fork() {
+    if (!side_) return 0;
+    hipEvent_t e = side_->fork[nfork_++ & 15];
+    return (hipEventRecord(e, main_) == hipSuccess && hipStreamWaitEvent(side_->stream, e, 0) == hipSuccess) ? 0 : -10;
+}
+int SideScope::join() {
+    if (!side_) return 0;
+    hipEvent_t e = side_->join[njoin_++ & 3];
+    return (hipEventRecord(e, side_->stream) == hipSuccess && hipStreamWaitEvent(main_, e, 0) == hipSuccess) ? 0 : -10;
+}
+void side_streams_forget() {
     std::lock_guard<std::mutex> lk(g_side_mutex);
-    for (WgradSide& w : g_side) w = WgradSide{};
+    for (SideStream& w : g_side) w = SideStream{};
 }
 
 // ------------------------------- driver -----------------------------------------------------------------------
@@ -1412,7 +1414,8 @@ int enc_nxp(int B);
 template <int MATH>
 static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws,
                                  float* gplanes /* [3B][40][40][32], in: dLoss/dPlanes, clobbered */, uint8_t* gws,
-                                 float* grads /* flat, state-dict order */, int head_present, int B, hipStream_t s, bool convin_mask) {
+                                 float* grads /* flat, state-dict order */, int head_present, int B, hipStream_t s, bool convin_mask,
+                                 SideScope& side) {
     if (B <= 0) return 0;
     const PackOff ko = pack_offsets();
     const BwdPackOff bo = bwd_pack_offsets();
@@ -1427,18 +1430,9 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
     // launch per layer, right behind its weight-gradient kernel, as before round 5)
     const bool one_reduce = [] { const char* e = getenv("GIGA_WGRAD_ONE_REDUCE"); return !e || atoi(e) != 0; }();     // (per call)
     Wg3RedArgs RED{};
-    // the weight gradients on the device's side stream (GIGA_WGRAD_STREAM=0: on the caller's stream, between the data gradients)
-    const bool want_side = [] { const char* e = getenv("GIGA_WGRAD_STREAM"); return !e || atoi(e) != 0; }();
-    std::unique_lock<std::mutex> side_lock(g_side_mutex, std::defer_lock);
-    WgradSide* side = nullptr;
-    if (want_side) { side_lock.lock(); side = wgrad_side_locked(); if (!side) side_lock.unlock(); }
-    const hipStream_t ws = side ? side->stream : s;
-    int nfork = 0;
-    auto fork = [&]() {                               // what the caller's stream has enqueued so far precedes what follows on `ws`
-        if (!side) return;
-        hipEvent_t e = side->fork[nfork++ & 15];
-        if (hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(ws, e, 0) != hipSuccess) rc |= -10;
-    };
+    // the weight gradients on the device's side stream (`side`: giga_side.h; inactive = on the caller's stream, between the data gradients)
+    const hipStream_t ws = side.stream();
+    auto fork = [&]() { rc |= side.fork(); };
     // weight gradient of layer l: R = dPre (channels = cout), columns = layer input (in0 [, in1])
     auto wgrad3 = [&](int l, const float* dpre, const float* in0, const float* in1, int H) {
         const ConvLayerDesc& d = kConv[l];
@@ -1579,7 +1573,6 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
         rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(M.layer[12], s);
     }
     rc |= launch_wgrad3_reduce_all(RED, ws);
-    if (side && (hipEventRecord(side->done, ws) != hipSuccess)) rc |= -10;
     // conv_in + projection
     {
         const int nxp = enc_nxp(B);
@@ -1596,15 +1589,16 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
         GIGA_LAUNCH(convin_bwd_reduce_kernel, dim3(CB_PART, 2), dim3(256), 0, s, part, B, nxp, grads + po.conv_in_w,
                            grads + po.conv_in_b);
     }
-    if (side && hipStreamWaitEvent(s, side->done, 0) != hipSuccess) rc |= -10;      // join: the caller's stream carries every gradient
+    rc |= side.join();                                // the caller's stream carries every gradient (the side stream's queue is far behind: its work ended with the reduce)
     if (hipGetLastError() != hipSuccess) rc |= -10;
     return rc;
 }
 
 int launch_encoder_backward(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws, float* gplanes,
-                            uint8_t* gws, float* grads, int head_present, int B, hipStream_t s, bool bf16_convs, bool convin_mask) {
-    return bf16_convs ? encoder_backward_impl<MATH_BF16>(tsdf, blob, bwd_blob, fws, gplanes, gws, grads, head_present, B, s, convin_mask)
-                      : encoder_backward_impl<MATH_NATIVE>(tsdf, blob, bwd_blob, fws, gplanes, gws, grads, head_present, B, s, convin_mask);
+                            uint8_t* gws, float* grads, int head_present, int B, hipStream_t s, bool bf16_convs, bool convin_mask,
+                            SideScope& side) {
+    return bf16_convs ? encoder_backward_impl<MATH_BF16>(tsdf, blob, bwd_blob, fws, gplanes, gws, grads, head_present, B, s, convin_mask, side)
+                      : encoder_backward_impl<MATH_NATIVE>(tsdf, blob, bwd_blob, fws, gplanes, gws, grads, head_present, B, s, convin_mask, side);
 }
 
 }  // namespace giga

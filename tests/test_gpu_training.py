@@ -654,3 +654,42 @@ def test_conv_in_relu_mask_of_the_training_forward(sd7):
                 sure = np.abs(ref) > 1e-5                                     # (fp32 summation order near zero)
                 bad += int(((got[:, wy] != want) & sure).sum()); tot += int(sure.sum())
         assert bad == 0, (B, bad, tot)
+
+
+def test_weight_gradients_on_the_side_stream(sd7, monkeypatch):
+    """The encoder backward enqueues its weight gradients on a library-owned second stream (csrc/giga_encoder_bwd.hip: fork events
+    behind the links of the data-gradient chain, one join) and reduces the 3x3 layers' partials in ONE launch.  Same gradients as the
+    single-stream form with one reduce per layer (GIGA_WGRAD_STREAM=0, GIGA_WGRAD_ONE_REDUCE=0) up to the atomics of the plane
+    gradients and of the decoders' weight gradients (1e-5 of the tensor's range -- measured up to 1.3e-6 at conv_in, the end of the
+    chain; the reduces themselves run in the same order; a missing partial or a race is O(1)); also from a caller on its own torch stream,
+    and again after giga_forget_device_state() dropped the library's stream handles."""
+    from giga_amd import _capi
+    dev = torch.device("cuda:0")
+    x, pos, pos_occ, y = (t.to(dev) if torch.is_tensor(t) else tuple(a.to(dev) for a in t) for t in _batch(90, 5, 300))
+    net = networks.get_network("giga"); net.load_state_dict(sd7); net = net.to(dev).train()
+
+    def grads():
+        net.zero_grad(set_to_none=True)
+        loss, _ = giga_loss(net(x, pos, p_tsdf=pos_occ), y)
+        loss.backward()
+        return {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+
+    monkeypatch.setenv("GIGA_WGRAD_STREAM", "0"); monkeypatch.setenv("GIGA_WGRAD_ONE_REDUCE", "0")
+    ref = grads()
+    monkeypatch.setenv("GIGA_WGRAD_STREAM", "1"); monkeypatch.setenv("GIGA_WGRAD_ONE_REDUCE", "1")
+
+    def check(got):
+        for n, r in ref.items():
+            assert (got[n] - r).abs().max().item() <= 1e-5 * r.abs().max().item() + 1e-9, n
+
+    for _ in range(3):
+        check(grads())
+    own = torch.cuda.Stream(device=dev)
+    own.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(own):
+        g = grads()
+    own.synchronize()
+    check(g)
+    torch.cuda.synchronize()
+    _capi.lib().giga_forget_device_state()                    # (no device reset here: the old handles are simply abandoned)
+    check(grads())
