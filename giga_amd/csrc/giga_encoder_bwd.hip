@@ -10,6 +10,7 @@
 // Weight/bias gradients are ACCUMULATED into the flat fp32 gradient buffer (reference state-dict order) with
 // fp32 atomics (summation order is not fixed, as with PyTorch's own CUDA/HIP backward kernels).
 #include "giga_conv16.h"
+#include <functional>
 #include <mutex>
 
 #include "giga_bwd_mega.h"
@@ -1434,7 +1435,7 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
     const hipStream_t ws = side.stream();
     auto fork = [&]() { rc |= side.fork(); };
     // weight gradient of layer l: R = dPre (channels = cout), columns = layer input (in0 [, in1])
-    auto wgrad3 = [&](int l, const float* dpre, const float* in0, const float* in1, int H) {
+    auto wgrad3_now = [&](int l, const float* dpre, const float* in0, const float* in1, int H) {
         const ConvLayerDesc& d = kConv[l];
         const int cin = d.cin0 + d.cin1, taps = d.kind == CONV3 ? 9 : 1;
         WgradArgs a{};
@@ -1465,7 +1466,7 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
         }
     };
     // ConvTranspose2d(cin, cout, 2, 2): dW[ci][co][d] = sum In[p][ci] * dU[up(p,d)][co]; dU = channels [0,cout) of dcat
-    auto wgrad_up = [&](int l, const float* in, const float* dcat, int cs_cat, int H) {
+    auto wgrad_up_now = [&](int l, const float* in, const float* dcat, int cs_cat, int H) {
         const ConvLayerDesc& d = kConv[l];
         WgradArgs a{};
         a.R = in; a.csR = d.cin0; a.coR = 0;
@@ -1476,6 +1477,27 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
         a.partial = G(g.WG);
         a.db = grads + po.conv_b[l]; a.nbias = d.cout;          // bias gradient = column sums of dU over all four taps
         rc |= launch_wgrad(a, ws);
+    };
+    // Forks are not free (an event record drains the caller's queue between two data gradients, the wait costs the side queue a few
+    // microseconds): GIGA_WGRAD_FORK_EVERY = n enqueues the weight gradients in groups of n behind ONE fork (default 1).
+    const int fork_every = [] { const char* e = getenv("GIGA_WGRAD_FORK_EVERY"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+    std::function<void()> pending[16];
+    int npending = 0;
+    auto flush = [&]() {
+        if (npending == 0) return;
+        fork();
+        for (int i = 0; i < npending; ++i) pending[i]();
+        npending = 0;
+    };
+    auto defer = [&](std::function<void()> f) {
+        pending[npending++] = std::move(f);
+        if (npending >= fork_every) flush();
+    };
+    auto wgrad3 = [&](int l, const float* dpre, const float* in0, const float* in1, int H) {
+        defer([=, &wgrad3_now]() { wgrad3_now(l, dpre, in0, in1, H); });
+    };
+    auto wgrad_up = [&](int l, const float* in, const float* dcat, int cs_cat, int H) {
+        defer([=, &wgrad_up_now]() { wgrad_up_now(l, in, dcat, cs_cat, H); });
     };
     // data gradient of layer l; relu_of: the forward activation the gradient flows into next (ReLU output of the layer
     // below): its backward mask is applied in the convolution's epilogue instead of by a separate pass over the tensor
@@ -1518,7 +1540,6 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
     if (mega > 0) {
         // the weight gradients: every one needs only what the chain has left in memory (dPre of its layer, mask applied) and the
         // forward's activations
-        fork();
         wgrad3(12, gplanes, F(f.A6), nullptr, 40);
         wgrad3(11, G(g.gA6), F(f.A5), nullptr, 40);
         wgrad3(10, G(g.gA5), F(f.U1), F(f.S0), 40);
@@ -1535,43 +1556,44 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
     } else {
         // one launch per stage, the weight gradient of a layer right behind the launch that produced its dPre (it is still in the
         // Infinity Cache then)
-        fork(); wgrad3(12, gplanes, F(f.A6), nullptr, 40);
+        wgrad3(12, gplanes, F(f.A6), nullptr, 40);
         rc |= launch_conv<float, CONV1, 32, 0, 32, 40, 40, 2, false, false, MATH>(M.layer[0], s);
-        fork(); wgrad3(11, G(g.gA6), F(f.A5), nullptr, 40);
+        wgrad3(11, G(g.gA6), F(f.A5), nullptr, 40);
         rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(M.layer[1], s);
-        fork(); wgrad3(10, G(g.gA5), F(f.U1), F(f.S0), 40);
+        wgrad3(10, G(g.gA5), F(f.U1), F(f.S0), 40);
         rc |= launch_conv<float, CONV3, 32, 0, 64, 40, 40, 2, false, false, MATH>(M.layer[2], s);
-        fork(); wgrad_up(9, F(f.A4), G(g.gC1), 64, 20);
+        wgrad_up(9, F(f.A4), G(g.gC1), 64, 20);
         rc |= launch_conv<float, DOWN, 32, 0, 64, 20, 20, 2, false, false, MATH>(M.layer[3], s);
-        fork(); wgrad3(8, G(g.gA4), F(f.A3), nullptr, 20);
+        wgrad3(8, G(g.gA4), F(f.A3), nullptr, 20);
         rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false, MATH>(M.layer[4], s);
-        fork(); wgrad3(7, G(g.gA3), F(f.U0), F(f.S1), 20);
+        wgrad3(7, G(g.gA3), F(f.U0), F(f.S1), 20);
         rc |= launch_conv<float, CONV3, 64, 0, 128, 20, 20, 1, false, false, MATH>(M.layer[5], s);
-        fork(); wgrad_up(6, F(f.S2), G(g.gC0), 128, 10);
+        wgrad_up(6, F(f.S2), G(g.gC0), 128, 10);
         rc |= launch_conv<float, DOWN, 64, 0, 128, 10, 10, 1, false, false, MATH>(M.layer[6], s);
-        fork(); wgrad3(5, G(g.gS2), F(f.A2), nullptr, 10);
+        wgrad3(5, G(g.gS2), F(f.A2), nullptr, 10);
         rc |= launch_conv<float, CONV3, 128, 0, 128, 10, 10, 1, false, false, MATH>(M.layer[7], s);
-        fork(); wgrad3(4, G(g.gA2), F(f.Q1), nullptr, 10);
+        wgrad3(4, G(g.gA2), F(f.Q1), nullptr, 10);
         rc |= launch_conv<float, CONV3, 128, 0, 64, 10, 10, 1, false, false, MATH>(M.layer[8], s);
         {
             const size_t tot = n20 * 64 / 4;
             GIGA_LAUNCH(pool_bwd_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, G(g.gS1),
                                G(g.gC0), 128, 64, G(g.gQ1), F(f.S1), F(f.Q1), nimg, 20, 20, 64);
         }
-        fork(); wgrad3(3, G(g.gS1), F(f.A1), nullptr, 20);
+        wgrad3(3, G(g.gS1), F(f.A1), nullptr, 20);
         rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false, MATH>(M.layer[9], s);
-        fork(); wgrad3(2, G(g.gA1), F(f.Q0), nullptr, 20);
+        wgrad3(2, G(g.gA1), F(f.Q0), nullptr, 20);
         rc |= launch_conv<float, CONV3, 64, 0, 32, 20, 20, 2, false, false, MATH>(M.layer[10], s);
         {
             const size_t tot = n40 * 32 / 4;
             GIGA_LAUNCH(pool_bwd_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, G(g.gS0),
                                G(g.gC1), 64, 32, G(g.gQ0), F(f.S0), F(f.Q0), nimg, 40, 40, 32);
         }
-        fork(); wgrad3(1, G(g.gS0), F(f.A0), nullptr, 40);
+        wgrad3(1, G(g.gS0), F(f.A0), nullptr, 40);
         rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(M.layer[11], s);
-        fork(); wgrad3(0, G(g.gA0), F(f.P0), nullptr, 40);
+        wgrad3(0, G(g.gA0), F(f.P0), nullptr, 40);
         rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(M.layer[12], s);
     }
+    flush();
     rc |= launch_wgrad3_reduce_all(RED, ws);
     // conv_in + projection
     {
