@@ -514,23 +514,7 @@ __device__ __forceinline__ void c32_run(const ConvArgs& a, uint8_t* smem, int me
             __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's share of the weight fill has landed
             __syncthreads();                               // (the compiler waits for the LDS writes before the barrier)
             C32_T(a, 2);
-            // write-allocate by hand (giga_conv16.h: conv16_touch): the member reads one word of every 128-byte line of the output rows it
-            // is about to compute -- here, where its staging loads have landed and the tile phase issues no global load at all: nothing
-            // waits on these loads before the stores' own vmcnt(0), thousands of clocks later
-            unsigned tj[3] = {0u, 0u, 0u};
-            if (a.touch_bytes[0]) {
-                constexpr unsigned rowb = (unsigned)(G::OH / G::H) * G::OW * G::COUT * G::ES;     // output bytes per real input row
-                const int ra = G::real_rows_below(sb, a.nimg), rb = G::real_rows_below(sb + R, a.nimg);
-                const unsigned lines = ((unsigned)(rb - ra) * rowb + 127u) >> 7;
-                const char* tb = reinterpret_cast<const char*>(a.out) + (size_t)ra * rowb;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const unsigned l = threadIdx.x + k * (C32_NW * 64);
-                    if (l < lines) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(tj[k]) : "v"(tb + ((size_t)l << 7)) : "memory");
-                }
-            }
             c32_tiles_any<G, RELU>(a, smem, sgm, G::n_tiles(R), sb, R, 0);
-            if (a.touch_bytes[0]) asm volatile("s_waitcnt vmcnt(0)" : "+v"(tj[0]), "+v"(tj[1]), "+v"(tj[2]) : : "memory");
             C32_T(a, 3);
         }
     }

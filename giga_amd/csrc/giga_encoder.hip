@@ -492,8 +492,6 @@ struct MegaArgs {
     ConvArgs layer[NCONV];
     unsigned* sync;            // words zeroed by plane_finalize_kernel: [x * 32] ticket counter of XCD x, [(8 + q) * 32] arrival counter of group q
     int nlayers;               // 12 (conv_final folded into the decoder) or 13
-    int touch;                 // 1: a helper wave per workgroup reads the lines of the next layer's output region (conv16_touch)
-    unsigned out_img_bytes[NCONV], pool_img_bytes[NCONV];   // bytes of one image of layer l's output / pooled output (0: none)
 };
 constexpr int MEGA_GROUP = 8;                     // workgroups per group
 constexpr int MEGA_SLOTS = 4;                     // group slots per XCD at most: 8 x 4 x 8 = 256 workgroups, one per CU
@@ -582,7 +580,7 @@ __device__ __forceinline__ ConvArgs conv_image_range(ConvArgs a, int img0, int n
 }
 
 template <typename T, int MATH>
-__global__ __launch_bounds__((MEGA_NW + 1) * 64) void unet_mega_kernel(MegaArgs m) {
+__global__ __launch_bounds__(MEGA_NW * 64) void unet_mega_kernel(MegaArgs m) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // A workgroup finds its place by TICKET, not by blockIdx: it reads the XCD it runs on from the hardware (XCC_ID) and draws a
     // number from that XCD's ticket counter; ticket t is member t % 8 of group slot t / 8 on that XCD.
@@ -612,16 +610,8 @@ __global__ __launch_bounds__((MEGA_NW + 1) * 64) void unet_mega_kernel(MegaArgs 
     unsigned epoch = 0;
 #define X(l, KIND, C0, C1, COUT, H, W, NB, POOL, NB16)                                                                     \
     if (l < m.nlayers) {                                                                                                   \
-        ConvArgs a = conv_image_range<T, KIND, C0, C1, COUT, H, W>(m.layer[l], img0, per);                                 \
+        const ConvArgs a = conv_image_range<T, KIND, C0, C1, COUT, H, W>(m.layer[l], img0, per);                           \
         if (l == 0) conv16_fill<T, KIND, C0, C1, COUT, (sizeof(T) == 2 ? NB16 : NB), MATH>(a, smem, block, nblocks);                \
-        if (m.touch && l + 1 < NCONV && l + 1 < m.nlayers) { /* the helper wave reads the lines layer l + 1 will write (conv16_touch) */ \
-            a.touch[0] = reinterpret_cast<const char*>(m.layer[(l + 1) % NCONV].out) + (size_t)img0 * m.out_img_bytes[(l + 1) % NCONV];        \
-            a.touch_bytes[0] = (unsigned)per * m.out_img_bytes[(l + 1) % NCONV];                                                     \
-            if (m.pool_img_bytes[(l + 1) % NCONV]) {                                                                                 \
-                a.touch[1] = reinterpret_cast<const char*>(m.layer[(l + 1) % NCONV].out_pool) + (size_t)img0 * m.pool_img_bytes[(l + 1) % NCONV]; \
-                a.touch_bytes[1] = (unsigned)per * m.pool_img_bytes[(l + 1) % NCONV];                                                \
-            }                                                                                                              \
-        }                                                                                                                  \
         conv16_run<T, KIND, C0, C1, COUT, H, W, (sizeof(T) == 2 ? NB16 : NB), POOL, KIND == CONV3, MATH>(a, smem, block, nblocks); \
         __builtin_amdgcn_s_waitcnt(0x0F70);            /* vmcnt(0): this wave's output stores are in the L2 */              \
         __syncthreads();                               /* ... everyone's, and everyone has left the weights in LDS */       \
@@ -800,9 +790,7 @@ __global__ __launch_bounds__(C32_NW * 64) void unet32_mega_kernel(MegaArgs m) {
     }
 #define RUN(l)                                                                                                     \
     if (l < m.nlayers) {                                                                                           \
-        ConvArgs a##l = c32_image_range<G##l>(m.layer[l], img0, per);                                              \
-        a##l.touch_bytes[0] = (unsigned)m.touch;       /* flag: c32_run pre-reads its output lines */              \
-        c32_run<G##l, U32Layer<MODE, l>::RELU>(a##l, smem, block);                                                 \
+        c32_run<G##l, U32Layer<MODE, l>::RELU>(c32_image_range<G##l>(m.layer[l], img0, per), smem, block);         \
         __builtin_amdgcn_s_waitcnt(0x0F70);            /* vmcnt(0): this wave's output stores are in the L2 */      \
         __syncthreads();                                                                                           \
         MEGA32_T(l, 4);                                                                                            \
@@ -1089,8 +1077,6 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
                 for (int l = 0; l < NCONV; ++l) m.layer[l] = M[l];
                 m.sync = reinterpret_cast<unsigned*>(b + w.SYNC);
                 m.nlayers = nlayers;
-                static const int env_touch32 = [] { const char* e = getenv("GIGA_C32_TOUCH"); return e ? atoi(e) : 0; }();   // off: measured slower (profiles/r05/unet_touch_ab.txt)
-                m.touch = env_touch32;
                 const unsigned grid = (unsigned)c32_groups(nimg) * MEGA_GROUP;
                 // fused same-resolution pairs (C32Pair) while a member's rows fit ONE sub-band of the pair (up to two images per
                 // group: the halo rows a member recomputes are 2 of ~12; beyond that the pair needs smaller sub-bands than the
@@ -1128,13 +1114,6 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
         for (int l = 0; l < NCONV; ++l) { m.layer[l] = L[l]; m.layer[l].xcd_local = 0; }   // (the kernel hands every group its images itself)
         m.sync = reinterpret_cast<unsigned*>(b + w.SYNC);
         m.nlayers = nlayers;
-        static const int env_touch = [] { const char* e = getenv("GIGA_UNET_TOUCH"); return e ? atoi(e) : 0; }();   // off: measured slower for conv16 (profiles/r05/unet_touch_ab.txt)
-        m.touch = env_touch;
-        for (int l = 0; l < NCONV; ++l) {
-            const ConvLayerDesc& d = kConv[l];
-            m.out_img_bytes[l] = (unsigned)((d.kind == UPCONV ? 4 : 1) * d.H * d.W * d.cout * sizeof(T));
-            m.pool_img_bytes[l] = d.pool ? (unsigned)((d.H / 2) * (d.W / 2) * d.cout * sizeof(T)) : 0u;
-        }
         const int slots = (nimg + 7) / 8 < MEGA_SLOTS ? (nimg + 7) / 8 : MEGA_SLOTS;
         const unsigned grid = 8u * (unsigned)slots * MEGA_GROUP;
         auto kern = unet_mega_kernel<T, MATH>;
@@ -1143,7 +1122,7 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
         giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
         stage_no = 15;                                        // probe stage 15 = the whole U-Net
         pre();
-        GIGA_LAUNCH(kern, dim3(grid), dim3((MEGA_NW + (m.touch ? 1 : 0)) * 64), lds, s, m);
+        GIGA_LAUNCH(kern, dim3(grid), dim3(MEGA_NW * 64), lds, s, m);
         persistent_launched(mega_slot, s);
         post();
         return hipGetLastError() == hipSuccess ? 0 : -10;
