@@ -15,11 +15,9 @@ python tools/prof_summary.py /tmp/prof_core $O/bench_core_kernel_stats.txt
 python tools/prof_summary.py /tmp/prof_train $O/train_kernel_stats.txt
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_train16 -o t -- python $R/tools/gpu_prof.py train_bf16_flat 10 > $O/prof_train_bf16.log 2>&1 ); echo "rocprof train bf16 rc=$?"
 python tools/prof_summary.py /tmp/prof_train16 $O/train_bf16_kernel_stats.txt
-bash tools/gpu_traffic.sh "c2 c4step c4step_x3" > $O/traffic.txt 2>&1; echo "traffic rc=$?"; cp gpurun_out/traffic/*.json $O/ 2>/dev/null
-bash tools/gpu_pmc.sh "c4step c4step_x3 c2" > $O/pmc.txt 2>&1; echo "pmc rc=$?"; grep -E "==|giga" $O/pmc.txt | cut -c1-250 | tail -n 45
-# the conv32 U-Net kernels under the same counters at 32 scenes, where conv16 is the default (GIGA_CONV32=1 forces them for the whole process)
-rm -rf gpurun_out/pmc; GIGA_CONV32=1 bash tools/gpu_pmc.sh "c4step c4step_x3" > $O/pmc_conv32.txt 2>&1; echo "pmc conv32 rc=$?"; grep -E "==|unet" $O/pmc_conv32.txt | cut -c1-250
-# conv16 against conv32 in one process, interleaved (the A/B that survives box drift), and the sustained-load clocks
-GIGA_PRECS=fp16,fp16x3 timeout 600 python tools/gpu_unet_ab.py 1 2 8 32 128 > $O/unet_ab.txt 2>&1; echo "unet_ab rc=$?"; grep B= $O/unet_ab.txt | cut -c1-180
-timeout 300 python tools/gpu_sustained_power.py 32 128 > $O/sustained_power.txt 2>&1; grep B= $O/sustained_power.txt | cut -c1-200
+bash tools/gpu_traffic.sh "c2 c4step c4step_x3 train_flat train_bf16_flat" > $O/traffic.txt 2>&1; echo "traffic rc=$?"; cp gpurun_out/traffic/*.json $O/ 2>/dev/null
+bash tools/gpu_pmc.sh "c4step c4step_x3 c2 train_bf16_flat" > $O/pmc.txt 2>&1; echo "pmc rc=$?"; grep -E "==|giga" $O/pmc.txt | cut -c1-250 | tail -n 70
+# round 5: every launch of a c5 step in order (event brackets on the launch's own stream), both precisions
+timeout 300 python tools/gpu_c5_launches.py bf16 > $O/c5_bf16_launches.txt 2>&1; timeout 300 python tools/gpu_c5_launches.py fp32 > $O/c5_fp32_launches.txt 2>&1
+timeout 300 python tools/gpu_c5_time.py > $O/c5_step_times.txt 2>&1; tail -n 3 $O/c5_step_times.txt
 tail -n 45 $O/traffic.txt
