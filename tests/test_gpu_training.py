@@ -693,3 +693,40 @@ def test_weight_gradients_on_the_side_stream(sd7, monkeypatch):
     torch.cuda.synchronize()
     _capi.lib().giga_forget_device_state()                    # (no device reset here: the old handles are simply abandoned)
     check(grads())
+
+
+def test_training_forward_backward_captured_in_a_hip_graph(sd7):
+    """A caller may capture forward + loss + backward into a hipGraph (torch.cuda.graph): the backward's second stream is forked from
+    and joined back into the capturing stream with events, so the capture takes both branches and ends with nothing left outside it.
+    Replays reproduce the eager gradients (to the atomics' rounding)."""
+    dev = torch.device("cuda:0")
+    x, pos, pos_occ, y = (t.to(dev) if torch.is_tensor(t) else tuple(a.to(dev) for a in t) for t in _batch(95, 4, 256))
+    net = networks.get_network("giga"); net.load_state_dict(sd7); net = net.to(dev).train()
+    flat = net.flatten_parameters()[0]
+
+    def step():
+        loss, _ = giga_loss(net(x, pos, p_tsdf=pos_occ), y)
+        loss.backward()
+        return loss
+
+    flat.grad = None
+    step()
+    ref = flat.grad.detach().clone()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(3):                                   # warm-up on the capture stream (allocator, lazy handles)
+            flat.grad = None
+            step()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    flat.grad = torch.zeros_like(flat)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        loss = step()
+    for _ in range(2):
+        flat.grad.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert (flat.grad - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    assert abs(loss.item() - step().item()) < 1e-6
