@@ -32,7 +32,6 @@ int launch_decoder_backward(const float* planes, const float* p, const uint8_t* 
                             SideScope* side);
 int launch_plane_gather(const float* dcbuf, const float* p, float* gplanes, int B, int N, hipStream_t s);
 // giga_decoder_train16.hip (bf16 decoder of the bf16 training step)
-struct DectPending { const float* partial[NHEADS]; int nwg[NHEADS]; int head_id[NHEADS]; int n; };
 int launch_dect_forward(const float* planes, const float* p, const uint8_t* blob, int head_mask, float* const* outs, int B, int N,
                         int post, hipStream_t s);
 size_t dect_partial_floats(long long P, int nheads);

@@ -693,7 +693,6 @@ size_t dect_partial_floats(long long P, int nheads) { return P > 0 ? (size_t)dec
 
 // One decoder-backward call on the bf16 kernels.  `scratch` receives the partial tiles (dect_partial_floats) and, with dcrows, the
 // [P][96] rows behind them; the reduce is enqueued by launch_dect_reduce once all calls of the step have run.
-struct DectPending { const float* partial[NHEADS]; int nwg[NHEADS]; int head_id[NHEADS]; int n; };
 int launch_dect_backward(const float* planes, const float* p, const uint8_t* blob, const uint8_t* bwd_blob, int head_mask,
                          const float* const* outs, const float* const* douts, float* gplanes, float* dcbuf, float* scratch, int B,
                          int N, hipStream_t s, DectPending* pend) {

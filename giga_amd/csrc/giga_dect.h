@@ -132,4 +132,8 @@ __device__ inline void dect_derive_block(uint8_t* fwd_blob, uint8_t* bwd_blob, i
 }
 
 
+// partial weight-gradient tiles of the fused backward launches of one step, waiting for dect_reduce_kernel (ONE definition for
+// giga_decoder_train16.hip and its caller giga_capi.hip)
+struct DectPending { const float* partial[NHEADS]; int nwg[NHEADS]; int head_id[NHEADS]; int n; };
+
 }  // namespace giga

@@ -1346,24 +1346,25 @@ __global__ __launch_bounds__(256) void convin_bwd_reduce_kernel(const float* __r
 }
 
 // ------------------------------- the library's side stream (giga_side.h) -------------------------------------------
-static std::mutex g_side_mutex;
+static std::mutex g_side_mutex[64];               // one per device: callers on different devices do not wait for each other
 static SideStream g_side[64];
 SideScope::SideScope(hipStream_t main, bool enable) : main_(main) {
     if (!enable) return;
-    g_side_mutex.lock();
     int dev = 0;
-    SideStream* w = (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) ? &g_side[dev] : nullptr;
-    if (w && !w->ok) {
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    g_side_mutex[dev].lock();
+    SideStream* w = &g_side[dev];
+    if (!w->ok) {
         bool ok = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) == hipSuccess;
         for (int i = 0; i < 16 && ok; ++i) ok = hipEventCreateWithFlags(&w->fork[i], hipEventDisableTiming) == hipSuccess;
         for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreateWithFlags(&w->join[i], hipEventDisableTiming) == hipSuccess;
         w->ok = ok;
     }
-    if (w && w->ok) side_ = w;
-    else g_side_mutex.unlock();
+    if (w->ok) { side_ = w; dev_ = dev; }
+    else g_side_mutex[dev].unlock();
 }
 SideScope::~SideScope() {
-    if (side_) g_side_mutex.unlock();
+    if (side_) g_side_mutex[dev_].unlock();
 }
 int SideScope::fork() {
     if (!side_) return 0;
@@ -1376,8 +1377,10 @@ int SideScope::join() {
     return (hipEventRecord(e, side_->stream) == hipSuccess && hipStreamWaitEvent(main_, e, 0) == hipSuccess) ? 0 : -10;
 }
 void side_streams_forget() {
-    std::lock_guard<std::mutex> lk(g_side_mutex);
-    for (SideStream& w : g_side) w = SideStream{};
+    for (int d = 0; d < 64; ++d) {
+        std::lock_guard<std::mutex> lk(g_side_mutex[d]);
+        g_side[d] = SideStream{};
+    }
 }
 
 // ------------------------------- driver -----------------------------------------------------------------------

@@ -3,7 +3,7 @@
 // of such a chain only (the 13 weight gradients, the decoders' weight-gradient reduces): on one stream they take the sum of their
 // times, at 2-3 TB/s and a few per cent of the MFMA rate.  The second kind therefore goes to a library-owned stream: forked from the
 // caller's stream with an event behind the launch each one needs, joined back with one event, so the caller sees ordinary stream
-// semantics (a capturing stream captures both branches).  One side stream per device; a SideScope holds the device table's mutex
+// semantics (a capturing stream captures both branches).  One side stream per device; a SideScope holds that device's mutex
 // for the enqueue of a whole backward pass because the events are shared by the device's callers.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -34,7 +34,7 @@ class SideScope {
   private:
     hipStream_t main_;
     SideStream* side_ = nullptr;
-    int nfork_ = 0, njoin_ = 0;
+    int nfork_ = 0, njoin_ = 0, dev_ = 0;
 };
 
 void side_streams_forget();       // giga_forget_device_state(): the handles died with the device's context
