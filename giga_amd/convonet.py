@@ -604,8 +604,8 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
     def set_train_precision(self, precision):
         """Arithmetic of the differentiable forward/backward (giga_amd/training.py): "fp32" (default), "bf16" (BASELINE config
         c5: bf16 MFMA operands / fp32 accumulation in the U-Net's forward, data-gradient and 3x3 weight-gradient convolutions AND in
-        the decoder heads -- forward, gradient chain and weight gradients in one fused kernel per call; fp32 activations in
-        memory, fp32 conv_in, master weights and optimizer) or "bf16_convs" (the convolutions only; fp32 decoders)."""
+        the decoder heads -- forward, gradient chain and weight gradients in one fused kernel per call; conv_in's forward on the f16
+        MFMA; fp32 activations in memory, master weights and optimizer) or "bf16_convs" (the convolutions only; fp32 decoders)."""
         if precision not in ("fp32", "bf16", "bf16_convs"):
             raise ValueError(precision)
         self._train_bf16 = precision != "fp32"

@@ -966,10 +966,12 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     float* YZP = XZP + 4 * per;
     const int nxp = enc_nxp(B);
     // conv_in arithmetic: fp32 MFMA (precision 0), the f16 MFMA with hi only (plain f16) or with f16x3 split operands (precision 2).
-    // The bf16 training forward (MATH_BF16) takes the f16x3 form too -- fp32-grade results (<= 1e-5 of the fp32 kernel: the backward's
-    // fp32 recomputation of the ReLU mask agrees with it) on three f16 MFMAs per unit instead of seven fp32 ones; its operand image
-    // (convin_ws) is rebuilt on the device with the other derived images (giga_derive_bf16_fragments).  GIGA_BF16_CONVIN=0: fp32.
-    static const bool bf_ci16 = [] { const char* e = getenv("GIGA_BF16_CONVIN"); return !e || atoi(e) != 0; }();
+    // The bf16 training forward (MATH_BF16): PLAIN f16 operands when it also stores the ReLU mask for the backward (GIGA_CONVIN_MASK:
+    // the backward then uses the forward's own decisions; f16's 11 bits are finer than the bf16 rounding the next layer applies to
+    // this kernel's output; -17 us per step against the split form), else the f16x3 form -- fp32-grade (<= 1e-5 of the fp32 kernel),
+    // so that a backward that RECOMPUTES the mask in fp32 agrees with it.  The operand image (convin_ws) is rebuilt on the device with
+    // the other derived images (giga_derive_bf16_fragments).  GIGA_BF16_CONVIN = 0: fp32 MFMA, 1: f16x3 always, 2 (default): as above.
+    static const int bf_ci16 = [] { const char* e = getenv("GIGA_BF16_CONVIN"); return e ? atoi(e) : 2; }();   // 0 fp32, 1 f16x3, 2 plain f16 (default)
     uint4* mask_out = keep_mask ? reinterpret_cast<uint4*>(ws + w.MASK) : nullptr;
     auto run_convin = [&](auto f16c, auto lo, auto msk) {
         constexpr bool CI_F16 = decltype(f16c)::value, CI_LO = decltype(lo)::value, MK = decltype(msk)::value;
@@ -995,7 +997,8 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     if constexpr (SPLIT) run_convin(TT{}, TT{}, FF{});
     else if constexpr (sizeof(T) == 2) run_convin(TT{}, FF{}, FF{});
     else if constexpr (MATH == MATH_BF16) {
-        if (bf_ci16) { if (keep_mask) run_convin(TT{}, TT{}, TT{}); else run_convin(TT{}, TT{}, FF{}); }
+        if (bf_ci16 == 2 && keep_mask) run_convin(TT{}, FF{}, TT{});
+        else if (bf_ci16) { if (keep_mask) run_convin(TT{}, TT{}, TT{}); else run_convin(TT{}, TT{}, FF{}); }
         else { if (keep_mask) run_convin(FF{}, FF{}, TT{}); else run_convin(FF{}, FF{}, FF{}); }
     } else { if (keep_mask) run_convin(FF{}, FF{}, TT{}); else run_convin(FF{}, FF{}, FF{}); }
     post();

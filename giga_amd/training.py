@@ -3,7 +3,7 @@
 fp32-input MFMA; gradients match torch autograd to <= 6e-6 relative), "bf16" (BASELINE config c5: the forward, data-gradient
 and weight-gradient GEMMs of the 3x3 U-Net layers AND the decoder heads -- forward, gradient chain and weight gradients in one fused
 kernel per call, csrc/giga_decoder_train16.hip -- take bf16 operands with fp32 accumulation on the bf16 MFMA; activations in memory,
-conv_in (f16x3 forward: fp32-grade), ConvTranspose / 1x1 weight gradients, master weights and the optimizer stay fp32, as under
+conv_in's backward (its forward runs on the f16 MFMA: 11-bit operands), ConvTranspose / 1x1 weight gradients, master weights and the optimizer stay fp32, as under
 torch.autocast; gradients then carry bf16 operand rounding) and "bf16_convs" (the convolutions only; fp32 decoders).
 The backward runs its weight gradients on a second, library-owned stream beside the data-gradient chain and joins it back into the
 caller's stream before it returns (csrc/giga_side.h).
