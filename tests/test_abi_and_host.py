@@ -270,3 +270,20 @@ def test_packed_blob_stamp_and_check():
     stale = blob.clone(); stale[-256 + 8] = 1                                       # ABI version 1 in the stamp
     assert lib.giga_packed_check(_capi.ptr(stale), stale.numel(), 0) == -8
     assert lib.giga_packed_check(None, 0, 0) == -1 and lib.giga_strerror(-8).startswith(b"packed blob was not produced")
+
+
+def test_precision_tables_cover_every_named_mode():
+    """Every name of `net.set_precision` maps to an encoder precision, a generic-decoder precision, a lattice-decoder precision
+    (with its flags) and a plane element type; the mixed mode 'fp16x3+fp16' is the f16x3 encoder (fp32 planes) under the plain-f16
+    lattice decoder with GIGA_PLANES_FP32 (include/giga_hip.h) and the f16x3 decoder for other query sets."""
+    import torch
+    from giga_amd import _capi
+    for name, v in _capi.PRECISION.items():
+        for table in (_capi.ENCODER_PRECISION, _capi.DECODER_PRECISION, _capi.LATTICE_PRECISION, _capi.PLANE_DTYPE):
+            assert v in table, (name, table)
+        assert _capi.PLANE_DTYPE[v] == _capi.PLANE_DTYPE[_capi.ENCODER_PRECISION[v]], name     # planes are the ENCODER's
+    m = _capi.PRECISION["fp16x3+fp16"]
+    assert _capi.ENCODER_PRECISION[m] == 2 and _capi.DECODER_PRECISION[m] == 2 and _capi.PLANE_DTYPE[m] == torch.float32
+    assert _capi.LATTICE_PRECISION[m] == (1 | _capi.PLANES_FP32) and _capi.PLANES_FP32 == 1024
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "giga_hip.h")).read()
+    assert "#define GIGA_PLANES_FP32 1024" in hdr
