@@ -730,3 +730,39 @@ def test_training_forward_backward_captured_in_a_hip_graph(sd7):
         torch.cuda.synchronize()
         assert (flat.grad - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
     assert abs(loss.item() - step().item()) < 1e-6
+
+
+@pytest.mark.parametrize("model,prec,B,N,M", [("giga", "fp32", 1, 1, 64), ("giga", "bf16", 7, 3, 300), ("giga", "bf16", 33, 1, 256),
+                                              ("giga_aff", "fp32", 5, 2, 0), ("giga_aff", "bf16", 17, 1, 0), ("giga_detach", "bf16", 4, 1, 256)])
+def test_backward_at_odd_shapes_with_and_without_the_side_stream(model, prec, B, N, M, monkeypatch):
+    """Ragged batch sizes on both sides of the kernels' size switches (1, 7, 33 scenes; several grasp queries per scene; no occupancy
+    head at all: giga_aff), fp32 and bf16: the backward with its weight gradients on the second stream and ONE reduce launch against the
+    single-stream form with per-layer reduces -- same sums in the same order (fp32: 1e-5 of the tensor's range, what the decoders'
+    atomics leave; bf16: 2e-3, a rounding flip in the heads' atomically summed plane gradients moves a bf16 operand) -- and finite."""
+    dev = torch.device("cuda:0")
+    sd = weights.make_state_dict(7, with_tsdf=model != "giga_aff")
+    net = networks.get_network(model); net.load_state_dict(sd); net = net.to(dev).train().set_train_precision(prec)
+    x = torch.from_numpy(synth.tsdf_batch(640, B)).to(dev)
+    pos = torch.from_numpy(synth.query_points(640, B, N, stream=2)).to(dev)
+    pos_occ = torch.from_numpy(synth.query_points(640, B, M, stream=3)).to(dev) if M else None
+    g = torch.Generator().manual_seed(3)
+    R = None
+
+    def grads():
+        nonlocal R
+        net.zero_grad(set_to_none=True)
+        out = net(x, pos, p_tsdf=pos_occ) if M else net(x, pos)
+        if R is None:
+            R = [torch.randn(o.shape, generator=g).to(dev) / max(1, o[0].numel()) for o in out]
+        sum((o * r).sum() for o, r in zip(out, R)).backward()
+        return {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    monkeypatch.setenv("GIGA_WGRAD_STREAM", "0"); monkeypatch.setenv("GIGA_WGRAD_ONE_REDUCE", "0")
+    ref = grads()
+    monkeypatch.setenv("GIGA_WGRAD_STREAM", "1"); monkeypatch.setenv("GIGA_WGRAD_ONE_REDUCE", "1")
+    got = grads()
+    assert set(ref) == set(got) and len(ref) >= 100
+    tol = 1e-5 if prec == "fp32" else 2e-3
+    for n, r in ref.items():
+        assert torch.isfinite(got[n]).all(), n
+        assert (got[n] - r).abs().max().item() <= tol * r.abs().max().item() + 1e-9, n
