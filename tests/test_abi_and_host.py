@@ -287,3 +287,19 @@ def test_precision_tables_cover_every_named_mode():
     assert _capi.LATTICE_PRECISION[m] == (1 | _capi.PLANES_FP32) and _capi.PLANES_FP32 == 1024
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "giga_hip.h")).read()
     assert "#define GIGA_PLANES_FP32 1024" in hdr
+
+
+def test_every_header_is_a_build_dependency():
+    """giga_amd/csrc/Makefile: editing ANY header of csrc/ (or include/giga_hip.h) makes `make` want to recompile.  Round 5's
+    hand-kept HDRS list had lost giga_side.h: build.py noticed the edit, called make, and make rebuilt nothing.
+    `make -n -W file` treats `file` as just modified without touching it."""
+    import glob
+    import subprocess
+    csrc = os.path.join(ROOT, "giga_amd", "csrc")
+    hdrs = sorted(glob.glob(os.path.join(csrc, "*.h"))) + [os.path.join(ROOT, "include", "giga_hip.h")]
+    assert any(h.endswith("giga_side.h") for h in hdrs) and len(hdrs) >= 11
+    for h in hdrs:
+        rel = os.path.relpath(h, csrc)
+        r = subprocess.run(["make", "-n", "-W", rel], cwd=csrc, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.count("hipcc") >= 2 and "-shared" in r.stdout, f"{rel}: a change would not rebuild the library"
