@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
     if (argc != 7) { std::fprintf(stderr, "usage: %s params.bin tsdf.bin points.bin B N out.bin\n", argv[0]); return 1; }
     const int B = std::atoi(argv[4]), N = std::atoi(argv[5]);
     const int heads = 15;                                  // qual | rot | width | occupancy
-    if (giga_abi_version() != 2) { std::fprintf(stderr, "ABI version mismatch\n"); return 1; }
+    if (giga_abi_version() != 3) { std::fprintf(stderr, "ABI version mismatch\n"); return 1; }
     std::vector<float> params, tsdf, pts;
     const size_t nparam = giga_param_count(heads);
     if (!read_file(argv[1], params, nparam) || !read_file(argv[2], tsdf, (size_t)B * 64000) ||

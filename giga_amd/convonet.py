@@ -258,7 +258,8 @@ class LocalVoxelEncoder(nn.Module):
             _capi.check(L.giga_encoder_forward_probe(_capi.ptr(x), _capi.ptr(blob), _capi.ptr(nhwc), _capi.ptr(nchw),
                                                      B, prec | (_capi.FOLD_FINAL if fold_final else 0) |
                                                      {False: 0, True: _capi.PERSIST_UNET, "layers": _capi.LAYERWISE_UNET}[getattr(self, "persistent_unet", False)] |
-                                                     ({"conv32": _capi.CONV32_UNET, "conv16": _capi.CONV16_UNET}.get(getattr(self, "unet_kernel", "auto"), 0) if prec in (1, 2) else 0),
+                                                     ({"conv32": _capi.CONV32_UNET, "conv16": _capi.CONV16_UNET}.get(getattr(self, "unet_kernel", "auto"), 0) if prec in (1, 2) else 0) |
+                                                     (_capi.DIRECT_CONV if prec == 0 and getattr(self, "unet_kernel", "auto") == "direct" else 0),
                                                      _capi.ptr(ws), ws.numel(), _capi.stream_ptr(x.device),
                                                      stage, ev0, ev1),
                         "giga_encoder_forward")
@@ -530,8 +531,10 @@ class ConvolutionalOccupancyNetwork(_ParamListCache, nn.Module):
         "auto" (the library's default: conv32 -- 32x32x16 MFMA register tiles over LDS-resident row bands, same-resolution layer pairs
         fused -- up to 16 scenes, conv16 beyond; the environment variable GIGA_CONV32=0 / 1 overrides), "conv32" or "conv16" (16x16x32,
         wave-private patches; the only kernels of 'fp32' / 'bf16').  A forced kernel makes a scene's result independent of the batch
-        size it runs in (bit for bit); "auto" does not across the 16-scene threshold."""
-        if kernel not in ("auto", "conv16", "conv32"):
+        size it runs in (bit for bit); "auto" does not across the 16-scene threshold.
+        'fp32' only: "direct" keeps the direct 3x3 convolutions (GIGA_DIRECT_CONV) where "auto" runs them as Winograd F(2x2, 3x3) on the
+        fp32 MFMA (csrc/giga_wino.h; planes within a few 1e-6 relative of the direct form)."""
+        if kernel not in ("auto", "conv16", "conv32", "direct"):
             raise ValueError(kernel)
         self.encoder.unet_kernel = kernel
         return self

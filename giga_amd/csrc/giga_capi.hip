@@ -263,14 +263,14 @@ int giga_repack_device(const float* params_dev, const int32_t* map_dev, void* pa
 }
 
 size_t giga_encoder_workspace_bytes(int B, int precision) {
-    precision &= ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET | GIGA_CONVIN_MASK);
+    precision &= ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET | GIGA_CONVIN_MASK | GIGA_DIRECT_CONV);
     if (B <= 0) return 0;
     return enc_workspace(B, precision).total;
 }
 
 int giga_encoder_workspace_layout(int B, int precision, size_t* offsets) {
     if (B <= 0 || !offsets) return -1;
-    precision &= ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET | GIGA_CONVIN_MASK);
+    precision &= ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET | GIGA_CONVIN_MASK | GIGA_DIRECT_CONV);
     if (precision < 0 || precision > 3) return -5;
     const EncWs w = enc_workspace(B, precision);
     const size_t v[17] = {w.P0, w.A0, w.S0, w.Q0, w.A1, w.S1, w.Q1, w.A2, w.S2, w.U0, w.A3, w.A4, w.U1, w.A5, w.A6,
@@ -285,9 +285,12 @@ int giga_encoder_forward_probe(const float* tsdf, const void* packed, void* plan
     if (B < 0 || (B > 0 && (!tsdf || !packed || !planes_nhwc || !workspace))) return -1;
     if (B > GIGA_MAX_SCENES) return -7;
     const bool fold = (precision & GIGA_FOLD_FINAL) != 0;     // stop before conv_final (folded decoder images)
-    const int persist = precision & (GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET | GIGA_CONVIN_MASK);   // U-Net launch form and kernels (see the header)
-    precision &= ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET | GIGA_CONVIN_MASK);
+    const int persist = precision & (GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET | GIGA_CONVIN_MASK | GIGA_DIRECT_CONV);   // U-Net launch form and kernels (see the header)
+    precision &= ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET | GIGA_CONVIN_MASK | GIGA_DIRECT_CONV);
     if (precision < 0 || precision > 3) return -5;
+    // only the fp32 and bf16 encoders store conv_in's ReLU mask: a precision 1 / 2 forward that claims to would leave giga_backward
+    // (GIGA_CONVIN_MASK_BWD) reading workspace bytes nobody wrote
+    if ((persist & GIGA_CONVIN_MASK) && (precision == 1 || precision == 2)) return -5;
     if (fold && planes_nchw) return -1;                       // the reference-layout copy is the FINAL planes only
     if (workspace_bytes < giga_encoder_workspace_bytes(B, precision)) return -4;
     return launch_encoder(tsdf, static_cast<const uint8_t*>(packed), planes_nhwc, planes_nchw, B,

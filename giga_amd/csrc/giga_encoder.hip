@@ -13,6 +13,7 @@
 #include "giga_dev.h"
 #include "giga_conv16.h"
 #include "giga_conv32.h"
+#include "giga_wino.h"
 #include "giga_bwd_mega.h"
 #include "giga_args.h"
 
@@ -492,6 +493,7 @@ struct MegaArgs {
     ConvArgs layer[NCONV];
     unsigned* sync;            // words zeroed by plane_finalize_kernel: [x * 32] ticket counter of XCD x, [(8 + q) * 32] arrival counter of group q
     int nlayers;               // 12 (conv_final folded into the decoder) or 13
+    unsigned wino_mask;        // bit l: layer l (a 3x3 layer of the exact-fp32 path) runs as Winograd F(2x2, 3x3) (giga_wino.h)
 };
 constexpr int MEGA_GROUP = 8;                     // workgroups per group
 constexpr int MEGA_SLOTS = 4;                     // group slots per XCD at most: 8 x 4 x 8 = 256 workgroups, one per CU
@@ -503,11 +505,12 @@ constexpr int MEGA_NW = CONV_NW;                  // waves per workgroup of the 
 constexpr unsigned long long MEGA_SPIN_TICKS = 20ull * 100000000ull;
 constexpr int MEGA_MAX_IN_FLIGHT = 4;             // persistent launches in flight per device (see persistent_slot below)
 
-template <typename T, int MATH>
+template <typename T, int MATH, bool WINO = false>
 constexpr size_t mega_lds_bytes() {
     size_t m = 0;
 #define X(l, KIND, C0, C1, COUT, H, W, NB, POOL, NB16) \
-    { constexpr size_t v = conv_lds_bytes<T, KIND, C0, C1, COUT, H, W, (sizeof(T) == 2 ? NB16 : NB), MATH>(); m = v > m ? v : m; }
+    { constexpr size_t v = conv_lds_bytes<T, KIND, C0, C1, COUT, H, W, (sizeof(T) == 2 ? NB16 : NB), MATH>(); m = v > m ? v : m; \
+      if constexpr (WINO && KIND == CONV3) { constexpr size_t u = wino_lds_bytes<C0, C1, H, W>(); m = u > m ? u : m; } }
     GIGA_UNET_LAYERS(X)
 #undef X
     return m;
@@ -579,7 +582,7 @@ __device__ __forceinline__ ConvArgs conv_image_range(ConvArgs a, int img0, int n
     return a;
 }
 
-template <typename T, int MATH>
+template <typename T, int MATH, bool WINO = false>
 __global__ __launch_bounds__(MEGA_NW * 64) void unet_mega_kernel(MegaArgs m) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // A workgroup finds its place by TICKET, not by blockIdx: it reads the XCD it runs on from the hardware (XCC_ID) and draws a
@@ -608,18 +611,38 @@ __global__ __launch_bounds__(MEGA_NW * 64) void unet_mega_kernel(MegaArgs m) {
     const int block = ticket - slot * MEGA_GROUP, nblocks = MEGA_GROUP;     // this workgroup's place inside its group
     unsigned* counter = m.sync + (8 + q) * 32;
     unsigned epoch = 0;
+    // a 3x3 layer whose bit is set in m.wino_mask runs as Winograd F(2x2, 3x3) (WINO instantiation only: exact fp32), in CIN / 64 K-passes
+    auto is_wino = [&](auto kind_tag, int l) { return WINO && decltype(kind_tag)::value == CONV3 && (m.wino_mask >> l & 1u); };
 #define X(l, KIND, C0, C1, COUT, H, W, NB, POOL, NB16)                                                                     \
     if (l < m.nlayers) {                                                                                                   \
         const ConvArgs a = conv_image_range<T, KIND, C0, C1, COUT, H, W>(m.layer[l], img0, per);                           \
+        bool direct = true;                                                                                                \
+        if constexpr (WINO && KIND == CONV3) {                                                                             \
+            if (is_wino(std::integral_constant<int, KIND>{}, l)) {                                                         \
+                direct = false;                                                                                            \
+                _Pragma("unroll") for (int k = 0; k < wino_kpass(C0 + C1); ++k) {                                          \
+                    if (l == 0 || k > 0) wino_fill<C0, C1, COUT>(a, smem, block, nblocks, k);                              \
+                    wino_run<C0, C1, COUT, H, W, POOL, true>(a, smem, block, nblocks, k);                                  \
+                    __builtin_amdgcn_s_waitcnt(0x0F70);                                                                    \
+                    __syncthreads();                                                                                       \
+                }                                                                                                          \
+            }                                                                                                              \
+        }                                                                                                                  \
+        if (direct) {                                                                                                      \
         if (l == 0) conv16_fill<T, KIND, C0, C1, COUT, (sizeof(T) == 2 ? NB16 : NB), MATH>(a, smem, block, nblocks);                \
         conv16_run<T, KIND, C0, C1, COUT, H, W, (sizeof(T) == 2 ? NB16 : NB), POOL, KIND == CONV3, MATH>(a, smem, block, nblocks); \
         __builtin_amdgcn_s_waitcnt(0x0F70);            /* vmcnt(0): this wave's output stores are in the L2 */              \
         __syncthreads();                               /* ... everyone's, and everyone has left the weights in LDS */       \
+        }                                                                                                                  \
     }
     // after layer l: request layer l+1's weights (they land while the barrier is waited for), then the XCD barrier
 #define NEXT(l, KIND, C0, C1, COUT, H, W, NB, POOL, NB16)                                                                  \
     if (l < m.nlayers) {                                                                                                   \
-        conv16_fill<T, KIND, C0, C1, COUT, (sizeof(T) == 2 ? NB16 : NB), MATH>(m.layer[l], smem, block, nblocks);                   \
+        bool direct = true;                                                                                                \
+        if constexpr (WINO && KIND == CONV3) {                                                                             \
+            if (is_wino(std::integral_constant<int, KIND>{}, l)) { direct = false; wino_fill<C0, C1, COUT>(m.layer[l], smem, block, nblocks, 0); } \
+        }                                                                                                                  \
+        if (direct) conv16_fill<T, KIND, C0, C1, COUT, (sizeof(T) == 2 ? NB16 : NB), MATH>(m.layer[l], smem, block, nblocks);       \
         xcd_barrier(counter, ++epoch * (unsigned)nblocks, l, img0 == 0 ? block : -1);                                                                 \
     }
     X(0, CONV3, 32, 0, 32, 40, 40, 2, false, 2)
@@ -952,7 +975,8 @@ static std::atomic<int> g_last_unet_path{0};
 
 template <typename T, int MATH = MATH_NATIVE>
 static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc, float* planes_nchw, int B,
-                       uint8_t* ws, hipStream_t s, const Probe& pr, bool fold_final, int persist, int conv32, bool keep_mask = false) {
+                       uint8_t* ws, hipStream_t s, const Probe& pr, bool fold_final, int persist, int conv32, bool keep_mask = false,
+                       unsigned wino_req = 0) {
     constexpr bool SPLIT = MATH == MATH_SPLIT;
     int stage_no = 0;
     auto pre = [&]() { if (pr.stage == stage_no) (void)hipEventRecord(pr.ev0, s); };
@@ -1013,7 +1037,15 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     const int nimg = 3 * B;
     // (tuning knob: GIGA_CONV_XCD=0 keeps the plain workgroup -> weight-group map, see conv_wg_map)
     const int xcd_local = [] { const char* e = getenv("GIGA_CONV_XCD"); return e ? atoi(e) : 1; }();
+    // exact fp32 only: the stride-1 3x3 layers whose bit is set run as Winograd F(2x2, 3x3) (giga_wino.h) on their own weight image
+    constexpr bool CAN_WINO = sizeof(T) == 4 && MATH == MATH_NATIVE;
+    unsigned wino_mask = 0;
+    if constexpr (CAN_WINO) {
+        for (int l = 0; l < NCONV; ++l)
+            if (kConv[l].kind == CONV3 && (wino_req >> l & 1u)) wino_mask |= 1u << l;
+    }
     auto W_ = [&](int l) {
+        if (wino_mask >> l & 1u) return blob + ko.conv[l].wino;
         return blob + (SPLIT ? ko.conv[l].w16s : MATH == MATH_BF16 ? ko.conv[l].wbf : precision == 1 ? ko.conv[l].w16 : ko.conv[l].w32);
     };
     auto Bi = [&](int l) { return reinterpret_cast<const float*>(blob + ko.conv[l].bias); };
@@ -1111,28 +1143,45 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
             return rc;
         }
     }
-    g_last_unet_path.store(mega ? GIGA_PATH_PERSISTENT : 0, std::memory_order_relaxed);
+    g_last_unet_path.store((mega ? GIGA_PATH_PERSISTENT : 0) | (wino_mask ? GIGA_PATH_WINOGRAD : 0), std::memory_order_relaxed);
     if (mega) {
         MegaArgs m{};
         for (int l = 0; l < NCONV; ++l) { m.layer[l] = L[l]; m.layer[l].xcd_local = 0; }   // (the kernel hands every group its images itself)
         m.sync = reinterpret_cast<unsigned*>(b + w.SYNC);
         m.nlayers = nlayers;
+        m.wino_mask = wino_mask;
         const int slots = (nimg + 7) / 8 < MEGA_SLOTS ? (nimg + 7) / 8 : MEGA_SLOTS;
         const unsigned grid = 8u * (unsigned)slots * MEGA_GROUP;
-        auto kern = unet_mega_kernel<T, MATH>;
+        stage_no = 15;                                        // probe stage 15 = the whole U-Net
+        auto go = [&](auto kern, const size_t lds) {
+            giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
+            pre();
+            GIGA_LAUNCH(kern, dim3(grid), dim3(MEGA_NW * 64), lds, s, m);
+            persistent_launched(mega_slot, s);
+            post();
+        };
         constexpr size_t lds = mega_lds_bytes<T, MATH>();
         static_assert(lds <= 160 * 1024, "LDS budget of the persistent U-Net kernel");
-        giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
-        stage_no = 15;                                        // probe stage 15 = the whole U-Net
-        pre();
-        GIGA_LAUNCH(kern, dim3(grid), dim3(MEGA_NW * 64), lds, s, m);
-        persistent_launched(mega_slot, s);
-        post();
+        if constexpr (CAN_WINO) {
+            constexpr size_t ldsw = mega_lds_bytes<T, MATH, true>();
+            static_assert(ldsw <= 160 * 1024, "LDS budget of the persistent U-Net kernel (Winograd stages)");
+            if (wino_mask) go(unet_mega_kernel<T, MATH, true>, ldsw); else go(unet_mega_kernel<T, MATH, false>, lds);
+        } else {
+            go(unet_mega_kernel<T, MATH, false>, lds);
+        }
         return hipGetLastError() == hipSuccess ? 0 : -10;
     }
     if (pr.stage == 15) (void)hipEventRecord(pr.ev0, s);
 #define X(l, KIND, C0, C1, COUT, H, W, NB, POOL, NB16)                                                                    \
-    if (l < nlayers) { pre(); rc |= launch_conv<T, KIND, C0, C1, COUT, H, W, (sizeof(T) == 2 ? NB16 : NB), POOL, KIND == CONV3, MATH>(L[l], s); post(); } \
+    if (l < nlayers) {                                                                                                    \
+        pre();                                                                                                            \
+        bool direct = true;                                                                                               \
+        if constexpr (CAN_WINO && KIND == CONV3) {                                                                        \
+            if (wino_mask >> l & 1u) { direct = false; rc |= launch_wino<C0, C1, COUT, H, W, POOL>(L[l], s); }            \
+        }                                                                                                                 \
+        if (direct) rc |= launch_conv<T, KIND, C0, C1, COUT, H, W, (sizeof(T) == 2 ? NB16 : NB), POOL, KIND == CONV3, MATH>(L[l], s); \
+        post();                                                                                                           \
+    }                                                                                                                     \
     else { pre(); post(); }
     GIGA_UNET_LAYERS(X)
 #undef X
@@ -1146,13 +1195,18 @@ int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, fl
     Probe pr{ev0 && ev1 ? probe_stage : -1, static_cast<hipEvent_t>(ev0), static_cast<hipEvent_t>(ev1)};
     const bool fold = (precision & GIGA_FOLD_FINAL) != 0;
     const int persist = (precision & GIGA_LAYERWISE_UNET) ? -1 : (precision & GIGA_PERSIST_UNET) ? 1 : 0;   // -1 per-layer launches, 0 auto, 1 persistent
-    const int prec = precision & ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET | GIGA_CONVIN_MASK);
+    const int prec = precision & ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET | GIGA_CONVIN_MASK | GIGA_DIRECT_CONV);
     const int c32 = (precision & GIGA_CONV32_UNET) ? 1 : (precision & GIGA_CONV16_UNET) ? -1 : 0;      // 1 conv32, -1 conv16, 0 default
     const bool km = (precision & GIGA_CONVIN_MASK) != 0;      // training forward (precisions 0 and 3): keep conv_in's ReLU mask for the backward
+    // Winograd F(2x2, 3x3) for the 3x3 layers of precision 0 (giga_wino.h): on unless the call says GIGA_DIRECT_CONV or is a training
+    // forward (GIGA_CONVIN_MASK: the blob rebuilt on the device every step holds no Winograd image); GIGA_WINOGRAD=<mask> in the
+    // environment selects the layers of a whole process (0 = none; A/B runs)
+    static const unsigned env_wino = [] { const char* e = getenv("GIGA_WINOGRAD"); return e ? (unsigned)strtoul(e, nullptr, 0) : WINO_DEFAULT_MASK; }();
+    const unsigned wino = (precision & (GIGA_DIRECT_CONV | GIGA_CONVIN_MASK)) ? 0u : env_wino;
     if (prec == 2) return encoder_run<float, MATH_SPLIT>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32);
     if (prec == 3) return encoder_run<float, MATH_BF16>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32, km);
     return prec == 1 ? encoder_run<half_t>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32)
-                     : encoder_run<float>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32, km);
+                     : encoder_run<float>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32, km, wino);
 }
 
 }  // namespace giga

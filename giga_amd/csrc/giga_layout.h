@@ -150,7 +150,8 @@ constexpr int ci16_pair_read(int p, int side) {
 constexpr int ci16_tap(int g, int e) { return ci16_pair_tap(8 * (g >> 1) + e, g & 1); }
 constexpr int ci16_read(int g, int e) { return ci16_pair_read(8 * (g >> 1) + e, g & 1); }
 
-struct ConvPackOff { size_t w16, w32, bias, w16s, wbf; int nfrag16, nfrag32; size_t c32h, c32s, c32b; int nfragc32; };
+struct ConvPackOff { size_t w16, w32, bias, w16s, wbf; int nfrag16, nfrag32; size_t c32h, c32s, c32b; int nfragc32;
+                     size_t wino; };   // Winograd-domain fp32 image of a 3x3 layer (giga_wino.h), 16 * cin * cout floats; 0 bytes otherwise
 struct PackOff {
     size_t convin_w;        // fp32 [2][7][64]  B operands (channel half, K-step of 4 taps; tap 27 = 0)
     size_t convin_b;        // fp32 [32]
@@ -205,6 +206,10 @@ inline PackOff pack_offsets() {
         o.conv[l].c32b = at; at += (size_t)o.conv[l].nfragc32 * FRAG;
     }
     for (int h = 0; h < NHEADS; ++h) { o.dect[h] = at; at += align_up(DEC16_BYTES, 256); }     // round 5 (ABI 2)
+    for (int l = 0; l < NCONV; ++l) {                                                            // round 6 (ABI 3): giga_wino.h
+        o.conv[l].wino = at;
+        if (kConv[l].kind == CONV3) at += (size_t)16 * (kConv[l].cin0 + kConv[l].cin1) * kConv[l].cout * sizeof(float);
+    }
     o.stamp = at; at += 256;
     o.total = at;
     return o;
@@ -252,7 +257,7 @@ inline BwdPackOff bwd_pack_offsets() {
 // slot orders change); a blob of another version run through this library reads weights from the wrong places, silently.
 // giga_packed_check() validates a HOST copy before it is uploaded; the kernels cannot afford to.
 struct PackStamp { char magic[8]; int abi_version; int backward; unsigned long long total; };
-constexpr int PACK_ABI_VERSION = 2;               // == GIGA_ABI_VERSION (include/giga_hip.h; giga_capi.hip static_asserts it)
+constexpr int PACK_ABI_VERSION = 3;               // == GIGA_ABI_VERSION (include/giga_hip.h; giga_capi.hip static_asserts it)
 
 // feature index held in D-register r of lane-half hi after a 32x32 MFMA with weights as the A
 // operand (rows = output features):  row = (r&3) + 8*(r>>2) + 4*hi   (C/D map, dtype independent)

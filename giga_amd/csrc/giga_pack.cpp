@@ -260,6 +260,35 @@ static void pack_conv(const float* P, const ParamOff& po, const PackOff& ko, int
             }
 }
 
+// Winograd F(2x2, 3x3) image of a 3x3 layer (giga_wino.h): U = G g G^T per (co, ci), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]],
+// accumulated in double and rounded to fp32 once.  Order [grp = co / 16][kpass][pos = 4 xi + nu][chunk of 16 ci][half][lane][2]:
+// lane (j = lane & 15 -> co = 16 grp + j, g = lane >> 4), element e -> ci = 64 kpass + 16 chunk + 4 g + 2 half + e -- the A operand of
+// v_mfma_f32_16x16x4_f32 for the two k-steps of a half-chunk, 8 bytes per lane (a conflict-free ds_read_b64).
+static void pack_wino(const float* P, const ParamOff& po, const PackOff& ko, int l, uint8_t* blob) {
+    const ConvLayerDesc& d = kConv[l];
+    if (d.kind != CONV3) return;
+    const float* W = P + po.conv_w[l];
+    const int cin = d.cin0 + d.cin1, kp = cin > 64 ? cin / 64 : 1, cinp = cin / kp, nchunk = cinp / 16;
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    float* out = reinterpret_cast<float*>(blob + ko.conv[l].wino);
+    size_t at = 0;
+    for (int grp = 0; grp < d.cout / 16; ++grp)
+        for (int k = 0; k < kp; ++k)
+            for (int pos = 0; pos < 16; ++pos)
+                for (int cc = 0; cc < nchunk; ++cc)
+                    for (int h = 0; h < 2; ++h)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 2; ++e, ++at) {
+                                const int co = 16 * grp + (lane & 15), ci = cinp * k + 16 * cc + 4 * (lane >> 4) + 2 * h + e;
+                                const int xi = pos >> 2, nu = pos & 3;
+                                double u = 0.0;
+                                for (int ky = 0; ky < 3; ++ky)
+                                    for (int kx = 0; kx < 3; ++kx)
+                                        u += G[xi][ky] * G[nu][kx] * (double)conv_w_at(W, d, co, ci, ky * 3 + kx);
+                                out[at] = (float)u;
+                            }
+}
+
 static void write_stamp(uint8_t* at, int backward, size_t total) {
     PackStamp st{};
     std::memcpy(st.magic, "GIGAPACK", 8);
@@ -311,7 +340,7 @@ int pack_weights_host(const float* P, size_t n_params, int head_present, uint8_t
     }
     float* cb = reinterpret_cast<float*>(blob + ko.convin_b);
     for (int n = 0; n < 32; ++n) cb[n] = P[po.conv_in_b + n];
-    for (int l = 0; l < NCONV; ++l) pack_conv(P, po, ko, l, blob);
+    for (int l = 0; l < NCONV; ++l) { pack_conv(P, po, ko, l, blob); pack_wino(P, po, ko, l, blob); }
     for (int h = 0; h < NHEADS; ++h) {
         if (!(head_present >> h & 1)) continue;
         pack_head16(P, po.head[h], HEAD_OUT[h], blob + ko.dec16[h]);

@@ -1,0 +1,369 @@
+// wino: the stride-1 3x3 U-Net layers of the exact-fp32 path as Winograd F(2x2, 3x3) on the fp32 MFMA.
+//
+//   reference: encoder/unet.py:14-23 (conv3x3, padding 1), :48-72 (DownConv: conv1, conv2, pool), :101-114 (UpConv conv1/conv2)
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A      d = 4x4 input patch of a 2x2 output tile, g = 3x3 kernel
+//   16 multiplies per (tile, cin, cout) instead of 36: the direct form (giga_conv16.h) sits at 0.41-0.73 of the fp32-MFMA peak and
+//   cannot go above 1; this form needs 0.44 of its MFMA instructions.  fp32-input MFMA does not co-execute with the VALU (DESIGN
+//   "fp32 MFMA and the VALU"), so both transforms are paid in MFMA time -- they are laid out so that they cost ~15 %:
+//     * GEMM per Winograd position p = 4*xi + nu:  M[p][co][tile] = sum_ci U[p][ci][co] * V[p][ci][tile]  on v_mfma_f32_16x16x4_f32,
+//       weights = A operand (rows = 16 output channels), transformed patches = B operand (columns = 16 tiles), K = 4 input channels.
+//       Lane (j = lane & 15, g = lane >> 4) supplies B[k = g][col = j]: the lane OWNS tile j and channels 4g .. 4g+3 of every 16-channel
+//       chunk, reads that tile's 4x4 patch from LDS itself and transforms it in registers -- the B operand never moves across lanes.
+//     * D row = 4g + r: a lane's four registers of position p are four consecutive output channels of ITS tile, so A^T M A is
+//       lane-local too, the 2x2 max-pool is a max over the lane's four results, and every store is one 16-byte vector.
+//     * both transforms are written on 2- / 4-float vectors (v_pk_add_f32): 32 packed adds per 32 MFMAs on the way in, ~50 per unit
+//       (256 MFMAs per 32 input channels) on the way out.
+//   Unit = (block of BW x BH tiles <= 16, 16 output channels).  Wave-independent like conv16: a workgroup keeps the Winograd-domain
+//   weights of its 16-channel group resident in LDS (16 positions x CIN x 16 x 4 B, one LDS-DMA fill), every wave walks its own
+//   units: haloed (2BH+2) x (2BW+2) patch of 16 input channels -> wave-private LDS (pixel stride 80 B, row stride chosen so that the
+//   lanes' ds_read hit 16 distinct 16-byte slots: /tmp search in DESIGN 3f), next chunk prefetched in registers, no workgroup barrier.
+//   Inputs wider than 64 channels run as CIN/64 K-PASSES: pass k keeps the weights of channels 64k .. 64k+63 resident, and a wave adds
+//   its units' pre-activation partials of the previous pass (which it wrote itself) before bias / ReLU.
+//   fp32 Winograd is not the bitwise fma chain of the direct form: results differ from it at the 1e-6 level (tests hold 1e-4 to the
+//   oracle); GIGA_WINOGRAD=0 / the GIGA_DIRECT_CONV flag keep the direct kernels, and the training forward always does (its device
+//   repack is a pure gather of parameters, the Winograd image is not).
+#pragma once
+#include "giga_conv16.h"
+
+namespace giga {
+
+// layers that run as Winograd by default (bit l = U-Net layer l of giga_layout.h::kConv); settled by measurement, DESIGN 3f
+constexpr unsigned WINO_DEFAULT_MASK = (1u << 0) | (1u << 1) | (1u << 10) | (1u << 11);
+constexpr int WINO_NW = 8;                        // waves per workgroup: two per SIMD, 256 registers each (64 accumulators + 32 transformed
+                                                  // values + a prefetched chunk do not fit the 168 of three per SIMD)
+constexpr int WINO_PS = 80;                       // LDS pixel stride: 16 channels x 4 B + 16 B pad
+template <int H, int W> struct WinoBlock {        // tiles per unit: 4 x 4 where the 20 x 20 tile grid of a 40^2 image divides, else 5 x 3
+    static constexpr int TW = W / 2, TH = H / 2;
+    static constexpr int BW = TW % 4 == 0 ? 4 : 5, BH = TW % 4 == 0 ? 4 : 3;
+    static constexpr int TXB = (TW + BW - 1) / BW, TYB = (TH + BH - 1) / BH;       // blocks per image
+    static constexpr int PW = 2 * BW + 2, PH = 2 * BH + 2;                         // staged patch (pixels)
+    static constexpr int RS = BW == 4 ? 832 : 1040;                                // LDS row stride (bytes): 52 / 65 sixteen-byte slots
+    static constexpr int REGION = PH * RS;                                         // 8320 B either way
+    static_assert(BW * BH <= 16 && PW * WINO_PS <= RS, "tile block");
+};
+constexpr int wino_kpass(int cin) { return cin > 64 ? cin / 64 : 1; }
+template <int C0, int C1, int H, int W>
+constexpr int wino_nw() {                         // waves per workgroup: WINO_NW unless weights + patches would not fit the 160 KiB LDS
+    constexpr int CINP = (C0 + C1) / wino_kpass(C0 + C1);
+    constexpr int fit = (160 * 1024 - 16 - 16 * CINP * 16 * 4) / WinoBlock<H, W>::REGION;
+    return fit >= WINO_NW ? WINO_NW : (fit / 2) * 2;
+}
+template <int C0, int C1, int H, int W>
+constexpr size_t wino_lds_bytes() {
+    constexpr int CINP = (C0 + C1) / wino_kpass(C0 + C1);
+    return (size_t)16 * CINP * 16 * 4 + (size_t)wino_nw<C0, C1, H, W>() * WinoBlock<H, W>::REGION + 16;      // + the unit counter
+}
+// Winograd weight image of a layer (giga_pack.cpp::pack_wino): [grp = cout / 16][kpass][pos 16][chunk of 16 ci][half 2][lane 64][2 floats]
+//   value = U[pos][ci = 64 * kpass + 16 * chunk + 4 * (lane >> 4) + 2 * half + e][co = 16 * grp + (lane & 15)],  U = G g G^T
+constexpr size_t wino_image_bytes(int cin, int cout) { return (size_t)16 * cin * cout * 4; }
+
+// 16-byte store at uniform base + 32-bit byte offset.  Plain C++ on purpose: the inline-asm saddr form of giga_dev.h is only safe for
+// <= 64-bit data -- a wider VMEM store reads its data registers over several cycles, the hazard recogniser does not see into the asm,
+// and the compiler reuses the registers at once (measured: the un-pooled layers stored garbage in two of four channels).
+__device__ __forceinline__ void store_f32x4(float* uniform_base, unsigned byte_off, f32x4v v) {
+    *reinterpret_cast<f32x4v*>(reinterpret_cast<char*>(uniform_base) + byte_off) = v;
+}
+
+template <int C0, int C1, int COUT>
+__device__ __forceinline__ void wino_fill(const ConvArgs& a, uint8_t* smem, int block, int nblocks, int kpass) {
+    constexpr int CIN = C0 + C1, KP = wino_kpass(CIN), CINP = CIN / KP, NGRP = COUT / 16;
+    constexpr int WFRAGS = 16 * (CINP / 16);                     // 1 KiB pieces of one (group, pass)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwl = blockDim.x >> 6;
+    const int grp = conv_wg_map<NGRP>(a, block, nblocks).grp;
+    const uint8_t* wsrc = a.w + ((size_t)grp * KP + kpass) * WFRAGS * FRAG;
+    for (int c = wave; c < WFRAGS; c += nwl)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(wsrc + (size_t)c * FRAG + lane * 16),
+            (__attribute__((address_space(3))) void*)(smem + c * FRAG), 16, 0, 0);
+}
+
+// one K-pass of the layer for this workgroup's units.  KPASS_FIRST / KPASS_LAST: the first pass starts from zero, later ones add the
+// partial the previous pass left in `out`; only the last applies bias, ReLU and the pool.
+template <int C0, int C1, int COUT, int H, int W, bool POOL, bool RELU>
+__device__ __forceinline__ void wino_run(const ConvArgs& a, uint8_t* smem, int block, int nblocks, int kpass) {
+    using G = WinoBlock<H, W>;
+    constexpr int CIN = C0 + C1, KP = wino_kpass(CIN), CINP = CIN / KP, NCHUNK = CINP / 16, NGRP = COUT / 16;
+    constexpr int NWV = wino_nw<C0, C1, H, W>();
+    constexpr int BW = G::BW, BH = G::BH, PW = G::PW, PH = G::PH, RS = G::RS, PS = WINO_PS, REGION = G::REGION;
+    constexpr int NVEC = PW * PH * 4, NLD = (NVEC + 63) / 64;   // 16-byte vectors of a staged chunk, staging loads per lane
+    constexpr int WBYTES = 16 * CINP * 16 * 4;
+    static_assert(C1 == 0 || (C0 % 16 == 0 && (KP == 1 || C0 % CINP == 0)), "concat boundary on a chunk / pass boundary");
+    static_assert(!POOL || KP == 1, "pooled layers are single-pass");
+    static_assert(KP <= 2, "a third pass would read partials back through an L1 line it has read before");
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const bool active = wave < NWV;
+    uint8_t* region = smem + WBYTES + (active ? wave : 0) * REGION;
+    const ConvWgMap wm = conv_wg_map<NGRP>(a, block, nblocks);
+    const int grp = wm.grp, wg_in_grp = wm.wg_in_grp, wgs_per_grp = wm.wgs_per_grp;
+    // Units are handed out DYNAMICALLY inside a workgroup: it owns a contiguous, balanced range [ulo, uhi) of its weight group's
+    // units, every wave starts on ulo + wave and draws the next one from an LDS counter.  A static stride leaves the SIMDs of a CU
+    // with 6 / 5.5 / 5 / 5 units of 4.7 on average at 32 scenes (the first waves of every workgroup get the remainder).
+    const int units_all = wm.nimg * G::TYB * G::TXB;
+    const int ulo = (int)((long long)units_all * wg_in_grp / wgs_per_grp), uhi = (int)((long long)units_all * (wg_in_grp + 1) / wgs_per_grp);
+    const int units = uhi;
+    int* counter = reinterpret_cast<int*>(smem + WBYTES + NWV * REGION);
+    if (threadIdx.x == 0) *counter = ulo + NWV;
+    const bool klast = kpass == KP - 1;
+
+    // this lane's tile inside the block (lanes beyond the block's tiles shadow tile 0 and store nothing)
+    const int jt = j < BW * BH ? j : 0;
+    const int tyl = jt / BW, txl = jt % BW;
+    const int a_off = 2 * tyl * RS + 2 * txl * PS + 16 * g;
+
+    // Staging geometry of this lane's NLD vectors: vector i = lane + 64 q is 16-byte vector (i & 3) = (lane & 3) of patch pixel i >> 2.
+    // fp32 MFMA and VALU do not overlap, so the staging is kept free of VALU work: the sources are read with BUFFER loads -- a vector
+    // outside the image (or beyond the patch) carries an offset beyond the buffer's size and comes back as zeros, so every load and
+    // every ds_write is unconditional and nobody zero-fills; a chunk's loads are `per-unit offset register + chunk offset in an SGPR`.
+    const int v16 = (lane & 3) * 16;
+    const uint32_t rowb = (uint32_t)(a.cs0 ? a.cs0 : C0) * 4;          // bytes per pixel of the source tensors (launch_wino: both alike)
+    constexpr uint32_t OOB = 0xFFFFFFF0u;
+    int st_lds[NLD];
+    uint32_t st_rel[NLD];                              // byte offset of the vector from the patch origin's pixel, in the source tensor
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int i = lane + 64 * q, pix = i >> 2, ly = pix / PW, lx = pix % PW;
+        st_lds[q] = i < NVEC ? ly * RS + lx * PS + v16 : 64;           // (beyond the patch: the pad bytes of pixel 0)
+        st_rel[q] = i < NVEC ? (uint32_t)(ly * W + lx) * rowb + (uint32_t)v16 : OOB;
+    }
+    const uint32_t in_bytes = (uint32_t)a.nimg * H * W * rowb;         // (conv_image_range has moved the bases to this group's first image)
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.in0)) + (size_t)a.co0 * 4, 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = C1 > 0 ? __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.in1)) + (size_t)a.co1 * 4, 0, in_bytes, 0x00020000) : rs0;
+    auto unit_coords = [&](int u, int& bx, int& by, int& img) {       // (u is wave-uniform: scalar arithmetic)
+        bx = u % G::TXB; by = (u / G::TXB) % G::TYB; img = wm.img0 + u / (G::TXB * G::TYB);
+    };
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v stg[NLD];
+    uint32_t st_off[NLD];                              // this unit's byte offsets (OOB outside the image)
+    auto unit_setup = [&](int u) {
+        int bx, by, img;
+        unit_coords(u, bx, by, img);
+        const int y0 = 2 * BH * by - 1, x0 = 2 * BW * bx - 1;
+        const uint32_t base = (uint32_t)((img * H + y0) * W + x0) * rowb;          // wraps for y0 = -1: only added to in-image vectors (mod 2^32)
+        if (y0 >= 0 && x0 >= 0 && y0 + PH <= H && x0 + PW <= W) {       // interior block (uniform): no bounds tests
+#pragma unroll
+            for (int q = 0; q < NLD; ++q) st_off[q] = (64 * (q + 1) > NVEC && st_rel[q] == OOB) ? OOB : st_rel[q] + base;
+        } else {
+#pragma unroll
+            for (int q = 0; q < NLD; ++q) {
+                const int pix = (lane >> 2) + 16 * q;
+                const int ly = (pix * (65536 / PW + 1)) >> 16, lx = pix - ly * PW;          // pix / PW for pix < 2^8
+                const bool ok = st_rel[q] != OOB && (unsigned)(y0 + ly) < (unsigned)H && (unsigned)(x0 + lx) < (unsigned)W;
+                st_off[q] = ok ? st_rel[q] + base : OOB;
+            }
+        }
+    };
+    auto issue_loads = [&](int cc) {                   // cc = chunk inside this pass (compile-time after unrolling)
+        const int c16 = kpass * CINP + cc * 16;        // first channel of the chunk in the concatenated input
+        const bool first = C1 == 0 || c16 < C0;
+        const int soff = (first ? c16 : c16 - C0) * 4;
+#pragma unroll
+        for (int q = 0; q < NLD; ++q)
+            stg[q] = first ? __builtin_amdgcn_raw_buffer_load_b128(rs0, st_off[q], soff, 0)
+                           : __builtin_amdgcn_raw_buffer_load_b128(rs1, st_off[q], soff, 0);
+    };
+
+    int u = ulo + wave;
+    const bool work = active && u < units;
+    if (work) { unit_setup(u); issue_loads(0); }
+    const f32x4v bias4 = (a.bias && klast) ? *reinterpret_cast<const f32x4v*>(a.bias + grp * 16 + 4 * g) : f32x4v{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): weights (LDS-DMA), first patch chunk and bias landed
+    __syncthreads();
+    if (!work) return;
+
+    f32x4v acc[16];
+    const uint8_t* wl = smem + lane * 8;               // this lane's 8 bytes of a (position, chunk, half) piece
+    float* outp = reinterpret_cast<float*>(a.out);
+
+    auto epilogue = [&](const int u) {
+        int bx, by, img;
+        unit_coords(u, bx, by, img);
+        const int ty = BH * by + tyl, tx = BW * bx + txl;
+        const bool ok = j < BW * BH && ty < G::TH && tx < G::TW;
+        // A^T M A on four-channel vectors
+        f32x4v t0[4], t1[4];
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            t0[xi] = (acc[4 * xi] + acc[4 * xi + 1]) + acc[4 * xi + 2];
+            t1[xi] = (acc[4 * xi + 1] - acc[4 * xi + 2]) - acc[4 * xi + 3];
+        }
+        f32x4v y[4];
+        y[0] = (t0[0] + t0[1]) + t0[2]; y[1] = (t1[0] + t1[1]) + t1[2];
+        y[2] = (t0[1] - t0[2]) - t0[3]; y[3] = (t1[1] - t1[2]) - t1[3];
+        const uint32_t pix = (uint32_t)((img * H + 2 * ty) * W + 2 * tx);
+        const uint32_t o00 = (pix * COUT + grp * 16 + 4 * g) * 4u;
+        if (ok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t off = o00 + (uint32_t)(((e >> 1) * W + (e & 1)) * COUT * 4);
+                if constexpr (KP > 1) {
+                    if (kpass > 0) y[e] += *reinterpret_cast<const f32x4v*>(reinterpret_cast<const char*>(outp) + off);
+                }
+                if (klast) {
+                    y[e] += bias4;
+                    if (RELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[e][r] = relu(y[e][r]);
+                    }
+                }
+                store_f32x4(outp, off, y[e]);
+            }
+            if constexpr (POOL) {
+                f32x4v mx;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx[r] = fmaxf(fmaxf(y[0][r], y[1][r]), fmaxf(y[2][r], y[3][r]));
+                const uint32_t pp = (uint32_t)((img * (H / 2) + ty) * (W / 2) + tx);
+                store_f32x4(reinterpret_cast<float*>(a.out_pool), (pp * COUT + grp * 16 + 4 * g) * 4u, mx);
+            }
+        }
+    };
+
+    // ---- the wave's instruction stream -------------------------------------------------------------------------------------------
+    // A half-chunk (this lane's channels 4g + 2h, 4g + 2h + 1 of a 16-channel chunk) is: 16 ds_read_b64 of the raw patch -> 32 packed
+    // adds (B^T d B) -> a burst of 32 MFMAs.  Only the adds have to sit between two bursts; everything else rides INSIDE a burst, after
+    // its fourth MFMA pair: the raw reads of the NEXT half, and at a chunk boundary the ds_writes that stage the next chunk and the
+    // buffer loads of the chunk after that (loads run two chunks ahead of the arithmetic).
+    f32x2v d[4][4];
+    auto load_d = [&](const int h) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+                d[r][x] = *reinterpret_cast<const f32x2v*>(region + a_off + r * RS + x * PS + 8 * h);
+    };
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) *reinterpret_cast<u32x4v*>(region + st_lds[q]) = stg[q];
+    };
+    f32x2v v[16];
+    auto transform = [&]() {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const f32x2v e0 = d[0][x] - d[2][x], e1 = d[1][x] + d[2][x], e2 = d[2][x] - d[1][x], e3 = d[1][x] - d[3][x];
+            d[0][x] = e0; d[1][x] = e1; d[2][x] = e2; d[3][x] = e3;
+        }
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            v[4 * xi + 0] = d[xi][0] - d[xi][2];
+            v[4 * xi + 1] = d[xi][1] + d[xi][2];
+            v[4 * xi + 2] = d[xi][2] - d[xi][1];
+            v[4 * xi + 3] = d[xi][1] - d[xi][3];
+        }
+    };
+    // 32 MFMAs: positions in pairs (two independent accumulators alternate: 40-cycle dependent latency, 32-cycle issue); the weights
+    // of pair pp + PD are read from LDS right after the MFMAs of pair pp are issued; `mid` runs after pair 3
+    auto burst = [&](auto first_tag, const int cc, const int h, auto&& mid) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const uint8_t* wbase = wl + (cc * 2 + h) * 512;              // [pos][chunk][half][lane][2]: pos stride = NCHUNK KiB
+        constexpr int PD = 4;
+        f32x2v wq[PD][2];
+#pragma unroll
+        for (int pp = 0; pp < PD; ++pp) {
+            wq[pp][0] = *reinterpret_cast<const f32x2v*>(wbase + (2 * pp) * NCHUNK * 1024);
+            wq[pp][1] = *reinterpret_cast<const f32x2v*>(wbase + (2 * pp + 1) * NCHUNK * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            const int sl = pp % PD, p0 = 2 * pp, p1 = 2 * pp + 1;
+            if constexpr (FIRST) {
+                acc[p0] = mfma32_16(wq[sl][0][0], v[p0][0], f32x4v{0.f, 0.f, 0.f, 0.f});
+                acc[p1] = mfma32_16(wq[sl][1][0], v[p1][0], f32x4v{0.f, 0.f, 0.f, 0.f});
+            } else {
+                acc[p0] = mfma32_16(wq[sl][0][0], v[p0][0], acc[p0]);
+                acc[p1] = mfma32_16(wq[sl][1][0], v[p1][0], acc[p1]);
+            }
+            acc[p0] = mfma32_16(wq[sl][0][1], v[p0][1], acc[p0]);
+            acc[p1] = mfma32_16(wq[sl][1][1], v[p1][1], acc[p1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (pp + PD < 8) {
+                wq[sl][0] = *reinterpret_cast<const f32x2v*>(wbase + (2 * (pp + PD)) * NCHUNK * 1024);
+                wq[sl][1] = *reinterpret_cast<const f32x2v*>(wbase + (2 * (pp + PD) + 1) * NCHUNK * 1024);
+            }
+            if (pp == 3) mid();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    static_assert(NCHUNK >= 2, "loads run two chunks ahead");
+    // prologue: chunk 0 of the first unit is in the staging registers (requested before the weight barrier)
+    stage_write();
+    issue_loads(1);
+    load_d(0);
+    // unit loop (runtime, uniform); the chunk loop inside is unrolled: what rides in which burst is known at compile time
+    while (true) {
+        int drawn = 0;
+        if (lane == 0) drawn = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int un = __builtin_amdgcn_readfirstlane(drawn);        // (needed at the middle of chunk NCHUNK - 2's second burst)
+        const bool more = un < units;
+#pragma unroll
+        for (int cc = 0; cc < NCHUNK; ++cc) {
+            transform();                                              // (cc, 0): raw values were read inside the previous burst
+            auto mid0 = [&]() { load_d(1); };
+            if (cc == 0) burst(std::true_type{}, cc, 0, mid0); else burst(std::false_type{}, cc, 0, mid0);
+            transform();                                              // (cc, 1)
+            // second burst of the chunk: stage the chunk after it, request the chunk after that, read the first half of the next chunk
+            auto mid1 = [&]() {
+                if (cc + 1 < NCHUNK) {                                // next chunk of this unit
+                    stage_write();
+                    if (cc + 2 < NCHUNK) issue_loads(cc + 2);
+                    else if (more) { unit_setup(un); issue_loads(0); }
+                    load_d(0);
+                } else if (more) {                                    // chunk 0 of the next unit (st_off already describes that unit)
+                    stage_write();
+                    issue_loads(1);
+                    load_d(0);
+                }
+            };
+            burst(std::false_type{}, cc, 1, mid1);
+        }
+        epilogue(u);
+        if (!more) break;
+        u = un;
+    }
+}
+
+template <int C0, int C1, int COUT, int H, int W, bool POOL, bool RELU>
+__global__ __launch_bounds__((wino_nw<C0, C1, H, W>() * 64)) void wino_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int KP = wino_kpass(C0 + C1);
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        if (k > 0) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);       // this wave's partial stores are acknowledged before it reads them back
+            __syncthreads();                           // everyone has left the previous pass's weights
+        }
+        wino_fill<C0, C1, COUT>(a, smem, (int)blockIdx.x, (int)gridDim.x, k);
+        wino_run<C0, C1, COUT, H, W, POOL, RELU>(a, smem, (int)blockIdx.x, (int)gridDim.x, k);
+    }
+}
+
+template <int C0, int C1, int COUT, int H, int W, bool POOL, bool RELU = true>
+inline int launch_wino(const ConvArgs& a, hipStream_t s) {
+    using G = WinoBlock<H, W>;
+    constexpr int NWV = wino_nw<C0, C1, H, W>(), NGRP = COUT / 16;
+    constexpr size_t lds = wino_lds_bytes<C0, C1, H, W>();
+    static_assert(lds <= 160 * 1024 && NWV >= 4, "LDS budget");
+    static_assert(256 % NGRP == 0, "weight groups must divide the CU count");
+    const size_t in_pix = (size_t)a.nimg * H * W;
+    if (C1 > 0 && (a.cs0 ? a.cs0 : C0) != (a.cs1 ? a.cs1 : C1)) return -7;              // one pixel stride for both sources (wino_run)
+    if (in_pix >= (1u << 24) || in_pix * (size_t)((a.cs0 ? a.cs0 : C0) * 4) >= (1ull << 32) ||
+        (C1 > 0 && in_pix * (size_t)((a.cs1 ? a.cs1 : C1) * 4) >= (1ull << 32)) || in_pix * COUT * 4 >= (1ull << 32)) return -7;
+    const int units = a.nimg * G::TXB * G::TYB;
+    int wgs = (units + NWV - 1) / NWV;
+    if (wgs > 256 / NGRP) wgs = 256 / NGRP;
+    else if (a.xcd_local && a.nimg % 8 == 0 && wgs % 8 != 0 && wgs + 8 - wgs % 8 <= 256 / NGRP) wgs += 8 - wgs % 8;
+    auto kern = wino_kernel<C0, C1, COUT, H, W, POOL, RELU>;
+    if (lds > 48 * 1024) giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
+    GIGA_LAUNCH(kern, dim3(wgs * NGRP), dim3(NWV * 64), lds, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
+
+}  // namespace giga

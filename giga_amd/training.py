@@ -166,7 +166,7 @@ class GigaFunction(torch.autograd.Function):
             sb = state.acquire(B, N, M)
             s = _capi.stream_ptr(dev)
             _capi.check(L.giga_encoder_forward(_capi.ptr(x), _capi.ptr(state.blob), _capi.ptr(sb.nhwc), None, B,
-                                               (_capi.ENC_BF16 if state.bf16 else 0) | _capi.CONVIN_MASK,
+                                               (_capi.ENC_BF16 if state.bf16 else 0) | _capi.CONVIN_MASK | _capi.DIRECT_CONV,
                                                _capi.ptr(sb.ws), sb.ws.numel(), s), "giga_encoder_forward")
             hp = state.head_present
             o = [torch.empty((B, N), device=dev) if hp & 1 and N > 0 else None,

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GIGA_ABI_VERSION 2   /* 2: the packed blobs grew (bf16 decoder images; conv_in f16 slot order of round 4): repack */
+#define GIGA_ABI_VERSION 3   /* 3: the forward blob grew (Winograd-domain images of the fp32 3x3 layers, round 6); 2: bf16 decoder images: repack */
 
 #define GIGA_HEAD_QUAL 1   /* decoder_qual  (out_dim 1, sigmoid epilogue)     */
 #define GIGA_HEAD_ROT 2    /* decoder_rot   (out_dim 4, L2-normalise epilogue) */
@@ -168,6 +168,14 @@ int giga_decoder_forward(const void* planes_nhwc, const float* p, const void* pa
  * its pre-activations (10 MB at 32 scenes, in the encoder workspace), and giga_backward called with GIGA_CONVIN_MASK_BWD on that workspace
  * takes the ReLU mask of conv_in from them instead of recomputing the convolution (8 instead of 15 MFMAs per unit). */
 #define GIGA_CONVIN_MASK 512
+/* The stride-1 3x3 layers of the U-Net in precision 0 (exact fp32; encoder/unet.py:14-23) run as Winograd F(2x2, 3x3) on the fp32
+ * MFMA by default (csrc/giga_wino.h: 16 instead of 36 multiplies per 2x2 outputs; transforms in registers, Winograd-domain weights
+ * from the packed blob).  fp32 Winograd is not the direct form's bitwise fma chain: planes differ from it by a few 1e-6 relative
+ * (the suite holds both to 1e-4 of the oracle).  GIGA_DIRECT_CONV, OR-ed into `precision` (0) of giga_encoder_forward*, keeps the
+ * direct convolutions for this call; the environment variable GIGA_WINOGRAD=0 does so for a whole process (a layer bit mask
+ * otherwise).  A training forward (GIGA_CONVIN_MASK) always runs the direct kernels: giga_repack_device gathers parameters, and the
+ * Winograd image is not a gather. */
+#define GIGA_DIRECT_CONV 1024
 
 /* Inference fast path for the FIXED QUERY LATTICE of VGNImplicit (detection_implicit.py:28-31,107):
  * the R^3 points meshgrid(lin, lin, lin, 'ij') with z fastest, shared by all B scenes.  Each plane is
@@ -329,10 +337,12 @@ const char* giga_launch_probe_name(void);
 void giga_forget_device_state(void);
 /* How the LAST encoder call of this process ran its U-Net (diagnostic: tests pin the launch-form and kernel flags to it):
  * an OR of GIGA_PATH_PERSISTENT (one persistent launch; else one launch per layer), GIGA_PATH_CONV32 (conv32 kernels; else
- * conv16) and GIGA_PATH_FUSED_PAIRS (the persistent conv32 launch ran its same-resolution layer pairs fused). */
+ * conv16), GIGA_PATH_FUSED_PAIRS (the persistent conv32 launch ran its same-resolution layer pairs fused) and GIGA_PATH_WINOGRAD
+ * (precision 0: 3x3 layers ran as Winograd F(2x2, 3x3)). */
 #define GIGA_PATH_PERSISTENT 1
 #define GIGA_PATH_CONV32 2
 #define GIGA_PATH_FUSED_PAIRS 4
+#define GIGA_PATH_WINOGRAD 8
 int giga_encoder_last_path(void);
 /* ---- measurement hooks (bench.py roofline): HIP events recorded on `stream` right before and
  * after ONE kernel launch, so the kernel's duration is measured live on the stream it runs on.

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"libgiga_hip.so does not export {name}"
     assert declared == set(_capi.EXPORTS), declared ^ set(_capi.EXPORTS)
-    assert lib.giga_abi_version() == 2
+    assert lib.giga_abi_version() == 3
     assert lib.giga_strerror(0) == b"ok" and lib.giga_strerror(-4) == b"workspace too small"
 
 

@@ -31,7 +31,7 @@ def maxerr(a, b):
 
 def test_native_library_is_loaded():
     from giga_amd import _capi
-    assert _capi.lib().giga_abi_version() == 2
+    assert _capi.lib().giga_abi_version() == 3
     maps = open("/proc/self/maps").read()
     assert "libgiga_hip.so" in maps
 
