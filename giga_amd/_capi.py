@@ -27,7 +27,7 @@ LAYERWISE_UNET = 64      # GIGA_LAYERWISE_UNET: one launch per U-Net layer even 
 CONV32_UNET = 128        # GIGA_CONV32_UNET: the f16-class U-Net on the conv32 kernels (the library's default)
 CONV16_UNET = 256        # GIGA_CONV16_UNET: ... on the conv16 kernels
 DIRECT_CONV = 1024       # GIGA_DIRECT_CONV: precision 0 keeps the direct 3x3 convolutions (default: Winograd F(2x2, 3x3), csrc/giga_wino.h)
-PATH_PERSISTENT, PATH_CONV32, PATH_FUSED_PAIRS = 1, 2, 4          # giga_encoder_last_path()
+PATH_PERSISTENT, PATH_CONV32, PATH_FUSED_PAIRS, PATH_WINOGRAD = 1, 2, 4, 8          # giga_encoder_last_path()
 MAX_SCENES = 3072        # GIGA_MAX_SCENES: scenes per encoder / training call (error -7 beyond)
 HEAD_BITS = {"decoder_qual": 1, "decoder_rot": 2, "decoder_width": 4, "decoder_tsdf": 8}
 PLANES_FP32 = 1024       # GIGA_PLANES_FP32: fp32 planes into the plain-f16 lattice decoder

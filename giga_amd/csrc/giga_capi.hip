@@ -129,9 +129,36 @@ __device__ __forceinline__ void derive_c32b_block(uint8_t* fwd, const C32bRegion
     }
 }
 
+// Winograd F(2x2, 3x3) images (giga_wino.h; giga_pack.cpp::pack_wino) from the fp32 conv16 fragments of the same layer: one workgroup per
+// 512-byte piece [grp][kpass][pos][chunk][half] = 64 lanes x 2 floats, U = G g G^T accumulated in double in the packer's order, so the
+// device image equals the host's bit for bit.
+struct WinoRegions { size_t src[NCONV], dst[NCONV]; int first[NCONV + 1]; int cin[NCONV]; };
+__device__ __forceinline__ void derive_wino_block(uint8_t* fwd, const WinoRegions& r, int blk) {
+    int l = 0;
+    while (l + 1 < NCONV && blk >= r.first[l + 1]) ++l;
+    const int f = blk - r.first[l], lane = threadIdx.x;
+    const int cin = r.cin[l], kp = cin > 64 ? cin / 64 : 1, cinp = cin / kp, nchunk = cinp / 16, KG = cin / 16;
+    const int h = f & 1, cc = (f >> 1) % nchunk, pos = (f / (2 * nchunk)) & 15, k = (f / (32 * nchunk)) % kp, grp = f / (32 * nchunk * kp);
+    const int j = lane & 15, g = lane >> 4, xi = pos >> 2, nu = pos & 3;
+    const float* f32 = reinterpret_cast<const float*>(fwd + r.src[l]);           // [nb][tap][kg][lane (j, g')][e']: W[16 nb + j][16 kg + 4 g' + e'][tap]
+    float* out = reinterpret_cast<float*>(fwd + r.dst[l]) + ((size_t)f * 64 + lane) * 2;
+    const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int ci = cinp * k + 16 * cc + 4 * g + 2 * h + e;
+        double u = 0.0;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                const float w = f32[((((size_t)grp * 9 + ky * 3 + kx) * KG + ci / 16) * 64 + ((ci % 16) / 4) * 16 + j) * 4 + ci % 4];
+                u += G[xi][ky] * G[nu][kx] * (double)w;
+            }
+        out[e] = (float)u;
+    }
+}
+
 constexpr int DECT_DERIVE_BLOCKS = (59 + 51) * NHEADS;
 struct DeriveArgs {
-    BfRegions r; C32bRegions c; int n16, n32;
+    BfRegions r; C32bRegions c; WinoRegions w; int n16, n32, nwino;
     size_t dec32_0, dec32_stride, dectf_0, dectf_stride, decb_0, decb_stride, dectb_0, dectb_stride;
     size_t convin_w, convin_ws;
 };
@@ -139,6 +166,7 @@ __global__ __launch_bounds__(64) void derive_all_kernel(uint8_t* fwd, uint8_t* b
     const int b = blockIdx.x;
     if (b < d.n16) derive_bf16_block(fwd, bwd, d.r, b);
     else if (b < d.n16 + d.n32) derive_c32b_block(fwd, d.c, b - d.n16);
+    else if (b > d.n16 + d.n32 + DECT_DERIVE_BLOCKS) { if (fwd) derive_wino_block(fwd, d.w, b - (d.n16 + d.n32 + DECT_DERIVE_BLOCKS + 1)); }
     else if (b == d.n16 + d.n32 + DECT_DERIVE_BLOCKS) {
         // f16x3 split conv_in operands (giga_pack.cpp): [2 channel halves][hi | lo][lane (j, g)][8 halfs e] <- W[16 h + j][ci16_tap(g, e)],
         // from the fp32 image [h][K-step s of 4 taps][lane (j, k)] = W[16 h + j][4 s + k]
@@ -196,8 +224,17 @@ int giga_derive_bf16_fragments(void* packed_dev, void* bwd_packed_dev, void* str
     d.dec32_0 = ko.dec32[0]; d.dec32_stride = ko.dec32[1] - ko.dec32[0]; d.dectf_0 = ko.dect[0]; d.dectf_stride = ko.dect[1] - ko.dect[0];
     d.decb_0 = bo.dec[0]; d.decb_stride = bo.dec[1] - bo.dec[0]; d.dectb_0 = bo.dect[0]; d.dectb_stride = bo.dect[1] - bo.dect[0];
     d.convin_w = ko.convin_w; d.convin_ws = ko.convin_ws;
-    // ONE launch: the bf16 conv16 fragments of both blobs, the bf16 conv32 images, the bf16 decoder images (giga_dect.h), the f16x3 conv_in operands
-    GIGA_LAUNCH(derive_all_kernel, dim3(d.n16 + d.n32 + DECT_DERIVE_BLOCKS + 1), dim3(64), 0, static_cast<hipStream_t>(stream),
+    int nw = 0;
+    for (int l = 0; l < NCONV; ++l) {
+        const ConvLayerDesc& cd = kConv[l];
+        d.w.src[l] = ko.conv[l].w32; d.w.dst[l] = ko.conv[l].wino; d.w.first[l] = nw; d.w.cin[l] = cd.cin0 + cd.cin1;
+        if (cd.kind == CONV3) nw += (cd.cin0 + cd.cin1) * cd.cout / 8;           // 512-byte pieces of the layer's image
+    }
+    d.w.first[NCONV] = nw;
+    d.nwino = packed_dev ? nw : 0;
+    // ONE launch: the bf16 conv16 fragments of both blobs, the bf16 conv32 images, the bf16 decoder images (giga_dect.h), the f16x3 conv_in
+    // operands, the Winograd images of the 3x3 layers
+    GIGA_LAUNCH(derive_all_kernel, dim3(d.n16 + d.n32 + DECT_DERIVE_BLOCKS + 1 + d.nwino), dim3(64), 0, static_cast<hipStream_t>(stream),
                 static_cast<uint8_t*>(packed_dev), static_cast<uint8_t*>(bwd_packed_dev), d);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }

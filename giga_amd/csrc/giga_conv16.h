@@ -61,7 +61,7 @@ static __device__ int g_conv_trace_layer = -1;
 template <int KIND, int H, int W>
 constexpr bool conv_lin() { return H == 10 && W == 10 && KIND != DOWN; }
 // waves per workgroup: 12 unless the resident weights + the wave-private patches would not fit the 160 KiB LDS
-template <typename T, int KIND, int C0, int C1, int H, int W, int NB>
+template <typename T, int KIND, int C0, int C1, int H, int W, int NB, int MAXW = CONV_NW>
 constexpr int conv_nw() {       // (SPLIT instantiations have T = float and exactly the fp32 LDS footprint)
     constexpr int ES = (int)sizeof(T), PS = 32 * ES + 16, HALO = KIND == CONV3 ? 1 : 0;
     constexpr int TAPS = KIND == CONV3 ? 9 : KIND == DOWN ? 4 : 1;
@@ -69,7 +69,7 @@ constexpr int conv_nw() {       // (SPLIT instantiations have T = float and exac
     constexpr int REGION = (NPIX * PS + 15) / 16 * 16;
     constexpr int WB = NB * TAPS * ((C0 + C1) / 32 * (ES == 4 ? 2 : 1)) * (int)FRAG;
     constexpr int fit = (160 * 1024 - WB) / REGION;
-    return fit >= CONV_NW ? CONV_NW : (fit / 2) * 2;
+    return fit >= MAXW ? MAXW : (fit / 2) * 2;   // (MAXW: the persistent kernel of the Winograd path launches 8 waves, giga_wino.h)
 }
 
 // H, W are the OUTPUT-grid dimensions for DOWN (its input is 2H x 2W) and the input dimensions otherwise.
@@ -136,7 +136,7 @@ __device__ __forceinline__ void conv16_fill(const ConvArgs& a, uint8_t* smem, in
             (__attribute__((address_space(3))) void*)(smem + c * FRAG), 16, 0, 0);
 }
 
-template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL, bool RELU, int MATH>
+template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, bool POOL, bool RELU, int MATH, int MAXW = CONV_NW>
 __device__ __forceinline__ void conv16_run(const ConvArgs& a, uint8_t* smem, int block, int nblocks) {
     constexpr bool SPLIT = MATH == MATH_SPLIT, BF = MATH == MATH_BF16;
     static_assert(MATH == MATH_NATIVE || sizeof(T) == 4, "split / bf16 modes read and write fp32 activations");
@@ -149,7 +149,7 @@ __device__ __forceinline__ void conv16_run(const ConvArgs& a, uint8_t* smem, int
     // LIN (the 10x10 layers): a 4x4 tiling covers 144 pixel slots for 100 pixels; instead a unit is 16 CONSECUTIVE
     // pixels of an image in row-major order (7 units per image), staged as the haloed band of rows they touch.
     constexpr bool LIN = conv_lin<KIND, H, W>();
-    constexpr int NWV = conv_nw<T, KIND, C0, C1, H, W, NB>();
+    constexpr int NWV = conv_nw<T, KIND, C0, C1, H, W, NB, MAXW>();
     constexpr int LW = LIN ? W + 2 * HALO : KIND == DOWN ? 8 : 4 + 2 * HALO;                 // staged patch width
     constexpr int LH = LIN ? 3 + 2 * HALO : LW;                                                // 16 pixels of a 10-wide image touch <= 3 rows
     constexpr int NPIX = LW * LH;                     // (DOWN: the 8x8 fine pixels)
@@ -521,7 +521,7 @@ __global__ __launch_bounds__((conv_nw<T, KIND, C0, C1, H, W, NB>() * 64)) void c
 }
 
 // LDS bytes of one layer (weights resident + wave-private patches)
-template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, int MATH>
+template <typename T, int KIND, int C0, int C1, int COUT, int H, int W, int NB, int MATH, int MAXW = CONV_NW>
 constexpr size_t conv_lds_bytes() {       // (sized for the fp32 / split footprint; the bf16 mode needs less)
     constexpr bool SPLIT = MATH == MATH_SPLIT;
     constexpr int HALO = KIND == CONV3 ? 1 : 0;
@@ -529,7 +529,7 @@ constexpr size_t conv_lds_bytes() {       // (sized for the fp32 / split footpri
     constexpr int ES = (int)sizeof(T);
     constexpr int PS = 32 * ES + 16;
     constexpr bool LIN = conv_lin<KIND, H, W>();
-    constexpr int NWV = conv_nw<T, KIND, C0, C1, H, W, NB>();
+    constexpr int NWV = conv_nw<T, KIND, C0, C1, H, W, NB, MAXW>();
     constexpr int NPIX = LIN ? (W + 2 * HALO) * (3 + 2 * HALO) : KIND == DOWN ? 64 : (4 + 2 * HALO) * (4 + 2 * HALO);
     constexpr int REGION = (NPIX * PS + 15) / 16 * 16;
     constexpr int KGT = (C0 + C1) / 32 * ((ES == 4 && !SPLIT) ? 2 : 1);

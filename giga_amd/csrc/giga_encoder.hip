@@ -509,7 +509,7 @@ template <typename T, int MATH, bool WINO = false>
 constexpr size_t mega_lds_bytes() {
     size_t m = 0;
 #define X(l, KIND, C0, C1, COUT, H, W, NB, POOL, NB16) \
-    { constexpr size_t v = conv_lds_bytes<T, KIND, C0, C1, COUT, H, W, (sizeof(T) == 2 ? NB16 : NB), MATH>(); m = v > m ? v : m; \
+    { constexpr size_t v = conv_lds_bytes<T, KIND, C0, C1, COUT, H, W, (sizeof(T) == 2 ? NB16 : NB), MATH, (WINO ? WINO_NW : CONV_NW)>(); m = v > m ? v : m; \
       if constexpr (WINO && KIND == CONV3) { constexpr size_t u = wino_lds_bytes<C0, C1, H, W>(); m = u > m ? u : m; } }
     GIGA_UNET_LAYERS(X)
 #undef X
@@ -582,8 +582,11 @@ __device__ __forceinline__ ConvArgs conv_image_range(ConvArgs a, int img0, int n
     return a;
 }
 
+// WINO (exact fp32 only): the instantiation whose 3x3 layers may run as Winograd stages (giga_wino.h).  It launches WINO_NW = 8 waves
+// per workgroup -- those stages hold 64 accumulators + a transformed half-chunk + a prefetched chunk per lane, ~230 registers, which
+// three waves per SIMD (168) cannot -- and its direct stages (ConvTranspose, 1x1, unselected 3x3 layers) walk their units with 8 waves.
 template <typename T, int MATH, bool WINO = false>
-__global__ __launch_bounds__(MEGA_NW * 64) void unet_mega_kernel(MegaArgs m) {
+__global__ __launch_bounds__((WINO ? WINO_NW : MEGA_NW) * 64) void unet_mega_kernel(MegaArgs m) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // A workgroup finds its place by TICKET, not by blockIdx: it reads the XCD it runs on from the hardware (XCC_ID) and draws a
     // number from that XCD's ticket counter; ticket t is member t % 8 of group slot t / 8 on that XCD.
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(MEGA_NW * 64) void unet_mega_kernel(MegaArgs m) {
         }                                                                                                                  \
         if (direct) {                                                                                                      \
         if (l == 0) conv16_fill<T, KIND, C0, C1, COUT, (sizeof(T) == 2 ? NB16 : NB), MATH>(a, smem, block, nblocks);                \
-        conv16_run<T, KIND, C0, C1, COUT, H, W, (sizeof(T) == 2 ? NB16 : NB), POOL, KIND == CONV3, MATH>(a, smem, block, nblocks); \
+        conv16_run<T, KIND, C0, C1, COUT, H, W, (sizeof(T) == 2 ? NB16 : NB), POOL, KIND == CONV3, MATH, (WINO ? WINO_NW : CONV_NW)>(a, smem, block, nblocks); \
         __builtin_amdgcn_s_waitcnt(0x0F70);            /* vmcnt(0): this wave's output stores are in the L2 */              \
         __syncthreads();                               /* ... everyone's, and everyone has left the weights in LDS */       \
         }                                                                                                                  \
@@ -1153,10 +1156,10 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
         const int slots = (nimg + 7) / 8 < MEGA_SLOTS ? (nimg + 7) / 8 : MEGA_SLOTS;
         const unsigned grid = 8u * (unsigned)slots * MEGA_GROUP;
         stage_no = 15;                                        // probe stage 15 = the whole U-Net
-        auto go = [&](auto kern, const size_t lds) {
+        auto go = [&](auto kern, const size_t lds, const int nw) {
             giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
             pre();
-            GIGA_LAUNCH(kern, dim3(grid), dim3(MEGA_NW * 64), lds, s, m);
+            GIGA_LAUNCH(kern, dim3(grid), dim3(nw * 64), lds, s, m);
             persistent_launched(mega_slot, s);
             post();
         };
@@ -1165,9 +1168,9 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
         if constexpr (CAN_WINO) {
             constexpr size_t ldsw = mega_lds_bytes<T, MATH, true>();
             static_assert(ldsw <= 160 * 1024, "LDS budget of the persistent U-Net kernel (Winograd stages)");
-            if (wino_mask) go(unet_mega_kernel<T, MATH, true>, ldsw); else go(unet_mega_kernel<T, MATH, false>, lds);
+            if (wino_mask) go(unet_mega_kernel<T, MATH, true>, ldsw, WINO_NW); else go(unet_mega_kernel<T, MATH, false>, lds, MEGA_NW);
         } else {
-            go(unet_mega_kernel<T, MATH, false>, lds);
+            go(unet_mega_kernel<T, MATH, false>, lds, MEGA_NW);
         }
         return hipGetLastError() == hipSuccess ? 0 : -10;
     }

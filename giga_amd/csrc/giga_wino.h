@@ -29,7 +29,7 @@
 namespace giga {
 
 // layers that run as Winograd by default (bit l = U-Net layer l of giga_layout.h::kConv); settled by measurement, DESIGN 3f
-constexpr unsigned WINO_DEFAULT_MASK = (1u << 0) | (1u << 1) | (1u << 10) | (1u << 11);
+constexpr unsigned WINO_DEFAULT_MASK = 0xDBF;     // all ten 3x3 layers: 0, 1, 2, 3, 4, 5, 7, 8, 10, 11 (profiles/r06/wino_ab.txt)
 constexpr int WINO_NW = 8;                        // waves per workgroup: two per SIMD, 256 registers each (64 accumulators + 32 transformed
                                                   // values + a prefetched chunk do not fit the 168 of three per SIMD)
 constexpr int WINO_PS = 80;                       // LDS pixel stride: 16 channels x 4 B + 16 B pad

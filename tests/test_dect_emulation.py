@@ -27,7 +27,8 @@ def _images(sd):
     blob = _capi.pack_weights(flat, 15).numpy()
     bblob = _capi.pack_bwd_weights(flat, 15).numpy()
     up = lambda x: (x + 255) // 256 * 256  # noqa: E731
-    fwd = [blob[blob.size - 256 - (4 - h) * up(FWD_BYTES):][:FWD_BYTES] for h in range(4)]   # the last regions of both blobs (before the stamp)
+    wino = 16 * 48128 * 4           # round 6: the Winograd images of the ten 3x3 layers (sum of cin * cout = 48 128) sit between them and the stamp
+    fwd = [blob[blob.size - 256 - wino - (4 - h) * up(FWD_BYTES):][:FWD_BYTES] for h in range(4)]   # the last regions of both blobs (before the stamp)
     bwd = [bblob[bblob.size - 256 - (4 - h) * BWD_BYTES:][:BWD_BYTES] for h in range(4)]
     return fwd, bwd
 

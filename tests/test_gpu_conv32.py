@@ -58,7 +58,7 @@ def test_kernel_choice_flags_select_what_runs(net32):
         net32.set_precision("fp32")                       # fp32 has conv16 only, whatever is asked for
         net32.set_unet_kernel("conv32").set_persistent_unet(False)
         _planes(net32, torch.from_numpy(synth.tsdf_batch(3, 32)).to(dev))
-        assert L.giga_encoder_last_path() == _capi.PATH_PERSISTENT
+        assert L.giga_encoder_last_path() == _capi.PATH_PERSISTENT | _capi.PATH_WINOGRAD     # (fp32: 3x3 layers as Winograd, giga_wino.h)
     finally:
         net32.set_unet_kernel("conv32").set_persistent_unet(False).set_precision("fp32")
 

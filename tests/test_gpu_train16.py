@@ -111,9 +111,11 @@ def test_bf16_decoder_images_derived_on_the_device_equal_the_host_packer(sd7):
     flat = torch.cat([p.detach().reshape(-1) for p in net._ordered_params()]).cpu()
     host_fwd, host_bwd = _capi.pack_weights(flat, 15), _capi.pack_bwd_weights(flat, 15)
     nf, nb = 4 * 59 * 1024, 4 * 51 * 1024                    # the last regions of the two blobs (giga_layout.h)
-    assert torch.equal(st.blob.cpu()[-nf - 256:-256], host_fwd[-nf - 256:-256])        # (behind them: the 256-byte stamp of a host blob)
+    wino = 16 * 48128 * 4                                    # behind the forward blob's decoder images: the Winograd images of the ten 3x3
+    fe = -256 - wino                                         # layers (round 6, sum of cin * cout = 48 128), then the 256-byte stamp of a host blob
+    assert torch.equal(st.blob.cpu()[fe - nf:fe], host_fwd[fe - nf:fe])
     assert torch.equal(st.bwd_blob.cpu()[-nb - 256:-256], host_bwd[-nb - 256:-256])
-    assert host_fwd[-nf - 256:-256].any() and host_bwd[-nb - 256:-256].any()
+    assert host_fwd[fe - nf:fe].any() and host_bwd[-nb - 256:-256].any()
 
 
 def test_bf16_decoder_is_deterministic(sd7):

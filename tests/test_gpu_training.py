@@ -250,7 +250,10 @@ def test_bf16_training_step(sd7, monkeypatch):
     tail = sum((co // 16 * (4 if k == 1 else 1)) * (9 if k == 0 else 1) * (ci // 32) * 1024 for k, ci, co in conv)
     # (the conv32 images of round 4 -- f16, f16x3 pairs, bf16: 4 fragments per (32-channel slice, tap, 16-channel chunk) -- follow them)
     c32 = sum(4 * (co // 32 * (4 if k == 1 else 1)) * (9 if k == 0 else 1) * (ci // 16) * 1024 for k, ci, co in conv)
-    n = st.blob.numel() - 4 * 59 * 1024 - 256                # (behind: the bf16 decoder images of round 5 -- test_gpu_train16.py -- and the stamp)
+    wino = sum(16 * ci * co * 4 for k, ci, co in conv if k == 0)    # round 6: the Winograd images of the 3x3 layers (giga_wino.h)
+    n = st.blob.numel() - 4 * 59 * 1024 - wino - 256         # (behind: the bf16 decoder images of round 5 -- test_gpu_train16.py --, the Winograd images and the stamp)
+    w0 = st.blob.numel() - 256 - wino
+    assert torch.equal(st.blob.cpu()[w0:w0 + wino], host_fwd[w0:w0 + wino]), "device-derived Winograd images != host pack (bit for bit)"
     assert torch.equal(st.blob.cpu()[n - c32 - tail:n - c32], host_fwd[n - c32 - tail:n - c32]), \
         "device repack + derive != host pack (forward bf16 fragments)"
     assert torch.equal(st.bwd_blob.cpu()[:-256], host_bwd[:-256]), "device repack + derive != host pack (backward blob)"   # (last 256 B: the host blob's stamp)

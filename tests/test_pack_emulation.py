@@ -47,6 +47,7 @@ def _blob_and_offsets(sd):
     # conv32 images (round 4): f16 + f16x3 [hi, lo] pairs + bf16 = 4 fragments per (32-channel slice, tap, 16-channel chunk)
     at += sum(4 * (co // 32 * (4 if kind == 1 else 1)) * (9 if kind == 0 else 1) * ((c0 + c1) // 16) * 1024 for kind, c0, c1, co in conv)
     at += 4 * up(59 * 1024)                            # bf16 images of the bf16 training decoder (round 5), appended
+    at += sum(16 * (c0 + c1) * co * 4 for kind, c0, c1, co in conv if kind == 0)    # Winograd images of the 3x3 layers (round 6, giga_wino.h)
     at += 256                                          # the stamp (giga_packed_check)
     assert at == blob.size
     _blob_and_offsets.dec16s = dec16s
