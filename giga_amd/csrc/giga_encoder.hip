@@ -631,6 +631,14 @@ __global__ __launch_bounds__((WINO ? WINO_NW : MEGA_NW) * 64) void unet_mega_ker
                 }                                                                                                          \
             }                                                                                                              \
         }                                                                                                                  \
+        if constexpr (WINO && KIND == UPCONV) {                                                                            \
+            if (m.wino_mask >> l & 1u) {                                                                                   \
+                direct = false;                                                                                            \
+                up_run<C0, COUT, H, W>(a, smem, block, nblocks);                                                           \
+                __builtin_amdgcn_s_waitcnt(0x0F70);                                                                        \
+                __syncthreads();                                                                                           \
+            }                                                                                                              \
+        }                                                                                                                  \
         if (direct) {                                                                                                      \
         if (l == 0) conv16_fill<T, KIND, C0, C1, COUT, (sizeof(T) == 2 ? NB16 : NB), MATH>(a, smem, block, nblocks);                \
         conv16_run<T, KIND, C0, C1, COUT, H, W, (sizeof(T) == 2 ? NB16 : NB), POOL, KIND == CONV3, MATH, (WINO ? WINO_NW : CONV_NW)>(a, smem, block, nblocks); \
@@ -644,6 +652,9 @@ __global__ __launch_bounds__((WINO ? WINO_NW : MEGA_NW) * 64) void unet_mega_ker
         bool direct = true;                                                                                                \
         if constexpr (WINO && KIND == CONV3) {                                                                             \
             if (is_wino(std::integral_constant<int, KIND>{}, l)) { direct = false; wino_fill<C0, C1, COUT>(m.layer[l], smem, block, nblocks, 0); } \
+        }                                                                                                                  \
+        if constexpr (WINO && KIND == UPCONV) {                                                                            \
+            if (m.wino_mask >> l & 1u) { direct = false; up_fill<C0, COUT>(m.layer[l], smem, block, nblocks); }            \
         }                                                                                                                  \
         if (direct) conv16_fill<T, KIND, C0, C1, COUT, (sizeof(T) == 2 ? NB16 : NB), MATH>(m.layer[l], smem, block, nblocks);       \
         xcd_barrier(counter, ++epoch * (unsigned)nblocks, l, img0 == 0 ? block : -1);                                                                 \
@@ -1045,10 +1056,10 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
     unsigned wino_mask = 0;
     if constexpr (CAN_WINO) {
         for (int l = 0; l < NCONV; ++l)
-            if (kConv[l].kind == CONV3 && (wino_req >> l & 1u)) wino_mask |= 1u << l;
+            if ((kConv[l].kind == CONV3 || kConv[l].kind == UPCONV) && (wino_req >> l & 1u)) wino_mask |= 1u << l;
     }
     auto W_ = [&](int l) {
-        if (wino_mask >> l & 1u) return blob + ko.conv[l].wino;
+        if ((wino_mask >> l & 1u) && kConv[l].kind == CONV3) return blob + ko.conv[l].wino;    // (up_run reads the ordinary fp32 fragments)
         return blob + (SPLIT ? ko.conv[l].w16s : MATH == MATH_BF16 ? ko.conv[l].wbf : precision == 1 ? ko.conv[l].w16 : ko.conv[l].w32);
     };
     auto Bi = [&](int l) { return reinterpret_cast<const float*>(blob + ko.conv[l].bias); };
@@ -1181,6 +1192,9 @@ static int encoder_run(const float* tsdf, const uint8_t* blob, void* planes_nhwc
         bool direct = true;                                                                                               \
         if constexpr (CAN_WINO && KIND == CONV3) {                                                                        \
             if (wino_mask >> l & 1u) { direct = false; rc |= launch_wino<C0, C1, COUT, H, W, POOL>(L[l], s); }            \
+        }                                                                                                                 \
+        if constexpr (CAN_WINO && KIND == UPCONV) {                                                                       \
+            if (wino_mask >> l & 1u) { direct = false; rc |= launch_up<C0, COUT, H, W>(L[l], s); }                        \
         }                                                                                                                 \
         if (direct) rc |= launch_conv<T, KIND, C0, C1, COUT, H, W, (sizeof(T) == 2 ? NB16 : NB), POOL, KIND == CONV3, MATH>(L[l], s); \
         post();                                                                                                           \

@@ -29,7 +29,8 @@
 namespace giga {
 
 // layers that run as Winograd by default (bit l = U-Net layer l of giga_layout.h::kConv); settled by measurement, DESIGN 3f
-constexpr unsigned WINO_DEFAULT_MASK = 0xDBF;     // all ten 3x3 layers: 0, 1, 2, 3, 4, 5, 7, 8, 10, 11 (profiles/r06/wino_ab.txt)
+constexpr unsigned WINO_DEFAULT_MASK = 0xFFF;     // all ten 3x3 layers (0, 1, 2, 3, 4, 5, 7, 8, 10, 11) as Winograd, the two ConvTranspose layers
+                                                  // (6, 9) as plain GEMMs on the same lane layout (up_run); profiles/r06/wino_ab_*.txt
 constexpr int WINO_NW = 8;                        // waves per workgroup: two per SIMD, 256 registers each (64 accumulators + 32 transformed
                                                   // values + a prefetched chunk do not fit the 168 of three per SIMD)
 constexpr int WINO_PS = 80;                       // LDS pixel stride: 16 channels x 4 B + 16 B pad
@@ -343,6 +344,127 @@ __global__ __launch_bounds__((wino_nw<C0, C1, H, W>() * 64)) void wino_kernel(Co
         wino_fill<C0, C1, COUT>(a, smem, (int)blockIdx.x, (int)gridDim.x, k);
         wino_run<C0, C1, COUT, H, W, POOL, RELU>(a, smem, (int)blockIdx.x, (int)gridDim.x, k);
     }
+}
+
+// ----------------------------------------------------------------------------------------------------------------------------------
+// up: ConvTranspose2d(k = 2, s = 2) of the exact-fp32 path (encoder/unet.py:25-31,101-104: no activation) as four plain GEMMs on the
+// same lane layout -- out[2y + dy][2x + dx][co] = bias[co] + sum_ci in[y][x][ci] W[ci][co][dy][dx].  Unit = (16 consecutive pixels of the
+// workgroup's image range, 16 output channels); lane (j, g) reads channels 4g .. 4g+3 of every 16-channel chunk of ITS pixel straight
+// from memory into the B operand (no LDS staging, no transform), the four sub-pixel products accumulate side by side (four independent
+// accumulators: no dependent-MFMA stalls), a lane's D registers are four consecutive channels of its pixel: four 16-byte stores.  The
+// A operands are the layer's ordinary fp32 conv16 fragments (same lane layout; a pure gather of parameters, so the training path's
+// device repack keeps them valid), the four sub-pixel runs of the workgroup's channel block resident in LDS (CIN x 256 B).
+// The direct form (conv16 UPCONV) stages a patch per 32-channel chunk and is latency-bound: 0.27-0.30 of the fp32 peak, and 16 / 14 us
+// per layer inside the 8-wave persistent launch (profiles/r06/unet_trace_wino_8waves.txt).
+// ----------------------------------------------------------------------------------------------------------------------------------
+template <int CIN, int COUT>
+__device__ __forceinline__ void up_fill(const ConvArgs& a, uint8_t* smem, int block, int nblocks) {
+    constexpr int KG = CIN / 16, NBT = COUT / 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwl = blockDim.x >> 6;
+    const int grp = conv_wg_map<NBT>(a, block, nblocks).grp;
+    for (int c = wave; c < 4 * KG; c += nwl) {                    // piece c = (sub, kg): conv16 fragment (sub * NBT + grp) * KG + kg
+        const int sub = c / KG, kg = c - sub * KG;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(a.w + ((size_t)(sub * NBT + grp) * KG + kg) * FRAG + lane * 16),
+            (__attribute__((address_space(3))) void*)(smem + c * FRAG), 16, 0, 0);
+    }
+}
+template <int CIN, int COUT, int H, int W>
+__device__ __forceinline__ void up_run(const ConvArgs& a, uint8_t* smem, int block, int nblocks) {
+    constexpr int KG = CIN / 16, NBT = COUT / 16, NWV = WINO_NW;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const bool active = wave < NWV;
+    const ConvWgMap wm = conv_wg_map<NBT>(a, block, nblocks);
+    const int grp = wm.grp;
+    const int npix = wm.nimg * H * W, p0 = wm.img0 * H * W;      // this workgroup's pixel range of the input tensor
+    const int units_all = (npix + 15) / 16;
+    const int ulo = (int)((long long)units_all * wm.wg_in_grp / wm.wgs_per_grp), uhi = (int)((long long)units_all * (wm.wg_in_grp + 1) / wm.wgs_per_grp);
+    int* counter = reinterpret_cast<int*>(smem + 4 * KG * FRAG);
+    if (threadIdx.x == 0) *counter = ulo + NWV;
+    const uint32_t rowb = (uint32_t)(a.cs0 ? a.cs0 : CIN) * 4;
+    const char* in = reinterpret_cast<const char*>(a.in0) + (size_t)a.co0 * 4 + 16 * g;
+    f32x4v x[2][KG];                                              // B operands of this and of the next unit
+    auto issue = [&](int u, f32x4v (&dst)[KG]) {
+        int p = 16 * u + j;
+        p = p < npix ? p : npix - 1;
+        const char* q = in + (size_t)(p0 + p) * rowb;
+#pragma unroll
+        for (int k = 0; k < KG; ++k) dst[k] = *reinterpret_cast<const f32x4v*>(q + 64 * k);
+    };
+    int u = ulo + wave;
+    const bool work = active && u < uhi;
+    if (work) issue(u, x[0]);
+    const f32x4v bias4 = a.bias ? *reinterpret_cast<const f32x4v*>(a.bias + grp * 16 + 4 * g) : f32x4v{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    if (!work) return;
+    const f32x4v* wl = reinterpret_cast<const f32x4v*>(smem) + lane;
+    float* outp = reinterpret_cast<float*>(a.out);
+    auto unit = [&](const int u, const f32x4v (&xb)[KG]) {
+        f32x4v acc[4];
+#pragma unroll
+        for (int k = 0; k < KG; ++k) {
+            f32x4v wv[4];
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) wv[sub] = wl[(sub * KG + k) * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub)
+                    acc[sub] = (k == 0 && e == 0) ? mfma32_16(wv[sub][e], xb[k][e], bias4) : mfma32_16(wv[sub][e], xb[k][e], acc[sub]);
+        }
+        const int p = 16 * u + j;
+        if (p < npix) {
+            const int pg = p0 + p, img = pg / (H * W), r = pg - img * (H * W), y = r / W, xx = r - y * W;
+            const uint32_t o00 = ((uint32_t)((img * 2 * H + 2 * y) * 2 * W + 2 * xx) * COUT + grp * 16 + 4 * g) * 4u;
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+                store_f32x4(outp, o00 + (uint32_t)(((sub >> 1) * 2 * W + (sub & 1)) * COUT * 4), acc[sub]);
+        }
+    };
+    while (true) {
+        int drawn = 0;
+        if (lane == 0) drawn = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int un = __builtin_amdgcn_readfirstlane(drawn);
+        const bool more = un < uhi;
+        if (more) issue(un, x[1]);
+        unit(u, x[0]);
+        if (!more) break;
+        const int un2 = [&] { int d2 = 0; if (lane == 0) d2 = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                              return __builtin_amdgcn_readfirstlane(d2); }();
+        const bool more2 = un2 < uhi;
+        if (more2) issue(un2, x[0]);
+        unit(un, x[1]);
+        if (!more2) break;
+        u = un2;
+    }
+}
+template <int CIN, int COUT>
+constexpr size_t up_lds_bytes() { return (size_t)4 * (CIN / 16) * FRAG + 16; }
+template <int CIN, int COUT, int H, int W>
+__global__ __launch_bounds__(WINO_NW * 64) void up_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    up_fill<CIN, COUT>(a, smem, (int)blockIdx.x, (int)gridDim.x);
+    up_run<CIN, COUT, H, W>(a, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+template <int CIN, int COUT, int H, int W>
+inline int launch_up(const ConvArgs& a, hipStream_t s) {
+    constexpr int NBT = COUT / 16;
+    constexpr size_t lds = up_lds_bytes<CIN, COUT>();
+    const size_t in_pix = (size_t)a.nimg * H * W;
+    if (in_pix * 4 >= (1u << 24) || in_pix * 4 * COUT * 4 >= (1ull << 32)) return -7;
+    const int units = (int)((in_pix + 15) / 16);
+    int wgs = (units + WINO_NW - 1) / WINO_NW;
+    if (wgs > 256 / NBT) wgs = 256 / NBT;
+    else if (a.xcd_local && a.nimg % 8 == 0 && wgs % 8 != 0 && wgs + 8 - wgs % 8 <= 256 / NBT) wgs += 8 - wgs % 8;
+    auto kern = up_kernel<CIN, COUT, H, W>;
+    if (lds > 48 * 1024) giga::dyn_lds_once(reinterpret_cast<const void*>(kern), (int)lds);
+    GIGA_LAUNCH(kern, dim3(wgs * NBT), dim3(WINO_NW * 64), lds, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
 template <int C0, int C1, int COUT, int H, int W, bool POOL, bool RELU = true>

@@ -86,7 +86,7 @@ def test_planes_match_direct_convolutions(sd7):
 
 
 def test_every_3x3_layer_as_winograd(sd7):
-    """GIGA_WINOGRAD=0xDBF: all ten 3x3 layers (incl. the two-pass 128-channel ones and the 5 x 3 tile blocks of the 20^2 / 10^2 layers)"""
+    """GIGA_WINOGRAD=0xFFF: all ten 3x3 layers and the two ConvTranspose GEMM stages (incl. the two-pass 128-channel ones and the 5 x 3 tile blocks of the 20^2 / 10^2 layers)"""
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "from test_gpu_wino import layer_errors, TOL\nfrom giga_amd import weights\n"
             "sd = weights.make_state_dict(7)\n"
@@ -97,5 +97,5 @@ def test_every_3x3_layer_as_winograd(sd7):
             "        assert path & 8\n"
             "        assert all(v < TOL for v in errs.values()), errs\n"
             "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GIGA_WINOGRAD="0xDBF"), capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GIGA_WINOGRAD="0xFFF"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-3000:] + r.stderr[-3000:]
