@@ -158,7 +158,7 @@ __device__ __forceinline__ void derive_wino_block(uint8_t* fwd, const WinoRegion
 
 constexpr int DECT_DERIVE_BLOCKS = (59 + 51) * NHEADS;
 struct DeriveArgs {
-    BfRegions r; C32bRegions c; WinoRegions w; int n16, n32, nwino;
+    BfRegions r; C32bRegions c; int n16, n32;
     size_t dec32_0, dec32_stride, dectf_0, dectf_stride, decb_0, decb_stride, dectb_0, dectb_stride;
     size_t convin_w, convin_ws;
 };
@@ -166,7 +166,6 @@ __global__ __launch_bounds__(64) void derive_all_kernel(uint8_t* fwd, uint8_t* b
     const int b = blockIdx.x;
     if (b < d.n16) derive_bf16_block(fwd, bwd, d.r, b);
     else if (b < d.n16 + d.n32) derive_c32b_block(fwd, d.c, b - d.n16);
-    else if (b > d.n16 + d.n32 + DECT_DERIVE_BLOCKS) { if (fwd) derive_wino_block(fwd, d.w, b - (d.n16 + d.n32 + DECT_DERIVE_BLOCKS + 1)); }
     else if (b == d.n16 + d.n32 + DECT_DERIVE_BLOCKS) {
         // f16x3 split conv_in operands (giga_pack.cpp): [2 channel halves][hi | lo][lane (j, g)][8 halfs e] <- W[16 h + j][ci16_tap(g, e)],
         // from the fp32 image [h][K-step s of 4 taps][lane (j, k)] = W[16 h + j][4 s + k]
@@ -198,7 +197,25 @@ __global__ void repack2_kernel(const float* __restrict__ params, const int32_t* 
     else if (m == -1) words[i] = 0.f;
 }
 
+__global__ __launch_bounds__(64) void derive_wino_kernel(uint8_t* fwd, WinoRegions w) { derive_wino_block(fwd, w, (int)blockIdx.x); }
+
 extern "C" {
+
+/* Winograd images of the fp32 3x3 layers (giga_wino.h) from the fp32 fragments of the same DEVICE blob, after giga_repack_device */
+int giga_derive_winograd(void* packed_dev, void* stream) {
+    if (!packed_dev) return -1;
+    const PackOff ko = pack_offsets();
+    WinoRegions w{};
+    int nw = 0;
+    for (int l = 0; l < NCONV; ++l) {
+        const ConvLayerDesc& cd = kConv[l];
+        w.src[l] = ko.conv[l].w32; w.dst[l] = ko.conv[l].wino; w.first[l] = nw; w.cin[l] = cd.cin0 + cd.cin1;
+        if (cd.kind == CONV3) nw += (cd.cin0 + cd.cin1) * cd.cout / 8;           // 512-byte pieces of the layer's image
+    }
+    w.first[NCONV] = nw;
+    GIGA_LAUNCH(derive_wino_kernel, dim3(nw), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<uint8_t*>(packed_dev), w);
+    return hipGetLastError() == hipSuccess ? 0 : -10;
+}
 
 int giga_derive_bf16_fragments(void* packed_dev, void* bwd_packed_dev, void* stream) {
     if (!packed_dev && !bwd_packed_dev) return -1;
@@ -224,17 +241,8 @@ int giga_derive_bf16_fragments(void* packed_dev, void* bwd_packed_dev, void* str
     d.dec32_0 = ko.dec32[0]; d.dec32_stride = ko.dec32[1] - ko.dec32[0]; d.dectf_0 = ko.dect[0]; d.dectf_stride = ko.dect[1] - ko.dect[0];
     d.decb_0 = bo.dec[0]; d.decb_stride = bo.dec[1] - bo.dec[0]; d.dectb_0 = bo.dect[0]; d.dectb_stride = bo.dect[1] - bo.dect[0];
     d.convin_w = ko.convin_w; d.convin_ws = ko.convin_ws;
-    int nw = 0;
-    for (int l = 0; l < NCONV; ++l) {
-        const ConvLayerDesc& cd = kConv[l];
-        d.w.src[l] = ko.conv[l].w32; d.w.dst[l] = ko.conv[l].wino; d.w.first[l] = nw; d.w.cin[l] = cd.cin0 + cd.cin1;
-        if (cd.kind == CONV3) nw += (cd.cin0 + cd.cin1) * cd.cout / 8;           // 512-byte pieces of the layer's image
-    }
-    d.w.first[NCONV] = nw;
-    d.nwino = packed_dev ? nw : 0;
-    // ONE launch: the bf16 conv16 fragments of both blobs, the bf16 conv32 images, the bf16 decoder images (giga_dect.h), the f16x3 conv_in
-    // operands, the Winograd images of the 3x3 layers
-    GIGA_LAUNCH(derive_all_kernel, dim3(d.n16 + d.n32 + DECT_DERIVE_BLOCKS + 1 + d.nwino), dim3(64), 0, static_cast<hipStream_t>(stream),
+    // ONE launch: the bf16 conv16 fragments of both blobs, the bf16 conv32 images, the bf16 decoder images (giga_dect.h), the f16x3 conv_in operands
+    GIGA_LAUNCH(derive_all_kernel, dim3(d.n16 + d.n32 + DECT_DERIVE_BLOCKS + 1), dim3(64), 0, static_cast<hipStream_t>(stream),
                 static_cast<uint8_t*>(packed_dev), static_cast<uint8_t*>(bwd_packed_dev), d);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }

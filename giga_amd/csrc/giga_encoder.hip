@@ -1215,11 +1215,11 @@ int launch_encoder(const float* tsdf, const uint8_t* blob, void* planes_nhwc, fl
     const int prec = precision & ~(GIGA_FOLD_FINAL | GIGA_PERSIST_UNET | GIGA_LAYERWISE_UNET | GIGA_CONV32_UNET | GIGA_CONV16_UNET | GIGA_CONVIN_MASK | GIGA_DIRECT_CONV);
     const int c32 = (precision & GIGA_CONV32_UNET) ? 1 : (precision & GIGA_CONV16_UNET) ? -1 : 0;      // 1 conv32, -1 conv16, 0 default
     const bool km = (precision & GIGA_CONVIN_MASK) != 0;      // training forward (precisions 0 and 3): keep conv_in's ReLU mask for the backward
-    // Winograd F(2x2, 3x3) for the 3x3 layers of precision 0 (giga_wino.h): on unless the call says GIGA_DIRECT_CONV or is a training
-    // forward (GIGA_CONVIN_MASK: the blob rebuilt on the device every step holds no Winograd image); GIGA_WINOGRAD=<mask> in the
-    // environment selects the layers of a whole process (0 = none; A/B runs)
+    // Winograd F(2x2, 3x3) for the 3x3 layers of precision 0 (giga_wino.h): on unless the call says GIGA_DIRECT_CONV (a blob rebuilt on
+    // the device needs giga_derive_winograd first); GIGA_WINOGRAD=<mask> in the environment selects the layers of a whole process
+    // (0 = none; A/B runs)
     static const unsigned env_wino = [] { const char* e = getenv("GIGA_WINOGRAD"); return e ? (unsigned)strtoul(e, nullptr, 0) : WINO_DEFAULT_MASK; }();
-    const unsigned wino = (precision & (GIGA_DIRECT_CONV | GIGA_CONVIN_MASK)) ? 0u : env_wino;
+    const unsigned wino = (precision & GIGA_DIRECT_CONV) ? 0u : env_wino;
     if (prec == 2) return encoder_run<float, MATH_SPLIT>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32);
     if (prec == 3) return encoder_run<float, MATH_BF16>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32, km);
     return prec == 1 ? encoder_run<half_t>(tsdf, blob, planes_nhwc, planes_nchw, B, ws, s, pr, fold, persist, c32)

@@ -98,6 +98,8 @@ class _TrainState:
         if self.bf16:                   # bf16 images of the convolution fragments, from the fp32 fragments just rebuilt
             _capi.check(L.giga_derive_bf16_fragments(_capi.ptr(self.blob), _capi.ptr(self.bwd_blob), s),
                         "giga_derive_bf16_fragments")
+        if (_capi.ENC_BF16 if self.bf16 else 0) == 0:     # an fp32 forward runs its 3x3 layers as Winograd F(2x2, 3x3): their images, from the same fragments
+            _capi.check(L.giga_derive_winograd(_capi.ptr(self.blob), s), "giga_derive_winograd")
         if key != self._wkey:
             self.repacks += 1
         self._wkey = key
@@ -166,7 +168,7 @@ class GigaFunction(torch.autograd.Function):
             sb = state.acquire(B, N, M)
             s = _capi.stream_ptr(dev)
             _capi.check(L.giga_encoder_forward(_capi.ptr(x), _capi.ptr(state.blob), _capi.ptr(sb.nhwc), None, B,
-                                               (_capi.ENC_BF16 if state.bf16 else 0) | _capi.CONVIN_MASK | _capi.DIRECT_CONV,
+                                               (_capi.ENC_BF16 if state.bf16 else 0) | _capi.CONVIN_MASK,
                                                _capi.ptr(sb.ws), sb.ws.numel(), s), "giga_encoder_forward")
             hp = state.head_present
             o = [torch.empty((B, N), device=dev) if hp & 1 and N > 0 else None,

@@ -173,8 +173,8 @@ int giga_decoder_forward(const void* planes_nhwc, const float* p, const void* pa
  * from the packed blob).  fp32 Winograd is not the direct form's bitwise fma chain: planes differ from it by a few 1e-6 relative
  * (the suite holds both to 1e-4 of the oracle).  GIGA_DIRECT_CONV, OR-ed into `precision` (0) of giga_encoder_forward*, keeps the
  * direct convolutions for this call; the environment variable GIGA_WINOGRAD=0 does so for a whole process (a layer bit mask
- * otherwise).  A training forward (GIGA_CONVIN_MASK) always runs the direct kernels: giga_repack_device gathers parameters, and the
- * Winograd image is not a gather. */
+ * otherwise).  A blob rebuilt by giga_repack_device (the training path) needs giga_derive_winograd before such a forward:
+ * giga_repack_device gathers parameters, and the Winograd image is not a gather. */
 #define GIGA_DIRECT_CONV 1024
 
 /* Inference fast path for the FIXED QUERY LATTICE of VGNImplicit (detection_implicit.py:28-31,107):
@@ -230,6 +230,10 @@ int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, cons
 /* bf16 images of the convolution fragments, derived ON THE DEVICE from the fp32 fragments of the same blob(s) after
  * giga_repack_device (either pointer may be NULL).  giga_pack_weights / giga_pack_bwd_weights fill them on the host too. */
 int giga_derive_bf16_fragments(void* packed_dev, void* bwd_packed_dev, void* stream);
+/* The Winograd-domain images of the fp32 3x3 layers (csrc/giga_wino.h), derived ON THE DEVICE from the fp32 fragments of the same blob
+ * after giga_repack_device: U = G g G^T accumulated in double in the host packer's order -- bit-identical to giga_pack_weights'.
+ * A precision-0 forward on a device-repacked blob needs it unless the call carries GIGA_DIRECT_CONV. */
+int giga_derive_winograd(void* packed_dev, void* stream);
 size_t giga_bwd_packed_bytes(void);
 int giga_pack_bwd_weights(const float* params_host, size_t n_params, int head_present, void* packed_host,
                           size_t packed_bytes);
