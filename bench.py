@@ -73,7 +73,7 @@ NAMED_STAGE = 0                         # convin_project: the kernel VERDICT r01
 
 # kernel-name fragments (rocprofv3 names) of the stages whose HBM traffic bench.py quotes from the committed PMC tables
 TRAFFIC_KERNEL = {"convin_project": "convin_project_kernel<float, 5, false",
-                  "unet (one persistent launch: 12 layers)": "unet_mega_kernel<float, 0>",
+                  "unet (one persistent launch: 12 layers)": "unet_mega_kernel<float, 0",
                   "unet.up0.conv1": "conv16_kernel<float, 0, 64, 64, 64, 20, 20, 1, false, true, 0>",
                   "unet.up1.conv1": "conv16_kernel<float, 0, 32, 32, 32, 40, 40, 2, false, true, 0>"}
 
@@ -84,7 +84,7 @@ def traffic_lookup(workload, fragment):
     (bytes or None, provenance or None)."""
     if not fragment:
         return None, None
-    for rnd in ("r05", "r04", "r03", "r02"):                      # the newest committed table that knows the kernel
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):               # the newest committed table that knows the kernel
         try:
             tab = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_traffic_{workload}.json")))
         except (OSError, ValueError):
@@ -99,7 +99,7 @@ def traffic_lookup(workload, fragment):
 def traffic_c5(precision):
     """HBM bytes of ONE c5 training step (every kernel of it) from profiles/r0N_traffic_c5.json, and the five kernels that move the
     most.  Returns (bytes or None, provenance or None)."""
-    for rnd in ("r05",):
+    for rnd in ("r06", "r05"):
         try:
             tab = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_traffic_c5.json")))["bf16" if precision.startswith("bf16") else "fp32"]
         except (OSError, ValueError, KeyError):
@@ -121,6 +121,23 @@ def stage_flops(stage, B):
         return sum(stage_flops(st, B) for st in range(2, 14))
     taps, cin, cout, hw = _CONV[stage - 2]
     return 2 * hw * hw * taps * cin * cout * 3 * B
+
+
+def unet_issued_flops(B):
+    """fp32 MFMA FLOPs the U-Net launch ISSUES for B scenes in its default form (csrc/giga_wino.h): the ten 3x3 layers as Winograd
+    F(2x2, 3x3) -- 16 positions x cin / 4 K-steps of v_mfma_f32_16x16x4_f32 (2048 FLOP) per (block of <= 16 tiles, 16 output channels),
+    blocks of 4 x 4 tiles on the 40^2 images (all full), of 5 x 3 on the 20^2 / 10^2 ones (8 / 2 blocks per image for 100 / 25 tiles) --
+    and the two ConvTranspose layers as four plain GEMMs per 16 pixels.  `roofline.achieved` counts the ALGORITHMIC (direct-convolution)
+    FLOPs of SURVEY 8d; this is what keeps the matrix pipe busy."""
+    nimg, fl = 3 * B, 0
+    for taps, cin, cout, hw in _CONV[:12]:
+        if taps == 9:
+            tw = hw // 2
+            blocks = (tw // 4) ** 2 if tw % 4 == 0 else -(-tw // 5) * -(-tw // 3)
+            fl += nimg * blocks * (cout // 16) * 16 * (cin // 4) * 2048
+        elif taps == 4:
+            fl += -(-nimg * hw * hw // 16) * (cout // 16) * 4 * (cin // 4) * 2048
+    return fl
 
 
 def pick_headline(stage_ms):
@@ -446,7 +463,8 @@ def summary_of(out):
     ex = out.get("extra", {})
     g = lambda d, *ks: (lambda v: round(v, 4) if isinstance(v, float) else v)(_dig(d, ks))  # noqa: E731
     s = {"c2_fp32_ms": round(out["ms_per_step"], 4), "c2_scenes_per_s": round(out["value"], 1),
-         "c2_unet_launch_frac_fp32_peak": g(out, "roofline", "frac"), "c2_launches": out.get("launches_per_step"),
+         "c2_unet_launch_frac_fp32_peak": g(out, "roofline", "frac"), "c2_unet_issued_mfma_frac": g(out, "roofline", "issued_mfma_frac_of_peak"),
+         "c2_launches": out.get("launches_per_step"),
          "c2_fp16x3_ms": g(ex, "c2_fp16x3", "ms_per_step"), "c2_ii_fp32_ms": g(ex, "c2_ii", "fp32", "ms_per_step"),
          "c2_ii_fp16x3_ms": g(ex, "c2_ii", "fp16x3", "ms_per_step")}
     for k, v in ex.items():
@@ -546,10 +564,14 @@ def core_result(args, world, B, M, K, T, scenes_per_s, stage_ms, dec_grasp_ms, d
             "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
             "frac_of_measured_peak": achieved / MEASURED_F32_MATRIX_TFLOPS,
             "avg_launch_ms": dom_avg_ms, "median_launch_ms": float(np.median(dom_ms)), "flops_per_launch": dom_flops,
+            # the persistent U-Net launch in its default form issues fewer FLOPs than it is credited with (Winograd): the matrix pipe's own load
+            "issued_mfma_flops_per_launch": unet_issued_flops(B) if dom == UNET_STAGE else None,
+            "issued_mfma_frac_of_peak": unet_issued_flops(B) / (dom_avg_ms * 1e-3) / 1e12 / PEAK_F32_MATRIX_TFLOPS if dom == UNET_STAGE else None,
             # elapsed time of an EMPTY event bracket on the same stream: contained in every *_launch_ms / stage ms of this object
             # (rocprofv3's kernel durations under profiles/ do not contain it)
             "empty_event_bracket_ms": bracket_ms,
-            "note": "fp32-input MFMA (v_mfma_f32_32x32x2_f32) peak; events on the launch stream inside the timed steps (even steps); "
+            "note": "fp32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32) peak; `achieved` / `frac` count the ALGORITHMIC direct-convolution FLOPs of SURVEY 8d -- "
+                    "the launch runs its 3x3 layers as Winograd F(2x2, 3x3) and ISSUES issued_mfma_flops_per_launch; events on the launch stream inside the timed steps (even steps); "
                     "kernel = the longest launch of the step as it is launched: the persistent U-Net launch (twelve layers, "
                     "algorithmic FLOPs of all of them) when that form is in use, else unet.up0.conv1 unless another stage exceeds "
                     "1.15x its time (pick_headline)",

@@ -1350,8 +1350,11 @@ static std::mutex g_side_mutex[64];               // one per device: callers on 
 static SideStream g_side[64];
 SideScope::SideScope(hipStream_t main, bool enable) : main_(main) {
     if (!enable) return;
-    int dev = 0;
+    // the device that OWNS the caller's stream (the null stream belongs to the current device); a caller whose current device is
+    // another one gets the inactive scope: recording this device's events on a foreign stream would fail halfway through the pass
+    int dev = 0, sdev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    if (main && (hipStreamGetDevice(main, &sdev) != hipSuccess || sdev != dev)) return;
     g_side_mutex[dev].lock();
     SideStream* w = &g_side[dev];
     if (!w->ok) {
@@ -1364,7 +1367,9 @@ SideScope::SideScope(hipStream_t main, bool enable) : main_(main) {
     else g_side_mutex[dev].unlock();
 }
 SideScope::~SideScope() {
-    if (side_) g_side_mutex[dev_].unlock();
+    if (!side_) return;
+    if (nfork_ > 0 && njoin_ == 0) (void)join();      // an error path left the side stream forked (inside a capture: unjoined): join it anyway
+    g_side_mutex[dev_].unlock();
 }
 int SideScope::fork() {
     if (!side_) return 0;

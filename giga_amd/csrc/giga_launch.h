@@ -58,7 +58,7 @@ inline void dyn_lds_forget() {
 #define GIGA_LAUNCH(...)                                                                                                       \
     do {                                                                                                                       \
         const unsigned long long giga_n_ = ::giga::g_launch_count.fetch_add(1, std::memory_order_relaxed) + 1;                  \
-        const bool giga_pr_ = giga_n_ == ::giga::g_probe_target.load(std::memory_order_relaxed);                               \
+        const bool giga_pr_ = giga_n_ == ::giga::g_probe_target.load(std::memory_order_acquire);   /* pairs with the release store */ \
         if (giga_pr_) {                                                                                                        \
             const char* giga_nm_ = hipKernelNameRefByPtr(reinterpret_cast<const void*>(GIGA_LAUNCH_ARG1(__VA_ARGS__)),           \
                                                          GIGA_LAUNCH_ARG5(__VA_ARGS__));                                      \

@@ -1,5 +1,6 @@
 """CPU tests: the C-ABI library loads and exports every symbol include/giga_hip.h declares, the
 host-side packer and module tree behave (no compute calls: there is no GPU here)."""
+import ctypes
 import os
 import re
 
@@ -303,3 +304,13 @@ def test_every_header_is_a_build_dependency():
         r = subprocess.run(["make", "-n", "-W", rel], cwd=csrc, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         assert r.stdout.count("hipcc") >= 2 and "-shared" in r.stdout, f"{rel}: a change would not rebuild the library"
+
+
+def test_convin_mask_flag_is_refused_for_precisions_that_store_no_mask():
+    """GIGA_CONVIN_MASK with precision 1 / 2 (f16-class encoders store no ReLU mask): -5 instead of a backward that would read
+    workspace bytes nobody wrote (advisor finding, round 5).  The check precedes every device access."""
+    lib = _capi.lib()
+    fake = ctypes.c_void_p(16)
+    for prec in (1, 2):
+        rc = lib.giga_encoder_forward(fake, fake, fake, None, 1, prec | _capi.CONVIN_MASK, fake, ctypes.c_size_t(1 << 40), None)
+        assert rc == -5, (prec, rc)

@@ -89,7 +89,7 @@ def test_model_forward_g2(net, dev, sd7, golden, prec, tol, kernel):
             net.set_unet_kernel("auto")
     assert qual.shape == (2, 2048) and rot.shape == (2, 2048, 4) and width.shape == (2, 2048) and tsdf.shape == (2, 2048)
     assert maxerr(qual, g["qual"]) < tol
-    assert maxerr(rot, g["rot"]) < tol * (2 if prec == "fp16" else 1)
+    assert maxerr(rot, g["rot"]) < tol * (1.5 if prec == "fp16" else 1)     # fp16: 1.5e-2 (measured 1.0-1.1e-2 with either kernel)
     assert maxerr(width, g["width"]) < tol * 2
     assert maxerr(tsdf, g["tsdf"]) < tol * 2
 
