@@ -237,7 +237,11 @@ __device__ __forceinline__ void wino_run(const ConvArgs& a, uint8_t* smem, int b
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int x = 0; x < 4; ++x)
-                d[r][x] = *reinterpret_cast<const f32x2v*>(region + a_off + r * RS + x * PS + 8 * h);
+                // (volatile LDS access on purpose: left alone, the compiler pairs these into ds_read2_b64, which the LDS serves as 16-lane
+                //  groups over 32 banks -- the four tile rows of a block then collide 4-way, 192 extra LDS cycles per half-chunk, the LDS
+                //  saturated (52.7 M conflict cycles per U-Net launch, profiles/r06/final/pmc.txt).  A plain ds_read_b64 is served as two
+                //  32-lane groups over 64 banks: 2-way here, which tile stride 2 makes the floor for 8-byte reads of this layout)
+                d[r][x] = *(const volatile __attribute__((address_space(3))) f32x2v*)(region + a_off + r * RS + x * PS + 8 * h);
     };
     auto stage_write = [&]() {
 #pragma unroll
