@@ -188,16 +188,16 @@ __device__ __forceinline__ void wino_run(const ConvArgs& a, uint8_t* smem, int b
         unit_coords(u, bx, by, img);
         const int ty = BH * by + tyl, tx = BW * bx + txl;
         const bool ok = j < BW * BH && ty < G::TH && tx < G::TW;
-        // A^T M A on four-channel vectors
+        // A^T M A on four-channel vectors (a - (b + c): the form whose additions the compiler packs)
         f32x4v t0[4], t1[4];
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi) {
             t0[xi] = (acc[4 * xi] + acc[4 * xi + 1]) + acc[4 * xi + 2];
-            t1[xi] = (acc[4 * xi + 1] - acc[4 * xi + 2]) - acc[4 * xi + 3];
+            t1[xi] = acc[4 * xi + 1] - (acc[4 * xi + 2] + acc[4 * xi + 3]);
         }
         f32x4v y[4];
         y[0] = (t0[0] + t0[1]) + t0[2]; y[1] = (t1[0] + t1[1]) + t1[2];
-        y[2] = (t0[1] - t0[2]) - t0[3]; y[3] = (t1[1] - t1[2]) - t1[3];
+        y[2] = t0[1] - (t0[2] + t0[3]); y[3] = t1[1] - (t1[2] + t1[3]);
         const uint32_t pix = (uint32_t)((img * H + 2 * ty) * W + 2 * tx);
         const uint32_t o00 = (pix * COUT + grp * 16 + 4 * g) * 4u;
         if (ok) {

@@ -5,7 +5,8 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"; R=$PWD; export GIGA_COMMIT=${GIGA_COMMIT:-u
 O=$R/gpurun_out/final; mkdir -p $O; export TMPDIR=/tmp PYTHONPATH=$R
 timeout 900 python -m pytest tests -m gpu -q -x > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -n 2 $O/pytest.log
 timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 2 $O/smoke.log
-timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+GIGA_BENCH_EXTRA=$O/bench_extra.json timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+export GIGA_BENCH_EXTRA=/tmp/bench_extra_prof.json      # (the profiled reruns below must not overwrite the side file of the run above)
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -o b -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/prof_bench.log 2>&1 ); echo "rocprof bench rc=$?"
 python tools/prof_summary.py /tmp/prof_bench $O/bench_kernel_stats.txt
 # the same command without the extra legs: the dominant launch's rocprofv3 average in the SAME context as bench.py's HIP events
