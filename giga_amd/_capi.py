@@ -68,7 +68,7 @@ _SIGNATURES = {
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "giga_derive_bf16_fragments": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
-    "giga_derive_winograd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "giga_derive_winograd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "giga_bwd_packed_bytes": (ctypes.c_size_t, []),
     "giga_pack_bwd_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
                                              ctypes.c_size_t]),

@@ -201,19 +201,27 @@ __global__ __launch_bounds__(64) void derive_wino_kernel(uint8_t* fwd, WinoRegio
 
 extern "C" {
 
-/* Winograd images of the fp32 3x3 layers (giga_wino.h) from the fp32 fragments of the same DEVICE blob, after giga_repack_device */
-int giga_derive_winograd(void* packed_dev, void* stream) {
-    if (!packed_dev) return -1;
+/* Winograd images of the fp32 3x3 layers (giga_wino.h) from the fp32 fragments of the same DEVICE blob, after giga_repack_device:
+ * the forward blob's (the layers themselves) and / or the backward blob's (their data-gradient convolutions: the same fragment layout
+ * with the channels swapped) -- either pointer may be NULL */
+int giga_derive_winograd(void* packed_dev, void* bwd_packed_dev, void* stream) {
+    if (!packed_dev && !bwd_packed_dev) return -1;
     const PackOff ko = pack_offsets();
-    WinoRegions w{};
-    int nw = 0;
-    for (int l = 0; l < NCONV; ++l) {
-        const ConvLayerDesc& cd = kConv[l];
-        w.src[l] = ko.conv[l].w32; w.dst[l] = ko.conv[l].wino; w.first[l] = nw; w.cin[l] = cd.cin0 + cd.cin1;
-        if (cd.kind == CONV3) nw += (cd.cin0 + cd.cin1) * cd.cout / 8;           // 512-byte pieces of the layer's image
+    const BwdPackOff bo = bwd_pack_offsets();
+    for (int pass = 0; pass < 2; ++pass) {
+        void* dst = pass ? bwd_packed_dev : packed_dev;
+        if (!dst) continue;
+        WinoRegions w{};
+        int nw = 0;
+        for (int l = 0; l < NCONV; ++l) {
+            const ConvLayerDesc& cd = kConv[l];
+            w.src[l] = pass ? bo.conv[l] : ko.conv[l].w32; w.dst[l] = pass ? bo.wino[l] : ko.conv[l].wino; w.first[l] = nw;
+            w.cin[l] = pass ? cd.cout : cd.cin0 + cd.cin1;                            // channels IN of the convolution the image is for
+            if (cd.kind == CONV3) nw += (cd.cin0 + cd.cin1) * cd.cout / 8;           // 512-byte pieces of the layer's image
+        }
+        w.first[NCONV] = nw;
+        GIGA_LAUNCH(derive_wino_kernel, dim3(nw), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<uint8_t*>(dst), w);
     }
-    w.first[NCONV] = nw;
-    GIGA_LAUNCH(derive_wino_kernel, dim3(nw), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<uint8_t*>(packed_dev), w);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 

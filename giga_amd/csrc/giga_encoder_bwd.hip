@@ -10,6 +10,7 @@
 // Weight/bias gradients are ACCUMULATED into the flat fp32 gradient buffer (reference state-dict order) with
 // fp32 atomics (summation order is not fixed, as with PyTorch's own CUDA/HIP backward kernels).
 #include "giga_conv16.h"
+#include "giga_wino.h"
 #include <functional>
 #include <mutex>
 
@@ -1420,6 +1421,7 @@ int enc_nxp(int B);
 
 // MATH: arithmetic of the thirteen data-gradient convolutions (MATH_NATIVE fp32 MFMA, or MATH_BF16: bf16 operands from the
 // backward blob's bf16 images, fp32 accumulate and fp32 gradients in memory); everything else is fp32.
+template <int V> using IC = std::integral_constant<int, V>;
 template <int MATH>
 static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const uint8_t* bwd_blob, const uint8_t* fws,
                                  float* gplanes /* [3B][40][40][32], in: dLoss/dPlanes, clobbered */, uint8_t* gws,
@@ -1561,45 +1563,65 @@ static int encoder_backward_impl(const float* tsdf, const uint8_t* blob, const u
         wgrad3(2, G(g.gA1), F(f.Q0), nullptr, 20);
         wgrad3(1, G(g.gS0), F(f.A0), nullptr, 40);
         wgrad3(0, G(g.gA0), F(f.P0), nullptr, 40);
-    } else {
+    }
+    // stage k of the chain is the data gradient of U-Net layer 12 - k
+    static constexpr int LAYER_OF_STAGE[13] = {12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0};
+    // fp32 step: the data gradients of the 3x3 layers are stride-1 3x3 convolutions too (flipped taps, channels swapped) and run as
+    // Winograd F(2x2, 3x3) on the images giga_derive_winograd leaves behind the backward blob's other regions (giga_wino.h; the ReLU
+    // mask of the layer below in the epilogue as before).  GIGA_WINOGRAD_BWD=0: the direct conv16 kernels.
+    static const int env_wino_bwd = [] { const char* e = getenv("GIGA_WINOGRAD_BWD"); return e ? atoi(e) : 1; }();
+    constexpr bool CAN_WINO_BWD = MATH == MATH_NATIVE;
+    const bool wino_bwd = CAN_WINO_BWD && env_wino_bwd != 0;
+    auto dgrad3 = [&](auto c0, auto cout, auto hw, auto nb, int stage, int layer) {
+        constexpr int C0 = decltype(c0)::value, COUT = decltype(cout)::value, HW = decltype(hw)::value, NB = decltype(nb)::value;
+        if constexpr (CAN_WINO_BWD) {
+            if (wino_bwd) {
+                ConvArgs a = M.layer[stage];
+                a.w = bwd_blob + bo.wino[layer];
+                return launch_wino<C0, 0, COUT, HW, HW, false, false>(a, s);
+            }
+        }
+        return launch_conv<float, CONV3, C0, 0, COUT, HW, HW, NB, false, false, MATH>(M.layer[stage], s);
+    };
+    if (mega <= 0) {
         // one launch per stage, the weight gradient of a layer right behind the launch that produced its dPre (it is still in the
         // Infinity Cache then)
         wgrad3(12, gplanes, F(f.A6), nullptr, 40);
         rc |= launch_conv<float, CONV1, 32, 0, 32, 40, 40, 2, false, false, MATH>(M.layer[0], s);
         wgrad3(11, G(g.gA6), F(f.A5), nullptr, 40);
-        rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(M.layer[1], s);
+        rc |= dgrad3(IC<32>{}, IC<32>{}, IC<40>{}, IC<2>{}, 1, LAYER_OF_STAGE[1]);
         wgrad3(10, G(g.gA5), F(f.U1), F(f.S0), 40);
-        rc |= launch_conv<float, CONV3, 32, 0, 64, 40, 40, 2, false, false, MATH>(M.layer[2], s);
+        rc |= dgrad3(IC<32>{}, IC<64>{}, IC<40>{}, IC<2>{}, 2, LAYER_OF_STAGE[2]);
         wgrad_up(9, F(f.A4), G(g.gC1), 64, 20);
         rc |= launch_conv<float, DOWN, 32, 0, 64, 20, 20, 2, false, false, MATH>(M.layer[3], s);
         wgrad3(8, G(g.gA4), F(f.A3), nullptr, 20);
-        rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false, MATH>(M.layer[4], s);
+        rc |= dgrad3(IC<64>{}, IC<64>{}, IC<20>{}, IC<1>{}, 4, LAYER_OF_STAGE[4]);
         wgrad3(7, G(g.gA3), F(f.U0), F(f.S1), 20);
-        rc |= launch_conv<float, CONV3, 64, 0, 128, 20, 20, 1, false, false, MATH>(M.layer[5], s);
+        rc |= dgrad3(IC<64>{}, IC<128>{}, IC<20>{}, IC<1>{}, 5, LAYER_OF_STAGE[5]);
         wgrad_up(6, F(f.S2), G(g.gC0), 128, 10);
         rc |= launch_conv<float, DOWN, 64, 0, 128, 10, 10, 1, false, false, MATH>(M.layer[6], s);
         wgrad3(5, G(g.gS2), F(f.A2), nullptr, 10);
-        rc |= launch_conv<float, CONV3, 128, 0, 128, 10, 10, 1, false, false, MATH>(M.layer[7], s);
+        rc |= dgrad3(IC<128>{}, IC<128>{}, IC<10>{}, IC<1>{}, 7, LAYER_OF_STAGE[7]);
         wgrad3(4, G(g.gA2), F(f.Q1), nullptr, 10);
-        rc |= launch_conv<float, CONV3, 128, 0, 64, 10, 10, 1, false, false, MATH>(M.layer[8], s);
+        rc |= dgrad3(IC<128>{}, IC<64>{}, IC<10>{}, IC<1>{}, 8, LAYER_OF_STAGE[8]);
         {
             const size_t tot = n20 * 64 / 4;
             GIGA_LAUNCH(pool_bwd_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, G(g.gS1),
                                G(g.gC0), 128, 64, G(g.gQ1), F(f.S1), F(f.Q1), nimg, 20, 20, 64);
         }
         wgrad3(3, G(g.gS1), F(f.A1), nullptr, 20);
-        rc |= launch_conv<float, CONV3, 64, 0, 64, 20, 20, 1, false, false, MATH>(M.layer[9], s);
+        rc |= dgrad3(IC<64>{}, IC<64>{}, IC<20>{}, IC<1>{}, 9, LAYER_OF_STAGE[9]);
         wgrad3(2, G(g.gA1), F(f.Q0), nullptr, 20);
-        rc |= launch_conv<float, CONV3, 64, 0, 32, 20, 20, 2, false, false, MATH>(M.layer[10], s);
+        rc |= dgrad3(IC<64>{}, IC<32>{}, IC<20>{}, IC<2>{}, 10, LAYER_OF_STAGE[10]);
         {
             const size_t tot = n40 * 32 / 4;
             GIGA_LAUNCH(pool_bwd_add_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, G(g.gS0),
                                G(g.gC1), 64, 32, G(g.gQ0), F(f.S0), F(f.Q0), nimg, 40, 40, 32);
         }
         wgrad3(1, G(g.gS0), F(f.A0), nullptr, 40);
-        rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(M.layer[11], s);
+        rc |= dgrad3(IC<32>{}, IC<32>{}, IC<40>{}, IC<2>{}, 11, LAYER_OF_STAGE[11]);
         wgrad3(0, G(g.gA0), F(f.P0), nullptr, 40);
-        rc |= launch_conv<float, CONV3, 32, 0, 32, 40, 40, 2, false, false, MATH>(M.layer[12], s);
+        rc |= dgrad3(IC<32>{}, IC<32>{}, IC<40>{}, IC<2>{}, 12, LAYER_OF_STAGE[12]);
     }
     flush();
     rc |= launch_wgrad3_reduce_all(RED, ws);

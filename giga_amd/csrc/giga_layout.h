@@ -227,6 +227,7 @@ struct BwdPackOff {
     size_t dec[NHEADS];          // transposed decoder matrices of head h
     size_t convbf[NCONV];        // bf16 images of the dgrad fragments (f16 fragment layout, nfrag[l] / 2 fragments)
     size_t dect[NHEADS];         // bf16 transposed decoder matrices of the bf16 training decoder (giga_dect.h), derived from dec
+    size_t wino[NCONV];          // Winograd images of the 3x3 layers' DATA-GRADIENT convolutions (giga_wino.h; cin' = cout, cout' = cin, taps flipped)
     size_t stamp;                // PackStamp
     size_t total;
 };
@@ -248,6 +249,10 @@ inline BwdPackOff bwd_pack_offsets() {
     for (int h = 0; h < NHEADS; ++h) { o.dec[h] = at; at += DECB_BYTES; }
     for (int l = 0; l < NCONV; ++l) { o.convbf[l] = at; at += (size_t)(o.nfrag[l] / 2) * FRAG; }
     for (int h = 0; h < NHEADS; ++h) { o.dect[h] = at; at += (size_t)(NBLK * 10 + 1) * FRAG; }  // DECT_BWD_BYTES (giga_dect.h)
+    for (int l = 0; l < NCONV; ++l) {                                                            // round 6 (ABI 3)
+        o.wino[l] = at;
+        if (kConv[l].kind == CONV3) at += (size_t)16 * (kConv[l].cin0 + kConv[l].cin1) * kConv[l].cout * sizeof(float);
+    }
     o.stamp = at; at += 256;
     o.total = at;
     return o;

@@ -406,6 +406,35 @@ static void pack_conv_dgrad(const float* P, const ParamOff& po, const BwdPackOff
                 }
 }
 
+// Winograd image of the DATA-GRADIENT convolution of a 3x3 layer (giga_wino.h): the convolution with cin' = cout, cout' = cin and
+// W'[co'][ci'][tap'] = W[ci'][co'][8 - tap'] (pack_conv_dgrad), U' = G g' G^T summed over tap' in the order the device derive uses
+// (giga_capi.hip::derive_wino_block on the backward blob's fp32 fragments), so both images are bit-identical.
+static void pack_wino_dgrad(const float* P, const ParamOff& po, const BwdPackOff& bo, int l, uint8_t* blob) {
+    const ConvLayerDesc& d = kConv[l];
+    if (d.kind != CONV3) return;
+    const float* W = P + po.conv_w[l];
+    const int cinp_ = d.cout, coutp_ = d.cin0 + d.cin1;                   // the data-gradient convolution's channels in / out
+    const int kp = cinp_ > 64 ? cinp_ / 64 : 1, cinp = cinp_ / kp, nchunk = cinp / 16;
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    float* out = reinterpret_cast<float*>(blob + bo.wino[l]);
+    size_t at = 0;
+    for (int grp = 0; grp < coutp_ / 16; ++grp)
+        for (int k = 0; k < kp; ++k)
+            for (int pos = 0; pos < 16; ++pos)
+                for (int cc = 0; cc < nchunk; ++cc)
+                    for (int h = 0; h < 2; ++h)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 2; ++e, ++at) {
+                                const int cop = 16 * grp + (lane & 15), cip = cinp * k + 16 * cc + 4 * (lane >> 4) + 2 * h + e;
+                                const int xi = pos >> 2, nu = pos & 3;
+                                double u = 0.0;
+                                for (int ky = 0; ky < 3; ++ky)
+                                    for (int kx = 0; kx < 3; ++kx)
+                                        u += G[xi][ky] * G[nu][kx] * (double)conv_w_at(W, d, cip, cop, 8 - (ky * 3 + kx));
+                                out[at] = (float)u;
+                            }
+}
+
 // transposed decoder matrices for the backward chain (giga_decoder_bwd.hip):
 //   fragment order per block b: Wc_b^T (3 row blocks of 32 input features x 4 frags), W0_b^T (4), W1_b^T (4)
 //   A-operand fragment q of a transposed 32x32 matrix M^T: lane (i, hi), float j -> M[drow(4q+j, hi)][i]
@@ -440,7 +469,7 @@ int pack_bwd_host(const float* P, size_t n_params, int head_present, uint8_t* bl
     if (n_params != po.total) return -2;
     if (blob_bytes < bo.total) return -3;
     std::memset(blob, 0, bo.total);
-    for (int l = 0; l < NCONV; ++l) pack_conv_dgrad(P, po, bo, l, blob);
+    for (int l = 0; l < NCONV; ++l) { pack_conv_dgrad(P, po, bo, l, blob); pack_wino_dgrad(P, po, bo, l, blob); }
     for (int h = 0; h < NHEADS; ++h)
         if (head_present >> h & 1) {
             pack_head_bwd(P, po.head[h], HEAD_OUT[h], blob + bo.dec[h]);

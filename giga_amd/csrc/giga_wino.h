@@ -212,6 +212,10 @@ __device__ __forceinline__ void wino_run(const ConvArgs& a, uint8_t* smem, int b
                     if (RELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) y[e][r] = relu(y[e][r]);
+                    } else if (a.mask) {             // data-gradient convolutions: the ReLU backward of the layer below, fused (ConvArgs::mask)
+                        const f32x4v mk = *reinterpret_cast<const f32x4v*>(reinterpret_cast<const char*>(a.mask) + off);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[e][r] = mk[r] > 0.f ? y[e][r] : 0.f;
                     }
                 }
                 store_f32x4(outp, off, y[e]);

@@ -98,8 +98,10 @@ class _TrainState:
         if self.bf16:                   # bf16 images of the convolution fragments, from the fp32 fragments just rebuilt
             _capi.check(L.giga_derive_bf16_fragments(_capi.ptr(self.blob), _capi.ptr(self.bwd_blob), s),
                         "giga_derive_bf16_fragments")
-        if (_capi.ENC_BF16 if self.bf16 else 0) == 0:     # an fp32 forward runs its 3x3 layers as Winograd F(2x2, 3x3): their images, from the same fragments
-            _capi.check(L.giga_derive_winograd(_capi.ptr(self.blob), s), "giga_derive_winograd")
+        fwd32 = (_capi.ENC_BF16 if self.bf16 else 0) == 0          # an fp32 forward / an fp32 data-gradient chain run their 3x3 layers as
+        if fwd32 or not self.bf16:                                 # Winograd F(2x2, 3x3): their images, from the fragments just rebuilt
+            _capi.check(L.giga_derive_winograd(_capi.ptr(self.blob) if fwd32 else None,
+                                               _capi.ptr(self.bwd_blob) if not self.bf16 else None, s), "giga_derive_winograd")
         if key != self._wkey:
             self.repacks += 1
         self._wkey = key

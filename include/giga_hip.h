@@ -231,9 +231,11 @@ int giga_decoder_forward_lattice(const void* planes_nhwc, const float* lin, cons
  * giga_repack_device (either pointer may be NULL).  giga_pack_weights / giga_pack_bwd_weights fill them on the host too. */
 int giga_derive_bf16_fragments(void* packed_dev, void* bwd_packed_dev, void* stream);
 /* The Winograd-domain images of the fp32 3x3 layers (csrc/giga_wino.h), derived ON THE DEVICE from the fp32 fragments of the same blob
- * after giga_repack_device: U = G g G^T accumulated in double in the host packer's order -- bit-identical to giga_pack_weights'.
- * A precision-0 forward on a device-repacked blob needs it unless the call carries GIGA_DIRECT_CONV. */
-int giga_derive_winograd(void* packed_dev, void* stream);
+ * after giga_repack_device: U = G g G^T accumulated in double in the host packer's order -- bit-identical to giga_pack_weights' /
+ * giga_pack_bwd_weights'.  packed_dev: the forward blob (a precision-0 forward on a device-repacked blob needs it unless the call carries
+ * GIGA_DIRECT_CONV); bwd_packed_dev: the backward blob (the fp32 data-gradient chain of giga_backward runs its 3x3 layers as Winograd
+ * too unless GIGA_WINOGRAD_BWD=0 is set in the environment).  Either may be NULL. */
+int giga_derive_winograd(void* packed_dev, void* bwd_packed_dev, void* stream);
 size_t giga_bwd_packed_bytes(void);
 int giga_pack_bwd_weights(const float* params_host, size_t n_params, int head_present, void* packed_host,
                           size_t packed_bytes);

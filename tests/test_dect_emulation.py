@@ -29,7 +29,7 @@ def _images(sd):
     up = lambda x: (x + 255) // 256 * 256  # noqa: E731
     wino = 16 * 48128 * 4           # round 6: the Winograd images of the ten 3x3 layers (sum of cin * cout = 48 128) sit between them and the stamp
     fwd = [blob[blob.size - 256 - wino - (4 - h) * up(FWD_BYTES):][:FWD_BYTES] for h in range(4)]   # the last regions of both blobs (before the stamp)
-    bwd = [bblob[bblob.size - 256 - (4 - h) * BWD_BYTES:][:BWD_BYTES] for h in range(4)]
+    bwd = [bblob[bblob.size - 256 - wino - (4 - h) * BWD_BYTES:][:BWD_BYTES] for h in range(4)]
     return fwd, bwd
 
 

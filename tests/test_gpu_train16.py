@@ -114,8 +114,8 @@ def test_bf16_decoder_images_derived_on_the_device_equal_the_host_packer(sd7):
     wino = 16 * 48128 * 4                                    # behind the forward blob's decoder images: the Winograd images of the ten 3x3
     fe = -256 - wino                                         # layers (round 6, sum of cin * cout = 48 128), then the 256-byte stamp of a host blob
     assert torch.equal(st.blob.cpu()[fe - nf:fe], host_fwd[fe - nf:fe])
-    assert torch.equal(st.bwd_blob.cpu()[-nb - 256:-256], host_bwd[-nb - 256:-256])
-    assert host_fwd[fe - nf:fe].any() and host_bwd[-nb - 256:-256].any()
+    assert torch.equal(st.bwd_blob.cpu()[fe - nb:fe], host_bwd[fe - nb:fe])          # (the backward blob ends likewise: data-gradient Winograd images, stamp)
+    assert host_fwd[fe - nf:fe].any() and host_bwd[fe - nb:fe].any()
 
 
 def test_bf16_decoder_is_deterministic(sd7):

@@ -253,9 +253,12 @@ def test_bf16_training_step(sd7, monkeypatch):
     wino = sum(16 * ci * co * 4 for k, ci, co in conv if k == 0)    # round 6: the Winograd images of the 3x3 layers (giga_wino.h)
     n = st.blob.numel() - 4 * 59 * 1024 - wino - 256         # (behind: the bf16 decoder images of round 5 -- test_gpu_train16.py --, the Winograd images and the stamp)
     w0 = st.blob.numel() - 256 - wino
-    _capi.check(_capi.lib().giga_derive_winograd(_capi.ptr(st.blob), _capi.stream_ptr(dev)), "giga_derive_winograd")   # (the fp32 step's derive)
+    _capi.check(_capi.lib().giga_derive_winograd(_capi.ptr(st.blob), _capi.ptr(st.bwd_blob), _capi.stream_ptr(dev)), "giga_derive_winograd")   # (the fp32 step's derive)
     torch.cuda.synchronize()
     assert torch.equal(st.blob.cpu()[w0:w0 + wino], host_fwd[w0:w0 + wino]), "device-derived Winograd images != host pack (bit for bit)"
+    wb = st.bwd_blob.numel() - 256 - wino                      # (the backward blob ends the same way: Winograd images of the data-gradient convolutions, stamp)
+    assert torch.equal(st.bwd_blob.cpu()[wb:wb + wino], host_bwd[wb:wb + wino]), "device-derived data-gradient Winograd images != host pack"
+    assert host_bwd[wb:wb + wino].any()
     assert torch.equal(st.blob.cpu()[n - c32 - tail:n - c32], host_fwd[n - c32 - tail:n - c32]), \
         "device repack + derive != host pack (forward bf16 fragments)"
     assert torch.equal(st.bwd_blob.cpu()[:-256], host_bwd[:-256]), "device repack + derive != host pack (backward blob)"   # (last 256 B: the host blob's stamp)
