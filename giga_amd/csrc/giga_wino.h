@@ -47,13 +47,13 @@ constexpr int wino_kpass(int cin) { return cin > 64 ? cin / 64 : 1; }
 template <int C0, int C1, int H, int W>
 constexpr int wino_nw() {                         // waves per workgroup: WINO_NW unless weights + patches would not fit the 160 KiB LDS
     constexpr int CINP = (C0 + C1) / wino_kpass(C0 + C1);
-    constexpr int fit = (160 * 1024 - 16 - 16 * CINP * 16 * 4) / WinoBlock<H, W>::REGION;
+    constexpr int fit = (160 * 1024 - 16 * CINP * 16 * 4) / WinoBlock<H, W>::REGION;
     return fit >= WINO_NW ? WINO_NW : (fit / 2) * 2;
 }
 template <int C0, int C1, int H, int W>
 constexpr size_t wino_lds_bytes() {
     constexpr int CINP = (C0 + C1) / wino_kpass(C0 + C1);
-    return (size_t)16 * CINP * 16 * 4 + (size_t)wino_nw<C0, C1, H, W>() * WinoBlock<H, W>::REGION + 16;      // + the unit counter
+    return (size_t)16 * CINP * 16 * 4 + (size_t)wino_nw<C0, C1, H, W>() * WinoBlock<H, W>::REGION;
 }
 // Winograd weight image of a layer (giga_pack.cpp::pack_wino): [grp = cout / 16][kpass][pos 16][chunk of 16 ci][half 2][lane 64][2 floats]
 //   value = U[pos][ci = 64 * kpass + 16 * chunk + 4 * (lane >> 4) + 2 * half + e][co = 16 * grp + (lane & 15)],  U = G g G^T
@@ -102,14 +102,14 @@ __device__ __forceinline__ void wino_run(const ConvArgs& a, uint8_t* smem, int b
     uint8_t* region = smem + WBYTES + (active ? wave : 0) * REGION;
     const ConvWgMap wm = conv_wg_map<NGRP>(a, block, nblocks);
     const int grp = wm.grp, wg_in_grp = wm.wg_in_grp, wgs_per_grp = wm.wgs_per_grp;
-    // Units are handed out DYNAMICALLY inside a workgroup: it owns a contiguous, balanced range [ulo, uhi) of its weight group's
-    // units, every wave starts on ulo + wave and draws the next one from an LDS counter.  A static stride leaves the SIMDs of a CU
-    // with 6 / 5.5 / 5 / 5 units of 4.7 on average at 32 scenes (the first waves of every workgroup get the remainder).
+    // A workgroup owns a contiguous, balanced range [ulo, uhi) of its weight group's units and deals them round-robin over its waves:
+    // wave w takes ulo + w, ulo + w + 8, ...  Waves w and w + 4 share a SIMD (a workgroup's waves go to the SIMDs cyclically), and the
+    // two waves of a SIMD share its matrix pipe, so what counts is units per SIMD: round-robin gives 5 / 5 / 5 / 4 for 19 units and
+    // 3 / 3 / 3 / 3 for 12 -- the optimum.  (Measured equal: units drawn from an LDS counter, 230.4 vs 229.9 us per U-Net launch; a stride
+    // over ALL workgroups' waves, conv16's, puts every remainder on the first waves of each workgroup: 6 / 5.5 / 5 / 5.)
     const int units_all = wm.nimg * G::TYB * G::TXB;
     const int ulo = (int)((long long)units_all * wg_in_grp / wgs_per_grp), uhi = (int)((long long)units_all * (wg_in_grp + 1) / wgs_per_grp);
     const int units = uhi;
-    int* counter = reinterpret_cast<int*>(smem + WBYTES + NWV * REGION);
-    if (threadIdx.x == 0) *counter = ulo + NWV;
     const bool klast = kpass == KP - 1;
 
     // this lane's tile inside the block (lanes beyond the block's tiles shadow tile 0 and store nothing)
@@ -123,7 +123,8 @@ __device__ __forceinline__ void wino_run(const ConvArgs& a, uint8_t* smem, int b
     // every ds_write is unconditional and nobody zero-fills; a chunk's loads are `per-unit offset register + chunk offset in an SGPR`.
     const int v16 = (lane & 3) * 16;
     const uint32_t rowb = (uint32_t)(a.cs0 ? a.cs0 : C0) * 4;          // bytes per pixel of the source tensors (launch_wino: both alike)
-    constexpr uint32_t OOB = 0xFFFFFFF0u;
+    constexpr uint32_t OOB = 0x80000000u;             // beyond every source tensor (launch_wino: < 2 GiB) whether or not the hardware's range
+                                                      // check adds the SGPR chunk offset, and far from wrapping when it is added
     int st_lds[NLD];
     uint32_t st_rel[NLD];                              // byte offset of the vector from the patch origin's pixel, in the source tensor
 #pragma unroll
@@ -308,9 +309,7 @@ __device__ __forceinline__ void wino_run(const ConvArgs& a, uint8_t* smem, int b
     load_d(0);
     // unit loop (runtime, uniform); the chunk loop inside is unrolled: what rides in which burst is known at compile time
     while (true) {
-        int drawn = 0;
-        if (lane == 0) drawn = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int un = __builtin_amdgcn_readfirstlane(drawn);        // (needed at the middle of chunk NCHUNK - 2's second burst)
+        const int un = u + NWV;
         const bool more = un < units;
 #pragma unroll
         for (int cc = 0; cc < NCHUNK; ++cc) {
@@ -391,8 +390,6 @@ __device__ __forceinline__ void up_run(const ConvArgs& a, uint8_t* smem, int blo
     const int npix = wm.nimg * H * W, p0 = wm.img0 * H * W;      // this workgroup's pixel range of the input tensor
     const int units_all = (npix + 15) / 16;
     const int ulo = (int)((long long)units_all * wm.wg_in_grp / wm.wgs_per_grp), uhi = (int)((long long)units_all * (wm.wg_in_grp + 1) / wm.wgs_per_grp);
-    int* counter = reinterpret_cast<int*>(smem + 4 * KG * FRAG);
-    if (threadIdx.x == 0) *counter = ulo + NWV;
     const uint32_t rowb = (uint32_t)(a.cs0 ? a.cs0 : CIN) * 4;
     const char* in = reinterpret_cast<const char*>(a.in0) + (size_t)a.co0 * 4 + 16 * g;
     f32x4v x[2][KG];                                              // B operands of this and of the next unit
@@ -434,16 +431,13 @@ __device__ __forceinline__ void up_run(const ConvArgs& a, uint8_t* smem, int blo
                 store_f32x4(outp, o00 + (uint32_t)(((sub >> 1) * 2 * W + (sub & 1)) * COUT * 4), acc[sub]);
         }
     };
-    while (true) {
-        int drawn = 0;
-        if (lane == 0) drawn = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int un = __builtin_amdgcn_readfirstlane(drawn);
+    while (true) {                                                 // units dealt round-robin over the waves (see wino_run), two in flight
+        const int un = u + NWV;
         const bool more = un < uhi;
         if (more) issue(un, x[1]);
         unit(u, x[0]);
         if (!more) break;
-        const int un2 = [&] { int d2 = 0; if (lane == 0) d2 = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                              return __builtin_amdgcn_readfirstlane(d2); }();
+        const int un2 = un + NWV;
         const bool more2 = un2 < uhi;
         if (more2) issue(un2, x[0]);
         unit(un, x[1]);
@@ -452,7 +446,7 @@ __device__ __forceinline__ void up_run(const ConvArgs& a, uint8_t* smem, int blo
     }
 }
 template <int CIN, int COUT>
-constexpr size_t up_lds_bytes() { return (size_t)4 * (CIN / 16) * FRAG + 16; }
+constexpr size_t up_lds_bytes() { return (size_t)4 * (CIN / 16) * FRAG; }
 template <int CIN, int COUT, int H, int W>
 __global__ __launch_bounds__(WINO_NW * 64) void up_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -484,6 +478,7 @@ inline int launch_wino(const ConvArgs& a, hipStream_t s) {
     static_assert(256 % NGRP == 0, "weight groups must divide the CU count");
     const size_t in_pix = (size_t)a.nimg * H * W;
     if (C1 > 0 && (a.cs0 ? a.cs0 : C0) != (a.cs1 ? a.cs1 : C1)) return -7;              // one pixel stride for both sources (wino_run)
+    if (in_pix * (size_t)((a.cs0 ? a.cs0 : C0) * 4) >= (1ull << 31)) return -7;           // the buffer loads' out-of-range sentinel is 2 GiB
     if (in_pix >= (1u << 24) || in_pix * (size_t)((a.cs0 ? a.cs0 : C0) * 4) >= (1ull << 32) ||
         (C1 > 0 && in_pix * (size_t)((a.cs1 ? a.cs1 : C1) * 4) >= (1ull << 32)) || in_pix * COUT * 4 >= (1ull << 32)) return -7;
     const int units = a.nimg * G::TXB * G::TYB;
