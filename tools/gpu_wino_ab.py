@@ -1,5 +1,5 @@
-"""Winograd F(2x2, 3x3) vs the direct 3x3 convolutions of the fp32 U-Net (csrc/giga_wino.h): planes against each other and against the
-CPU oracle, per-stage HIP-event times in both forms.
+"""Winograd F(2x2, 3x3) vs the direct 3x3 convolutions of the fp32 U-Net (csrc/giga_wino.h): planes against each other (the comparison
+with the CPU oracle lives with the tests: tests/test_gpu_wino.py, tests/diag/gpu_wino_diag.py), per-stage HIP-event times in both forms.
     PYTHONPATH=. python tools/gpu_wino_ab.py [B]"""
 import ctypes
 import sys
@@ -27,15 +27,9 @@ with torch.no_grad():
             torch.cuda.synchronize()
             res[(form, kern)] = nchw.float().cpu()
             print(f"launch form {form!r:9} kernel {kern:7} path flags {L.giga_encoder_last_path()}")
-    from oracle import giga_oracle as O
-    ref = O.encoder_forward(sd, x[:2].cpu()) if hasattr(O, "encoder_forward") else None
 for k, v in res.items():
     d = (v - res[("layers", "direct")]).abs().max().item()
     print(f"{k}: max |planes - direct per-layer| = {d:.3e}  (planes max {v.abs().max().item():.3f})")
-if ref is not None:
-    for k, v in res.items():
-        e = max((v[i, :2] - ref[name]).abs().max().item() for i, name in enumerate(("xz", "xy", "yz")))
-        print(f"{k}: max |planes - oracle| (2 scenes) = {e:.3e}")
 ev = (L.giga_event_create(), L.giga_event_create())
 ms = ctypes.c_float()
 pos = torch.from_numpy(synth.query_points(0, B, 1, stream=2)).to(dev)
