@@ -107,3 +107,24 @@ def test_wino_emulation_matches_torch(sd7, layer):
     assert err < 2e-5 * max(1.0, np.abs(want).max()), f"layer {layer}: {err:.3e}"
     # every output element written (random data: exact zeros do not occur)
     assert (got != 0).all()
+
+
+@pytest.mark.parametrize("layer", [1, 3, 7, 10])
+def test_wino_data_gradient_emulation_matches_autograd(sd7, layer):
+    """The fp32 training step runs the 3x3 layers' DATA gradients on the same kernel with the Winograd images of the flipped / transposed
+    weights that end the backward blob (giga_pack.cpp::pack_wino_dgrad; channels in = the layer's cout, out = its cin): the emulation on
+    that image must reproduce autograd's dX of conv2d (scripts/train_giga.py:208 through encoder/unet.py:14-23)."""
+    c0, c1, cout, H = LAYERS[layer]
+    cin = c0 + c1
+    flat = torch.cat([v.reshape(-1) for v in sd7.values()])
+    blob = _capi.pack_bwd_weights(flat, 15).numpy().tobytes()
+    off = wino_offsets(len(blob))[layer]                       # (same tail layout as the forward blob: images in layer order, then the stamp)
+    rng = np.random.default_rng(200 + layer)
+    dy = rng.standard_normal((1, H, H, cout)).astype(np.float32)
+    got = emulate_layer(blob, off, cout, 0, cin, H, dy)        # a convolution with cout channels in, cin out
+    w = sd7[f"encoder.unet.{KEYS[layer]}.weight"].double()
+    x = torch.zeros((1, cin, H, H), dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w, padding=1).backward(torch.from_numpy(dy).permute(0, 3, 1, 2).double())
+    want = x.grad.permute(0, 2, 3, 1).float().numpy()
+    err = np.abs(got - want).max()
+    assert err < 2e-5 * max(1.0, np.abs(want).max()), f"layer {layer}: {err:.3e}"
