@@ -16,19 +16,23 @@
 //       (256 MFMAs per 32 input channels) on the way out.
 //   Unit = (block of BW x BH tiles <= 16, 16 output channels).  Wave-independent like conv16: a workgroup keeps the Winograd-domain
 //   weights of its 16-channel group resident in LDS (16 positions x CIN x 16 x 4 B, one LDS-DMA fill), every wave walks its own
-//   units: haloed (2BH+2) x (2BW+2) patch of 16 input channels -> wave-private LDS (pixel stride 80 B, row stride chosen so that the
-//   lanes' ds_read hit 16 distinct 16-byte slots: /tmp search in DESIGN 3f), next chunk prefetched in registers, no workgroup barrier.
+//   units (dealt round-robin inside the workgroup): haloed (2BH+2) x (2BW+2) patch of 16 input channels -> wave-private LDS (pixel
+//   stride 80 B, row stride 832 / 1040 B), loads two chunks ahead of the arithmetic, no workgroup barrier.
 //   Inputs wider than 64 channels run as CIN/64 K-PASSES: pass k keeps the weights of channels 64k .. 64k+63 resident, and a wave adds
-//   its units' pre-activation partials of the previous pass (which it wrote itself) before bias / ReLU.
+//   the pre-activation partials the previous pass left in the output (written by a wave of its own workgroup, behind a barrier)
+//   before bias / ReLU.
+//   The same kernel is the DATA-GRADIENT convolution of a 3x3 layer in the fp32 training step (RELU = false: no bias, the ReLU mask of
+//   the layer below in the epilogue; images of the flipped / transposed weights in the backward blob).
 //   fp32 Winograd is not the bitwise fma chain of the direct form: results differ from it at the 1e-6 level (tests hold 1e-4 to the
-//   oracle); GIGA_WINOGRAD=0 / the GIGA_DIRECT_CONV flag keep the direct kernels, and the training forward always does (its device
-//   repack is a pure gather of parameters, the Winograd image is not).
+//   oracle); GIGA_WINOGRAD=0 / the GIGA_DIRECT_CONV flag (forward) and GIGA_WINOGRAD_BWD=0 (data gradients) keep the direct kernels.
+//   A blob rebuilt on the device (training: giga_repack_device is a pure gather of parameters, the Winograd image is not) gets its
+//   images from giga_derive_winograd, bit-identical to the host packer's.
 #pragma once
 #include "giga_conv16.h"
 
 namespace giga {
 
-// layers that run as Winograd by default (bit l = U-Net layer l of giga_layout.h::kConv); settled by measurement, DESIGN 3f
+// layers that run as Winograd by default (bit l = U-Net layer l of giga_layout.h::kConv); settled by measurement
 constexpr unsigned WINO_DEFAULT_MASK = 0xFFF;     // all ten 3x3 layers (0, 1, 2, 3, 4, 5, 7, 8, 10, 11) as Winograd, the two ConvTranspose layers
                                                   // (6, 9) as plain GEMMs on the same lane layout (up_run); profiles/r06/wino_ab_*.txt
 constexpr int WINO_NW = 8;                        // waves per workgroup: two per SIMD, 256 registers each (64 accumulators + 32 transformed
