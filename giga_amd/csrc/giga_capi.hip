@@ -197,7 +197,12 @@ __global__ void repack2_kernel(const float* __restrict__ params, const int32_t* 
     else if (m == -1) words[i] = 0.f;
 }
 
-__global__ __launch_bounds__(64) void derive_wino_kernel(uint8_t* fwd, WinoRegions w) { derive_wino_block(fwd, w, (int)blockIdx.x); }
+// one launch for both blobs: blocks [0, nf) derive the forward blob's images, the rest the backward blob's
+__global__ __launch_bounds__(64) void derive_wino_kernel(uint8_t* fwd, WinoRegions wf, int nf, uint8_t* bwd, WinoRegions wb) {
+    const int b = (int)blockIdx.x;
+    if (b < nf) derive_wino_block(fwd, wf, b);
+    else derive_wino_block(bwd, wb, b - nf);
+}
 
 extern "C" {
 
@@ -208,20 +213,22 @@ int giga_derive_winograd(void* packed_dev, void* bwd_packed_dev, void* stream) {
     if (!packed_dev && !bwd_packed_dev) return -1;
     const PackOff ko = pack_offsets();
     const BwdPackOff bo = bwd_pack_offsets();
+    WinoRegions w[2] = {};
+    int n[2] = {0, 0};
     for (int pass = 0; pass < 2; ++pass) {
-        void* dst = pass ? bwd_packed_dev : packed_dev;
-        if (!dst) continue;
-        WinoRegions w{};
+        if (!(pass ? bwd_packed_dev : packed_dev)) continue;
         int nw = 0;
         for (int l = 0; l < NCONV; ++l) {
             const ConvLayerDesc& cd = kConv[l];
-            w.src[l] = pass ? bo.conv[l] : ko.conv[l].w32; w.dst[l] = pass ? bo.wino[l] : ko.conv[l].wino; w.first[l] = nw;
-            w.cin[l] = pass ? cd.cout : cd.cin0 + cd.cin1;                            // channels IN of the convolution the image is for
+            w[pass].src[l] = pass ? bo.conv[l] : ko.conv[l].w32; w[pass].dst[l] = pass ? bo.wino[l] : ko.conv[l].wino; w[pass].first[l] = nw;
+            w[pass].cin[l] = pass ? cd.cout : cd.cin0 + cd.cin1;                      // channels IN of the convolution the image is for
             if (cd.kind == CONV3) nw += (cd.cin0 + cd.cin1) * cd.cout / 8;           // 512-byte pieces of the layer's image
         }
-        w.first[NCONV] = nw;
-        GIGA_LAUNCH(derive_wino_kernel, dim3(nw), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<uint8_t*>(dst), w);
+        w[pass].first[NCONV] = nw;
+        n[pass] = nw;
     }
+    GIGA_LAUNCH(derive_wino_kernel, dim3(n[0] + n[1]), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<uint8_t*>(packed_dev), w[0], n[0],
+                static_cast<uint8_t*>(bwd_packed_dev), w[1]);
     return hipGetLastError() == hipSuccess ? 0 : -10;
 }
 
