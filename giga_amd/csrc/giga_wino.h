@@ -103,6 +103,7 @@ __device__ __forceinline__ void wino_run(const ConvArgs& a, uint8_t* smem, int b
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
     const bool active = wave < NWV;
+    CONV_T(0);
     uint8_t* region = smem + WBYTES + (active ? wave : 0) * REGION;
     const ConvWgMap wm = conv_wg_map<NGRP>(a, block, nblocks);
     const int grp = wm.grp, wg_in_grp = wm.wg_in_grp, wgs_per_grp = wm.wgs_per_grp;
@@ -183,6 +184,8 @@ __device__ __forceinline__ void wino_run(const ConvArgs& a, uint8_t* smem, int b
     __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): weights (LDS-DMA), first patch chunk and bias landed
     __syncthreads();
     if (!work) return;
+    CONV_T(1);
+    int tcount = 2;                                    // (diagnostic builds: 2 + 2k = unit k's first burst issued, 3 + 2k = its epilogue done)
 
     f32x4v acc[16];
     const uint8_t* wl = smem + lane * 8;               // this lane's 8 bytes of a (position, chunk, half) piece
@@ -320,6 +323,7 @@ __device__ __forceinline__ void wino_run(const ConvArgs& a, uint8_t* smem, int b
             transform();                                              // (cc, 0): raw values were read inside the previous burst
             auto mid0 = [&]() { load_d(1); };
             if (cc == 0) burst(std::true_type{}, cc, 0, mid0); else burst(std::false_type{}, cc, 0, mid0);
+            if (cc == 0) { CONV_T(tcount); ++tcount; }
             transform();                                              // (cc, 1)
             // second burst of the chunk: stage the chunk after it, request the chunk after that, read the first half of the next chunk
             auto mid1 = [&]() {
@@ -337,9 +341,11 @@ __device__ __forceinline__ void wino_run(const ConvArgs& a, uint8_t* smem, int b
             burst(std::false_type{}, cc, 1, mid1);
         }
         epilogue(u);
+        CONV_T(tcount); ++tcount;
         if (!more) break;
         u = un;
     }
+    CONV_T(63);
 }
 
 template <int C0, int C1, int COUT, int H, int W, bool POOL, bool RELU>

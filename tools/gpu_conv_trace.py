@@ -19,7 +19,7 @@ for layer in [int(a) for a in sys.argv[1:]]:
         for _ in range(3):
             net.encoder.encode_nhwc(x)
     torch.cuda.synchronize()
-    buf = np.zeros((12, 64), np.int64)
+    buf = np.zeros((12, 64), np.int64)   # (the Winograd stages of the fp32 path run 8 waves: columns 8..11 stay empty)
     dbg(layer, buf.ctypes.data_as(ctypes.c_void_p))
     t0 = buf[:, 0][buf[:, 0] > 0].min()
     print(f"=== layer {layer}: cycles since first wave entry; rows = events, columns = waves 0..11")
