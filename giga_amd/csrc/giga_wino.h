@@ -216,7 +216,6 @@ __device__ __forceinline__ void wino_run(const ConvArgs& a, uint8_t* smem, int b
                     if (kpass > 0) y[e] += *reinterpret_cast<const f32x4v*>(reinterpret_cast<const char*>(outp) + off);
                 }
                 if (klast) {
-                    y[e] += bias4;
                     if (RELU) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) y[e][r] = relu(y[e][r]);
@@ -291,8 +290,9 @@ __device__ __forceinline__ void wino_run(const ConvArgs& a, uint8_t* smem, int b
         for (int pp = 0; pp < 8; ++pp) {
             const int sl = pp % PD, p0 = 2 * pp, p1 = 2 * pp + 1;
             if constexpr (FIRST) {
+                // (position 5 = (xi 1, nu 1) enters all four outputs of A^T M A with weight +1: the bias rides in its C operand)
                 acc[p0] = mfma32_16(wq[sl][0][0], v[p0][0], f32x4v{0.f, 0.f, 0.f, 0.f});
-                acc[p1] = mfma32_16(wq[sl][1][0], v[p1][0], f32x4v{0.f, 0.f, 0.f, 0.f});
+                acc[p1] = mfma32_16(wq[sl][1][0], v[p1][0], p1 == 5 ? bias4 : f32x4v{0.f, 0.f, 0.f, 0.f});
             } else {
                 acc[p0] = mfma32_16(wq[sl][0][0], v[p0][0], acc[p0]);
                 acc[p1] = mfma32_16(wq[sl][1][0], v[p1][0], acc[p1]);
